@@ -1,0 +1,228 @@
+"""ctypes binding of oracle/librc_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (raycore.jl_amd) never does.  See oracle/rc_oracle.h for what the oracle is and how
+its parity is pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librc_oracle.so")
+
+NODE_DT = np.dtype([("aabb0_min", "<f4", 3), ("aabb0_max", "<f4", 3), ("aabb1_min", "<f4", 3),
+                    ("aabb1_max", "<f4", 3), ("child0", "<u4"), ("child1", "<u4"), ("parent", "<u4")])
+INSTANCE_DT = np.dtype([("blas_index", "<u4"), ("instance_id", "<u4"), ("transform", "<f4", 12),
+                        ("inv_transform", "<f4", 12), ("flags", "<u4")])
+DESC_DT = np.dtype([("nodes_offset", "<u4"), ("primitives_offset", "<u4"), ("root_min", "<f4", 3),
+                    ("root_max", "<f4", 3)])
+TRI_DT = np.dtype([("v", "<f4", (3, 3)), ("meta", "<u4")])
+RAY_DT = np.dtype([("o", "<f4", 3), ("tmin", "<f4"), ("d", "<f4", 3), ("tmax", "<f4")])
+HIT_DT = np.dtype([("hit", "<u4"), ("t", "<f4"), ("primitive_id", "<u4"), ("instance_custom_index", "<u4"),
+                   ("bary_u", "<f4"), ("bary_v", "<f4"), ("instance_id", "<u4"), ("_pad", "<u4")])
+assert NODE_DT.itemsize == 60 and INSTANCE_DT.itemsize == 108 and DESC_DT.itemsize == 32
+assert TRI_DT.itemsize == 40 and RAY_DT.itemsize == 32 and HIT_DT.itemsize == 32
+
+INVALID_NODE = 0xFFFFFFFF
+IDENTITY = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32)
+
+
+def build(force=False):
+    """Compile the oracle with its committed recipe (oracle/Makefile)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(
+            os.path.getmtime(os.path.join(_HERE, f)) for f in ("rc_oracle.c", "rc_oracle.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        vp, u32, u64, i32, f32p = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(C.c_float)
+        L.rco_scene_new.restype = vp
+        L.rco_scene_free.argtypes = [vp]
+        L.rco_scene_add_blas.restype = u32
+        L.rco_scene_add_blas.argtypes = [vp, vp, vp, u32, C.c_int]
+        L.rco_scene_add_instance.argtypes = [vp, u32, u32, vp, vp]
+        L.rco_scene_build.argtypes = [vp]
+        for name in ("tlas_nodes", "instances", "blas_nodes", "blas_prims", "blas_descs"):
+            f = getattr(L, "rco_scene_" + name)
+            f.restype = u32
+            f.argtypes = [vp, vp]
+        L.rco_scene_world_bound.argtypes = [vp, vp]
+        L.rco_scene_blas_morton.restype = u32
+        L.rco_scene_blas_morton.argtypes = [vp, u32, vp]
+        L.rco_closest_hit.argtypes = [vp, vp, vp, vp]
+        L.rco_any_hit.argtypes = [vp, vp, vp, vp]
+        L.rco_trace_batch.argtypes = [vp, vp, vp, u64, C.c_int, C.c_int, vp]
+        L.rco_brute_closest.argtypes = [vp, vp, vp]
+        L.rco_expand_bits.restype = u32
+        L.rco_expand_bits.argtypes = [u32]
+        L.rco_morton_code_30bit.restype = u32
+        L.rco_morton_code_30bit.argtypes = [vp]
+        L.rco_clz32.restype = i32
+        L.rco_clz32.argtypes = [u32]
+        L.rco_delta.restype = i32
+        L.rco_delta.argtypes = [i32, i32, vp, i32]
+        for name in ("mat3x4_inverse", "mat4_to_mat3x4", "safe_invdir"):
+            getattr(L, "rco_" + name).argtypes = [vp, vp]
+        L.rco_transform_point.argtypes = [vp, vp, vp]
+        L.rco_transform_direction.argtypes = [vp, vp, vp]
+        L.rco_is_degenerate.argtypes = [vp]
+        L.rco_philox4x32_10.argtypes = [vp, vp, vp]
+        L.rco_generate_ray_grid.argtypes = [vp, vp, u32, vp]
+        L.rco_get_illumination.argtypes = [vp, vp, u32, vp, C.c_int]
+        L.rco_view_factors.argtypes = [vp, u32, u64, u32, u32, u32, u32, vp, C.c_int]
+        L.rco_view_factor_ray.argtypes = [vp, u32, u32, u64, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a.reshape(shape) if shape is not None else a
+
+
+class Scene:
+    """One-shot StaticTLAS: add_blas per geometry, add_instance, build (== build_tlas)."""
+
+    def __init__(self):
+        self._h = lib().rco_scene_new()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rco_scene_free(self._h)
+            self._h = None
+
+    def add_blas(self, verts, meta=None, filter_degenerate=True):
+        verts = _f32(verts).reshape(-1, 9)
+        m = None if meta is None else np.ascontiguousarray(meta, dtype=np.uint32)
+        idx = lib().rco_scene_add_blas(self._h, _p(verts), _p(m), len(verts), int(filter_degenerate))
+        if idx == 0:
+            raise ValueError("Geometry has no valid triangles")
+        return idx
+
+    def add_instance(self, blas_index, xform=None, instance_id=0, inv=None):
+        x = IDENTITY if xform is None else _f32(xform).reshape(12)
+        i = None if inv is None else _f32(inv).reshape(12)
+        if lib().rco_scene_add_instance(self._h, blas_index, instance_id, _p(x), _p(i)) != 0:
+            raise ValueError("bad blas index")
+
+    def build(self):
+        lib().rco_scene_build(self._h)
+        return self
+
+    def _arr(self, fn, dt):
+        n = fn(self._h, None)
+        out = np.zeros(n, dtype=dt)
+        if n:
+            fn(self._h, _p(out))
+        return out
+
+    @property
+    def tlas_nodes(self):
+        return self._arr(lib().rco_scene_tlas_nodes, NODE_DT)
+
+    @property
+    def instances(self):
+        return self._arr(lib().rco_scene_instances, INSTANCE_DT)
+
+    @property
+    def blas_nodes(self):
+        return self._arr(lib().rco_scene_blas_nodes, NODE_DT)
+
+    @property
+    def blas_prims(self):
+        return self._arr(lib().rco_scene_blas_prims, TRI_DT)
+
+    @property
+    def blas_descs(self):
+        return self._arr(lib().rco_scene_blas_descs, DESC_DT)
+
+    def blas_morton(self, blas_index):
+        n = lib().rco_scene_blas_morton(self._h, blas_index, None)
+        out = np.zeros(n, dtype=np.uint32)
+        lib().rco_scene_blas_morton(self._h, blas_index, _p(out))
+        return out
+
+    @property
+    def world_bound(self):
+        out = np.zeros(6, dtype=np.float32)
+        lib().rco_scene_world_bound(self._h, _p(out))
+        return out
+
+    # ---- traversal ----
+    def trace(self, rays, mode="closest", nthreads=1, counters=False):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DT)
+        hits = np.zeros(len(rays), dtype=HIT_DT)
+        cnt = np.zeros((len(rays), 2), dtype=np.uint32) if counters else None
+        lib().rco_trace_batch(self._h, _p(rays), _p(hits), len(rays), 0 if mode == "closest" else 1, nthreads, _p(cnt))
+        return (hits, cnt) if counters else hits
+
+    def brute(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DT)
+        hits = np.zeros(len(rays), dtype=HIT_DT)
+        for i in range(len(rays)):
+            lib().rco_brute_closest(self._h, _p(rays[i:i + 1]), _p(hits[i:i + 1]))
+        return hits
+
+    # ---- drivers ----
+    def ray_grid(self, viewdir, grid):
+        out = np.zeros(grid * grid, dtype=RAY_DT)
+        lib().rco_generate_ray_grid(self._h, _p(_f32(viewdir)), grid, _p(out))
+        return out
+
+    def get_illumination(self, viewdir, grid, nthreads=1):
+        out = np.zeros(len(self.blas_prims), dtype=np.float32)
+        lib().rco_get_illumination(self._h, _p(_f32(viewdir)), grid, _p(out), nthreads)
+        return out
+
+    def view_factors(self, rays_per_triangle, seed=0, src=None, rays=None, nthreads=1, out=None):
+        n = len(self.blas_prims)
+        if out is None:
+            out = np.zeros((n, n), dtype=np.uint32, order="F")  # Julia Matrix: [src, dst] column-major
+        s0, s1 = (0, n) if src is None else src
+        r0, r1 = (0, rays_per_triangle) if rays is None else rays
+        lib().rco_view_factors(self._h, rays_per_triangle, seed, s0, s1, r0, r1, _p(out), nthreads)
+        return out
+
+    def view_factor_ray(self, src_idx0, ray_idx, seed=0):
+        out = np.zeros(1, dtype=RAY_DT)
+        lib().rco_view_factor_ray(self._h, src_idx0, ray_idx, seed, _p(out))
+        return out[0]
+
+
+def make_rays(origins, directions, tmin=0.0, tmax=np.inf):
+    origins = np.asarray(origins, dtype=np.float32).reshape(-1, 3)
+    directions = np.broadcast_to(np.asarray(directions, dtype=np.float32).reshape(-1, 3), origins.shape)
+    r = np.zeros(len(origins), dtype=RAY_DT)
+    r["o"] = origins
+    r["d"] = directions
+    r["tmin"] = tmin
+    r["tmax"] = tmax
+    return r
+
+
+def mat4_to_mat3x4(m4_colmajor_16):
+    """Julia Mat4f(args...) is column-major: pass the 16 constructor arguments in order."""
+    out = np.zeros(12, dtype=np.float32)
+    lib().rco_mat4_to_mat3x4(_p(_f32(m4_colmajor_16).reshape(16)), _p(out))
+    return out
+
+
+def mat3x4_inverse(m):
+    out = np.zeros(12, dtype=np.float32)
+    lib().rco_mat3x4_inverse(_p(_f32(m).reshape(12)), _p(out))
+    return out
