@@ -1,0 +1,199 @@
+/*
+ * raycore_mi355x.h -- C ABI of the MI355X-native TLAS/BLAS traversal library (libraycore_mi355x.so).
+ *
+ * This is the drop-in boundary for ONE path of JuliaGeometry/Raycore.jl: the two-level BVH build,
+ * closest_hit / any_hit traversal, and the get_illumination / view_factors drivers that sit on it.
+ * The reference has no FFI of its own; its plug-in point is the Julia-level AbstractAccel contract
+ * (src/Raycore.jl:14-49), already implemented by Raycore.TLAS and the external Lava.HWTLAS.  Each entry
+ * point below names the reference function it replaces (paths relative to the reference repo); the
+ * Julia `ccall` binding a maintainer would add is shown in INTEGRATION.md and
+ * raycore.jl_amd/julia/RaycoreMI355X.jl.
+ *
+ * Conventions
+ *  - Every function returns 0 on success, non-zero on error; rc_last_error() returns the message of the
+ *    calling thread's last failure.  No C++ exception crosses this boundary.  The Julia wrapper turns a
+ *    non-zero status into ErrorException (test/test_tlas_stress.jl:585-617 expects that type).
+ *  - The caller owns every host buffer it passes.  The library owns all device memory behind the opaque
+ *    rc_scene handle and frees it in rc_scene_destroy (replaces free!, src/instanced-bvh.jl:383-399).
+ *  - Mutations (rc_add_*, rc_update_*, rc_delete, rc_sync) on one scene must be externally serialised;
+ *    trace calls on a synced scene may run concurrently on distinct HIP streams.  No global mutable state.
+ *  - There is NO CPU fallback: every compute entry point runs hand-written gfx950 HIP kernels and fails
+ *    with RC_ERR_NO_DEVICE when no GPU is present.
+ *  - Index bases at this boundary are 0-based (C); the host wrappers add 1 where the Julia API is 1-based.
+ */
+#ifndef RAYCORE_MI355X_H
+#define RAYCORE_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_OK 0
+#define RC_ERR_INVALID_ARGUMENT 1
+#define RC_ERR_INVALID_HANDLE 2   /* "Invalid handle" / "Handle has been deleted" (src/instanced-bvh.jl:715-716,756-757) */
+#define RC_ERR_NO_DEVICE 3
+#define RC_ERR_HIP 4
+#define RC_ERR_EMPTY_GEOMETRY 5   /* "Geometry has no valid triangles" (src/instanced-bvh.jl:601) */
+#define RC_ERR_NOT_SYNCED 6
+#define RC_ERR_STACK_OVERFLOW 7
+
+#define RC_INVALID_ID 0xFFFFFFFFu
+
+/* Wire structs: byte-identical to RTRay / RTHitResult (src/rt_transport.jl:10-19, 33-42). */
+typedef struct rc_ray {
+    float origin_x, origin_y, origin_z, tmin;
+    float dir_x, dir_y, dir_z, tmax;
+} rc_ray;
+
+/* hit: 1/0.  t: world-ray parameter (direction is NOT renormalised, src/instanced-bvh.jl:1974-1975).
+ * primitive_id: 0-based index into the flat Morton-sorted primitive array (all_blas_prims).
+ * instance_id: 0-based position in the instance array (Julia closest_hit returns this + 1).
+ * instance_custom_index: InstanceDescriptor.instance_id of the hit instance.
+ * bary_u/bary_v: Moeller-Trumbore u, v; Julia's bary = ((1-u)-v, u, v) (src/instanced-bvh.jl:2015-2016).
+ * Miss: hit=0, t=0, bary 0, primitive_id=instance_id=RC_INVALID_ID (Julia: empty triangle, index 0). */
+typedef struct rc_hit {
+    uint32_t hit;
+    float t;
+    uint32_t primitive_id;
+    uint32_t instance_custom_index;
+    float bary_u, bary_v;
+    uint32_t instance_id;
+    uint32_t _pad;
+} rc_hit;
+
+/* Reference-layout records for introspection / parity checks (rc_export_*). */
+typedef struct rc_bvh_node { /* BVHNode2, 60 bytes (src/instanced-bvh.jl:50-63) */
+    float aabb0_min[3], aabb0_max[3], aabb1_min[3], aabb1_max[3];
+    uint32_t child0, child1, parent;
+} rc_bvh_node;
+typedef struct rc_instance_desc { /* InstanceDescriptor, 108 bytes (src/instanced-bvh.jl:90-96) */
+    uint32_t blas_index; /* 1-based, as stored by the reference */
+    uint32_t instance_id;
+    float transform[12];     /* Mat3x4f = Vulkan row-major 3x4 (src/instanced-bvh.jl:28-31) */
+    float inv_transform[12];
+    uint32_t flags;
+} rc_instance_desc;
+typedef struct rc_blas_desc { /* BLASDescriptor, 32 bytes (src/instanced-bvh.jl:132-136) */
+    uint32_t nodes_offset, primitives_offset;
+    float root_min[3], root_max[3];
+} rc_blas_desc;
+typedef struct rc_prim { /* the part of Triangle{UInt32} the path reads (src/triangle_mesh.jl:1-7) */
+    float v[9];
+    uint32_t meta;
+} rc_prim;
+
+typedef struct rc_scene rc_scene; /* opaque; plays the role of the mutable TLAS (src/instanced-bvh.jl:261-310) */
+
+const char* rc_last_error(void);
+/* Number of visible HIP devices (0 when none); never fails. */
+int rc_device_count(void);
+
+/* TLAS(backend) (src/instanced-bvh.jl:334-358).  device = HIP device ordinal. */
+int rc_scene_create(int device, rc_scene** out);
+/* free!(tlas) (src/instanced-bvh.jl:383-399) */
+int rc_scene_destroy(rc_scene* scene);
+
+/* build_and_append_blas! minus the GeometryBasics mesh decomposition (src/instanced-bvh.jl:581-608):
+ * verts = n x 9 f32 triangle soup, meta = n u32 or NULL (=> face index 1..n, assigned BEFORE the
+ * degenerate filter, :595).  Degenerate faces (is_degenerate, src/triangle_mesh.jl:14-17) are dropped,
+ * the LBVH is built on the device (build_blas, :1376-1443).  *blas_id receives the 0-based geometry id. */
+int rc_add_blas(rc_scene* scene, const float* verts, const uint32_t* meta, uint32_t n, uint32_t* blas_id);
+
+/* push!(tlas, mesh, transforms; instance_ids) once the geometry exists (src/instanced-bvh.jl:639-676,
+ * append_instances_with_handle! :612-623): m instances of blas_id.  xforms = m x 12 f32 (Mat3x4f bytes)
+ * or NULL for identity; instance_ids = m u32 or NULL for 0.  *handle receives the TLASHandle id (>= 1). */
+int rc_add_instances(rc_scene* scene, uint32_t blas_id, const float* xforms, const uint32_t* instance_ids,
+                     uint32_t m, uint32_t* handle);
+/* Same, but the caller supplies the inverse transforms too (the InstanceDescriptor(..., transform,
+ * inv_transform, ...) constructor used with build_tlas, src/instanced-bvh.jl:90-102, 1605). */
+int rc_add_instances_with_inverse(rc_scene* scene, uint32_t blas_id, const float* xforms, const float* inv_xforms,
+                                  const uint32_t* instance_ids, uint32_t m, uint32_t* handle);
+
+/* update_transform! / update_transforms! (src/instanced-bvh.jl:755-797): m must equal the handle's
+ * instance count; marks the scene transforms-dirty (refit on the next rc_sync). */
+int rc_update_transforms(rc_scene* scene, uint32_t handle, const float* xforms, uint32_t m);
+/* update!(tlas, handle, new_geometry) (src/instanced-bvh.jl:808-857): replace the BLAS the handle uses. */
+int rc_update_geometry(rc_scene* scene, uint32_t handle, const float* verts, const uint32_t* meta, uint32_t n);
+/* delete!(tlas, handle) (src/instanced-bvh.jl:690-699): *deleted = 1 if it was live, 0 otherwise (idempotent). */
+int rc_delete(rc_scene* scene, uint32_t handle, int* deleted);
+/* is_valid (src/instanced-bvh.jl:524-526); n_instances(tlas, handle) (:533-537) */
+int rc_is_valid(rc_scene* scene, uint32_t handle, int* valid);
+int rc_handle_instance_count(rc_scene* scene, uint32_t handle, uint32_t* count);
+/* get_instances(tlas, handle) (src/instanced-bvh.jl:732-738): copies the handle's descriptors. */
+int rc_get_instances(rc_scene* scene, uint32_t handle, rc_instance_desc* out, uint32_t capacity, uint32_t* count);
+
+/* sync!(tlas) (src/instanced-bvh.jl:894-921): dirty => compact + rebuild TLAS + flat BLAS arrays;
+ * only transforms dirty => refit in place (refit_tlas!, :2197-2222); clean => no-op without a device
+ * synchronise.  *action (optional) receives 0 = no-op, 1 = refit, 2 = rebuild. */
+int rc_sync(rc_scene* scene, int* action);
+
+/* n_instances(tlas) (live, :2391-2398), length(tlas.instances) (n_total_instances, :544), n_geometries (:2405),
+ * number of flat primitives / TLAS nodes / BLAS nodes after the last sync. */
+int rc_counts(rc_scene* scene, uint32_t* n_live_instances, uint32_t* n_total_instances, uint32_t* n_geometries,
+              uint32_t* n_prims, uint32_t* n_tlas_nodes, uint32_t* n_blas_nodes);
+/* world_bound(tlas) (src/instanced-bvh.jl:2147-2149): out = {min xyz, max xyz}. */
+int rc_world_bound(rc_scene* scene, float out[6]);
+/* wait_for_gpu! (src/instanced-bvh.jl:2418-2421) */
+int rc_wait(rc_scene* scene);
+
+/* Reference-layout copies of the synced StaticTLAS arrays (src/instanced-bvh.jl:155-168).  Pass NULL
+ * buffers to query counts only. */
+int rc_export_tlas_nodes(rc_scene* scene, rc_bvh_node* out, uint32_t capacity, uint32_t* count);
+int rc_export_blas_nodes(rc_scene* scene, rc_bvh_node* out, uint32_t capacity, uint32_t* count);
+int rc_export_instances(rc_scene* scene, rc_instance_desc* out, uint32_t capacity, uint32_t* count);
+int rc_export_blas_descs(rc_scene* scene, rc_blas_desc* out, uint32_t capacity, uint32_t* count);
+int rc_export_prims(rc_scene* scene, rc_prim* out, uint32_t capacity, uint32_t* count);
+
+/* closest_hit / any_hit over a batch (src/instanced-bvh.jl:1902-2024, 2034-2140; batch shape =
+ * trace_rays, ext/RaycoreMakieExt.jl:81-87, and Lava.trace_closest_hits!, docs/src/hw_acceleration.md:141-146).
+ * Host-buffer form: copies rays in, hits out. */
+int rc_trace_closest(rc_scene* scene, const rc_ray* rays, rc_hit* hits, uint64_t n);
+int rc_trace_any(rc_scene* scene, const rc_ray* rays, rc_hit* hits, uint64_t n);
+/* Device-buffer form: d_rays / d_hits are device pointers on the scene's device; the launch is enqueued
+ * on `stream` (a hipStream_t, NULL = the null stream) and is asynchronous. */
+int rc_trace_closest_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream);
+int rc_trace_any_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream);
+
+/* Kernel selection for the trace entry points (tuning / A-B measurement).  The default is the tuned
+ * kernel; every variant returns identical results. */
+int rc_set_option(rc_scene* scene, const char* name, int64_t value);
+int rc_get_option(rc_scene* scene, const char* name, int64_t* value);
+
+/* generate_ray_grid as used by hits_from_grid (src/kernels.jl:10-72): grid*grid rays written to the
+ * device buffer d_rays (column-major (i-1) + grid*(j-1)), direction = normalize(viewdir). */
+int rc_generate_ray_grid_device(rc_scene* scene, const float viewdir[3], uint32_t grid, rc_ray* d_rays, void* stream);
+/* get_illumination(tlas, viewdir; grid_size) (src/kernels.jl:112-124): out_counts = n_prims f32 (host). */
+int rc_get_illumination(rc_scene* scene, const float viewdir[3], uint32_t grid, float* out_counts);
+/* Rays [ray_begin, ray_end) of the grid only, accumulated into a device histogram (n_prims f32) --
+ * the shard unit for multi-GPU runs. */
+int rc_get_illumination_device(rc_scene* scene, const float viewdir[3], uint32_t grid, uint64_t ray_begin,
+                               uint64_t ray_end, float* d_counts, void* stream);
+
+/* view_factors(tlas; rays_per_triangle) (src/kernels.jl:74-104) with the unseeded task-local RNG replaced
+ * by Philox4x32-10: key = seed, counter = (ray_idx, src_prim_index, 0, 0) -> (r1, r2, xi1, xi2), so a result
+ * does not depend on how the work is sharded.  Shoots rays [ray_begin, ray_end) of source primitives
+ * [src_begin, src_end) and ACCUMULATES into d_matrix (device, u32): element (src_meta-1, hit_meta-1) lives
+ * at (src_meta-1-row_offset)*row_stride + (hit_meta-1)*col_stride.  Julia's column-major N x N Matrix is
+ * row_stride=1, col_stride=N, row_offset=0; a row-sharded block is row_stride=N, col_stride=1,
+ * row_offset=src_begin (metadata == primitive index + 1 assumed for row shards). */
+int rc_view_factors_device(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin,
+                           uint32_t src_end, uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix,
+                           uint64_t row_stride, uint64_t col_stride, uint32_t row_offset, void* stream);
+/* Whole job into a host N x N column-major matrix (the Julia return value). */
+int rc_view_factors(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix);
+/* The rays view_factors shoots for one source primitive (ray indices [ray_begin, ray_begin + n_rays)),
+ * written to a device buffer: the body of the reference's inner loop up to the Ray constructor
+ * (src/kernels.jl:89-92), exposed so ray generation can be checked on its own. */
+int rc_view_factor_rays_device(rc_scene* scene, uint64_t seed, uint32_t src_prim, uint32_t ray_begin, uint32_t n_rays,
+                               rc_ray* d_rays, void* stream);
+
+/* Timing of the most recent trace / driver launch on this scene, measured with HIP events on the launch
+ * stream (kernel only, no copies), in milliseconds. */
+int rc_last_kernel_ms(rc_scene* scene, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -756,11 +756,53 @@ void rco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 static inline float u32_to_unit(uint32_t x) { return (float)(x >> 8) * 0x1.0p-24f; } /* rand(Float32): 24-bit [0,1) */
 
-/* Julia's Float32 sin/cos/acos evaluate in higher precision and round once; (float)f((double)x) is
- * the closest portable restatement (parity unpinned: the reference RNG is unseeded anyway). */
-static inline float f32_sin(float x) { return (float)sin((double)x); }
-static inline float f32_cos(float x) { return (float)cos((double)x); }
-static inline float f32_acos(float x) { return (float)acos((double)x); }
+/* Julia's Float32 sin/cos/acos evaluate in higher precision and round once.  The restatement evaluates
+ * them in f64 with fixed-order polynomial kernels (fdlibm's __kernel_sin/__kernel_cos/acos coefficients)
+ * and rounds once to f32; the product uses the same formulas so both sides generate bit-identical rays
+ * (parity unpinned against Julia: the reference RNG is unseeded anyway).  Valid for the sampler's ranges:
+ * sincos on [0, 2 pi], acos on [0, 1). */
+static void rc_sincos_f64(double x, double* s, double* c) {
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, two_over_pi = 6.36619772367581382433e-01;
+    int k = (int)(x * two_over_pi + 0.5);
+    double r = (x - (double)k * pio2_hi) - (double)k * pio2_lo;
+    double z = r * r;
+    double sp = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    double ks = r + (z * r) * (-1.66666666666666324348e-01 + z * sp);
+    double cp = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    double kc = 1.0 - (0.5 * z - z * cp);
+    switch (k & 3) {
+        case 0: *s = ks; *c = kc; break;
+        case 1: *s = kc; *c = -ks; break;
+        case 2: *s = -ks; *c = -kc; break;
+        default: *s = -kc; *c = ks; break;
+    }
+}
+static double rc_acos_f64(double x) {
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+                 pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+                 qS4 = 7.70381505559019352791e-02;
+    if (x < 0.5) {
+        double z = x * x;
+        double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        double r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    double z = (1.0 - x) * 0.5;
+    double s = sqrt(z);
+    uint64_t bits; memcpy(&bits, &s, 8); bits &= 0xFFFFFFFF00000000ull;
+    double df; memcpy(&df, &bits, 8);
+    double c = (z - df * df) / (s + df);
+    double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    double r = p / q;
+    double w = r * s + c;
+    return 2.0 * (df + w);
+}
+void rco_sincos_f64(double x, double* s, double* c) { rc_sincos_f64(x, s, c); }
+double rco_acos_f64(double x) { return rc_acos_f64(x); }
 
 int rco_view_factor_ray(const rco_scene* s, uint32_t src, uint32_t ray_idx, uint64_t seed, rco_ray* out) {
     if (src >= s->n_blas_prims) return -1;
@@ -786,9 +828,13 @@ int rco_view_factor_ray(const rco_scene* s, uint32_t src, uint32_t ray_idx, uint
     v3 pt = v3_add(v3_add(v3_scale(p1, bu_), v3_scale(p2, bv_)), v3_scale(p3, bw_));
     v3 o = v3_add(pt, v3_scale(normal, 0.01f)); /* :91 */
     /* random_hemisphere_uniform (src/math.jl:125-141) */
-    float theta = f32_acos(xi1);
+    float theta = (float)rc_acos_f64((double)xi1);
     float phi = (2.0f * 3.1415927f) * xi2;
-    float xl = f32_sin(theta) * f32_cos(phi), yl = f32_sin(theta) * f32_sin(phi), zl = f32_cos(theta);
+    double st, ct, sp, cp;
+    rc_sincos_f64((double)theta, &st, &ct);
+    rc_sincos_f64((double)phi, &sp, &cp);
+    float sin_t = (float)st, cos_t = (float)ct, sin_p = (float)sp, cos_p = (float)cp;
+    float xl = sin_t * cos_p, yl = sin_t * sin_p, zl = cos_t;
     v3 d = v3_add(v3_add(v3_scale(bu, xl), v3_scale(bv, yl)), v3_scale(normal, zl));
     out->ox = o.x; out->oy = o.y; out->oz = o.z; out->tmin = 0.0f;
     out->dx = d.x; out->dy = d.y; out->dz = d.z; out->tmax = INFINITY;

@@ -1,0 +1,414 @@
+"""Host-side mirror of Raycore.jl's accel API for the TLAS/BLAS path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference (paths relative to the reference repo):
+TLAS / push! / delete! / update_transform(s)! / update! / sync! / Adapt.adapt (src/instanced-bvh.jl:334-1102),
+closest_hit / any_hit (:1902-2140), trace_rays (ext/RaycoreMakieExt.jl:81-87), get_illumination /
+get_centroid / view_factors (src/kernels.jl:58-124).  Python has no `!`, so `push!` is `push`, etc.
+Where the Julia API is 1-based (instance index returned by closest_hit, blas_index) this layer is 1-based
+too; the C ABI underneath is 0-based.
+
+Triangles are passed as (n, 9) float32 soup (v0 v1 v2) plus optional uint32 metadata: GeometryBasics mesh
+decomposition is outside this path.  Transforms are 4x4 (rows 0..2 used, translation
+in column 4, like Mat4f) or 12 floats in Mat3x4f byte order.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _capi
+from ._capi import HIT_DT, RAY_DT, RaycoreError, check, lib, ptr
+
+TLASHandle = namedtuple("TLASHandle", ["id"])  # src/instanced-bvh.jl:180-182
+INVALID_HANDLE = TLASHandle(0)
+Triangle = namedtuple("Triangle", ["vertices", "metadata"])  # the fields of Triangle{UInt32} this path reads
+Bounds3 = namedtuple("Bounds3", ["p_min", "p_max"])
+RayHit = namedtuple("RayHit", ["hit", "point", "metadata"])  # src/kernels.jl:1-5
+Ray = namedtuple("Ray", ["o", "d", "t_min", "t_max"], defaults=(0.0, np.inf))  # src/ray.jl:1-7 (time unused on the path)
+
+EMPTY_TRIANGLE = Triangle(np.zeros((3, 3), np.float32), np.uint32(0))  # empty_triangle, src/triangle_mesh.jl:49-57
+
+
+def mat4_to_mat3x4(m):
+    """mat4_to_mat3x4 (src/instanced-bvh.jl:1663-1669): upper three rows of the 4x4, row-major."""
+    m = np.asarray(m, dtype=np.float32)
+    if m.shape == (4, 4):
+        return np.ascontiguousarray(m[:3, :].reshape(12))
+    if m.size == 12:
+        return np.ascontiguousarray(m.reshape(12))
+    raise ValueError("transform must be 4x4 or 12 floats (Mat3x4f)")
+
+
+def _as_xforms(transforms):
+    if transforms is None:
+        return None
+    t = np.asarray(transforms, dtype=np.float32)
+    if t.ndim == 2 and t.shape == (4, 4):
+        t = t[None]
+    if t.ndim == 3 and t.shape[1:] == (4, 4):
+        return np.ascontiguousarray(t[:, :3, :].reshape(-1, 12))
+    return np.ascontiguousarray(t.reshape(-1, 12))
+
+
+def _as_rays(rays):
+    if isinstance(rays, np.ndarray) and rays.dtype == RAY_DT:
+        return np.ascontiguousarray(rays)
+    if isinstance(rays, Ray):
+        rays = [rays]
+    out = np.zeros(len(rays), dtype=RAY_DT)
+    for i, r in enumerate(rays):
+        out[i] = (tuple(r.o), r.t_min, tuple(r.d), r.t_max)
+    return out
+
+
+class StaticTLAS:
+    """The adapted form (StaticTLAS, src/instanced-bvh.jl:155-168): what kernels traverse.  Returned by
+    TLAS.adapt(); arrays are read back lazily in the reference's layout."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def _export(self, fn, dt):
+        n = C.c_uint32()
+        check(fn(self._owner._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=dt)
+        if n.value:
+            check(fn(self._owner._h, ptr(out), n.value, None))
+        return out
+
+    @property
+    def nodes(self):
+        return self._export(lib().rc_export_tlas_nodes, _capi.NODE_DT)
+
+    @property
+    def instances(self):
+        return self._export(lib().rc_export_instances, _capi.INSTANCE_DT)
+
+    @property
+    def all_blas_nodes(self):
+        return self._export(lib().rc_export_blas_nodes, _capi.NODE_DT)
+
+    @property
+    def all_blas_prims(self):
+        return self._export(lib().rc_export_prims, _capi.PRIM_DT)
+
+    @property
+    def blas_descriptors(self):
+        return self._export(lib().rc_export_blas_descs, _capi.DESC_DT)
+
+    @property
+    def root_aabb(self):
+        return self._owner.world_bound()
+
+
+class TLAS:
+    """Mutable two-level accel (TLAS{Backend}, src/instanced-bvh.jl:261-310) on one MI355X."""
+
+    def __init__(self, device=0):  # TLAS(backend), :334-358
+        h = C.c_void_p()
+        check(lib().rc_scene_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self._static = StaticTLAS(self)
+        self._prims_cache = None
+
+    # -- lifetime -------------------------------------------------------------------------------------
+    def free(self):  # free!, :383-399
+        if getattr(self, "_h", None):
+            lib().rc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    # -- mutation -------------------------------------------------------------------------------------
+    def push(self, verts, transforms=None, instance_id=0, instance_ids=None, meta=None):
+        """push!(tlas, mesh, transform; instance_id) / push!(tlas, mesh, transforms; instance_ids) (:639-676)."""
+        verts = np.ascontiguousarray(np.asarray(verts, dtype=np.float32).reshape(-1, 9))
+        m = None if meta is None else np.ascontiguousarray(meta, dtype=np.uint32)
+        if m is not None and len(m) != len(verts):
+            raise ValueError("meta length != triangle count")
+        xf = _as_xforms(transforms)
+        n_inst = 1 if xf is None else len(xf)
+        if instance_ids is not None:
+            ids = np.ascontiguousarray(instance_ids, dtype=np.uint32)
+            if len(ids) != n_inst:  # ArgumentError, :664-666
+                raise ValueError(f"instance_ids length {len(ids)} != transforms length {n_inst}")
+        else:
+            ids = np.full(n_inst, instance_id, dtype=np.uint32)
+        blas_id, handle = C.c_uint32(), C.c_uint32()
+        check(lib().rc_add_blas(self._h, ptr(verts), ptr(m), len(verts), C.byref(blas_id)))
+        check(lib().rc_add_instances(self._h, blas_id.value, ptr(xf), ptr(ids), n_inst, C.byref(handle)))
+        self._prims_cache = None
+        return TLASHandle(handle.value)
+
+    def push_instances(self, blas_index, transforms=None, instance_ids=None, inv_transforms=None):
+        """More instances of an existing geometry (1-based blas_index, as InstanceDescriptor stores it, :90-96)."""
+        xf, inv = _as_xforms(transforms), _as_xforms(inv_transforms)
+        n_inst = 1 if xf is None else len(xf)
+        ids = np.zeros(n_inst, np.uint32) if instance_ids is None else np.ascontiguousarray(instance_ids, dtype=np.uint32)
+        handle = C.c_uint32()
+        check(lib().rc_add_instances_with_inverse(self._h, int(blas_index) - 1, ptr(xf), ptr(inv), ptr(ids), n_inst, C.byref(handle)))
+        return TLASHandle(handle.value)
+
+    def add_geometry(self, verts, meta=None):
+        """build_and_append_blas! alone (:581-608); returns the 1-based BLAS index."""
+        verts = np.ascontiguousarray(np.asarray(verts, dtype=np.float32).reshape(-1, 9))
+        m = None if meta is None else np.ascontiguousarray(meta, dtype=np.uint32)
+        blas_id = C.c_uint32()
+        check(lib().rc_add_blas(self._h, ptr(verts), ptr(m), len(verts), C.byref(blas_id)))
+        self._prims_cache = None
+        return blas_id.value + 1
+
+    def delete(self, handle):  # delete!, :690-699
+        d = C.c_int()
+        check(lib().rc_delete(self._h, handle.id, C.byref(d)))
+        self._prims_cache = None
+        return bool(d.value)
+
+    def update_transform(self, handle, transform):  # update_transform!, :755-770
+        n = self.n_instances(handle) if self.is_valid(handle) else None
+        if n is not None and n != 1:
+            raise RaycoreError(_capi.RC_ERR_INVALID_ARGUMENT, f"Handle has {n} instances, use update_transforms! for multiple")
+        xf = _as_xforms(transform)
+        check(lib().rc_update_transforms(self._h, handle.id, ptr(xf), 1))
+
+    def update_transforms(self, handle, transforms):  # update_transforms!, :784-797
+        xf = _as_xforms(transforms)
+        check(lib().rc_update_transforms(self._h, handle.id, ptr(xf), len(xf)))
+
+    def update(self, handle, verts, meta=None):  # update!, :808-857
+        verts = np.ascontiguousarray(np.asarray(verts, dtype=np.float32).reshape(-1, 9))
+        m = None if meta is None else np.ascontiguousarray(meta, dtype=np.uint32)
+        check(lib().rc_update_geometry(self._h, handle.id, ptr(verts), ptr(m), len(verts)))
+        self._prims_cache = None
+
+    def sync(self):  # sync!, :894-921
+        a = C.c_int()
+        check(lib().rc_sync(self._h, C.byref(a)))
+        self.last_sync_action = ("noop", "refit", "rebuild")[a.value]
+        if a.value == 2:
+            self._prims_cache = None
+        return self
+
+    def adapt(self):  # Adapt.adapt(backend, tlas), :1085-1102: sync, then hand out the adapted form
+        self.sync()
+        return self._static
+
+    @property
+    def static_tlas(self):
+        return self._static
+
+    # -- queries ----------------------------------------------------------------------------------------
+    def is_valid(self, handle):  # :524-526
+        v = C.c_int()
+        check(lib().rc_is_valid(self._h, handle.id, C.byref(v)))
+        return bool(v.value)
+
+    def _counts(self):
+        c = [C.c_uint32() for _ in range(6)]
+        check(lib().rc_counts(self._h, *[C.byref(x) for x in c]))
+        return [x.value for x in c]
+
+    def n_instances(self, handle=None):  # :533-537, :2391-2398
+        if handle is None:
+            return self._counts()[0]
+        n = C.c_uint32()
+        check(lib().rc_handle_instance_count(self._h, handle.id, C.byref(n)))
+        return n.value
+
+    def n_total_instances(self):  # :544
+        return self._counts()[1]
+
+    def n_geometries(self):  # :2405
+        return self._counts()[2]
+
+    def n_primitives(self):
+        return self._counts()[3]
+
+    def get_instances(self, handle):  # :732-738
+        n = C.c_uint32()
+        check(lib().rc_get_instances(self._h, handle.id, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=_capi.INSTANCE_DT)
+        check(lib().rc_get_instances(self._h, handle.id, ptr(out), n.value, None))
+        return out
+
+    def get_instance(self, handle, instance_idx=1):  # :714-723
+        inst = self.get_instances(handle)
+        if not 1 <= instance_idx <= len(inst):
+            raise RaycoreError(_capi.RC_ERR_INVALID_ARGUMENT, f"Instance index {instance_idx} out of range 1:{len(inst)}")
+        return inst[instance_idx - 1]
+
+    def world_bound(self):  # :2147-2149
+        out = np.zeros(6, dtype=np.float32)
+        check(lib().rc_world_bound(self._h, ptr(out)))
+        return Bounds3(out[:3].copy(), out[3:].copy())
+
+    def wait_for_gpu(self):  # wait_for_gpu!, :2418-2421
+        check(lib().rc_wait(self._h))
+        return self
+
+    # -- batch tracing (device kernels) -------------------------------------------------------------------
+    def set_option(self, name, value):
+        check(lib().rc_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        check(lib().rc_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def trace(self, rays, mode="closest"):
+        """Batch closest_hit / any_hit: RAY_DT array in, HIT_DT array out (RTRay/RTHitResult, src/rt_transport.jl)."""
+        rays = _as_rays(rays)
+        hits = np.zeros(len(rays), dtype=HIT_DT)
+        fn = lib().rc_trace_closest if mode == "closest" else lib().rc_trace_any
+        check(fn(self._h, ptr(rays), ptr(hits), len(rays)))
+        return hits
+
+    def trace_device(self, d_rays, d_hits, n, mode="closest", stream=None):
+        """Device-pointer form (e.g. torch tensors' data_ptr()); asynchronous on `stream`."""
+        fn = lib().rc_trace_closest_device if mode == "closest" else lib().rc_trace_any_device
+        check(fn(self._h, ptr(d_rays), ptr(d_hits), int(n), ptr(stream) if stream else None))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(lib().rc_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def _prims(self):
+        if self._prims_cache is None:
+            self._prims_cache = self._static.all_blas_prims
+        return self._prims_cache
+
+
+def _owner(accel):
+    if isinstance(accel, StaticTLAS):
+        return accel._owner
+    if isinstance(accel, TLAS):
+        accel.sync()  # the reference requires adapt-per-dispatch; adapt == sync + read (:1085-1102)
+        return accel
+    raise TypeError("expected TLAS or StaticTLAS")
+
+
+def sync(tlas):
+    return tlas.sync()
+
+
+def adapt(tlas):
+    return tlas.adapt()
+
+
+def world_bound(accel):
+    return _owner(accel).world_bound() if isinstance(accel, StaticTLAS) else accel.world_bound()
+
+
+def _tuple_from_hit(t, h, miss_prim):
+    """(hit, Triangle, t, bary, instance_idx) exactly as closest_hit/any_hit return it (:2010-2023, :2106-2139)."""
+    if not h["hit"]:
+        return (False, miss_prim, np.float32(0), np.zeros(3, np.float32), np.uint32(0))
+    p = t._prims()[h["primitive_id"]]
+    u, v = h["bary_u"], h["bary_v"]
+    w = (np.float32(1.0) - u) - v  # 1f0 - hit_u - hit_v (:2015)
+    return (True, Triangle(p["v"].copy(), p["meta"]), h["t"], np.array([w, u, v], np.float32), np.uint32(h["instance_id"] + 1))
+
+
+def closest_hit(accel, ray):
+    """closest_hit(tlas, ray) -> (hit, primitive, distance, barycentric, instance_idx) (:1902-2024)."""
+    t = _owner(accel)
+    return _tuple_from_hit(t, t.trace(_as_rays(ray))[0], EMPTY_TRIANGLE)
+
+
+def any_hit(accel, ray):
+    """any_hit(tlas, ray) (:2034-2140); on a miss the dummy primitive is all_blas_prims[1] (:2137)."""
+    t = _owner(accel)
+    h = t.trace(_as_rays(ray), mode="any")[0]
+    prims = t._prims()
+    dummy = Triangle(prims[0]["v"].copy(), prims[0]["meta"]) if len(prims) else EMPTY_TRIANGLE
+    return _tuple_from_hit(t, h, dummy)
+
+
+def trace_rays(accel, rays):
+    """trace_rays(tlas, rays) = map(closest_hit) (ext/RaycoreMakieExt.jl:81-87), one device launch."""
+    t = _owner(accel)
+    return [_tuple_from_hit(t, h, EMPTY_TRIANGLE) for h in t.trace(_as_rays(rays))]
+
+
+def generate_ray_grid(accel, viewdir, grid_size):
+    """generate_ray_grid as used by hits_from_grid (src/kernels.jl:10-72), computed on the device; returns RAY_DT rays."""
+    import torch
+    t = _owner(accel)
+    n = grid_size * grid_size
+    buf = torch.empty(n * 8, dtype=torch.float32, device=f"cuda:{t.device}")
+    vd = np.ascontiguousarray(viewdir, dtype=np.float32)
+    check(lib().rc_generate_ray_grid_device(t._h, ptr(vd), grid_size, ptr(buf.data_ptr()), None))
+    torch.cuda.synchronize(t.device)
+    return buf.cpu().numpy().view(RAY_DT).reshape(n)
+
+
+def hits_from_grid(accel, viewdir, grid_size=32):
+    """hits_from_grid (src/kernels.jl:58-72): RayHit per grid cell, point = sum(bary .* vertices)."""
+    t = _owner(accel)
+    rays = generate_ray_grid(t._static, viewdir, grid_size)
+    hits = t.trace(rays)
+    prims = t._prims()
+    out = []
+    for h in hits:
+        if h["hit"]:
+            p = prims[h["primitive_id"]]
+            u, v = h["bary_u"], h["bary_v"]
+            w = (np.float32(1) - u) - v
+            point = (w * p["v"][0] + u * p["v"][1]) + v * p["v"][2]  # sum_mul, src/math.jl:52
+            out.append(RayHit(True, point, p["meta"]))
+        else:
+            out.append(RayHit(False, np.zeros(3, np.float32), np.uint32(0)))
+    return out
+
+
+def get_centroid(accel, viewdir, grid_size=32):
+    """get_centroid (src/kernels.jl:106-110)."""
+    pts = [h.point for h in hits_from_grid(accel, viewdir, grid_size) if h.hit]
+    return pts, (np.mean(np.stack(pts), axis=0) if pts else np.full(3, np.nan, np.float32))
+
+
+def get_illumination(accel, viewdir, grid_size=1000):
+    """get_illumination (src/kernels.jl:112-124): per-primitive hit counts of a grid_size^2 orthographic ray grid."""
+    t = _owner(accel)
+    out = np.zeros(t.n_primitives(), dtype=np.float32)
+    vd = np.ascontiguousarray(viewdir, dtype=np.float32)
+    check(lib().rc_get_illumination(t._h, ptr(vd), int(grid_size), ptr(out)))
+    return out
+
+
+def view_factors(accel, rays_per_triangle=10000, seed=0):
+    """view_factors (src/kernels.jl:74-104): N x N UInt32 matrix, [src_meta, hit_meta] (column-major like Julia's Matrix)."""
+    t = _owner(accel)
+    n = t.n_primitives()
+    out = np.zeros((n, n), dtype=np.uint32, order="F")
+    check(lib().rc_view_factors(t._h, int(rays_per_triangle), int(seed), ptr(out)))
+    return out
+
+
+def TLAS_from_items(items, metadata_fn, device=0):
+    """TLAS(items, metadata_fn; backend) (src/instanced-bvh.jl:2276-2324): one BLAS + one identity instance per
+    item, instance_id = item index, metadata = metadata_fn(item_idx, face_idx) (1-based); returns the adapted accel."""
+    t = TLAS(device)
+    for mi, verts in enumerate(items, start=1):
+        verts = np.asarray(verts, dtype=np.float32).reshape(-1, 9)
+        meta = np.array([metadata_fn(mi, fi) for fi in range(1, len(verts) + 1)], dtype=np.uint32)
+        b = t.add_geometry(verts, meta)
+        ident = np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]], dtype=np.float32)
+        t.push_instances(b, ident, [mi], inv_transforms=ident)  # identity for both, :2314-2320
+    return t.adapt()
+
+
+def TLAS_from_meshes(meshes, device=0):
+    """TLAS(meshes; backend) -> (tlas, handles) (src/instanced-bvh.jl:2361-2378)."""
+    if len(meshes) == 0:
+        raise RaycoreError(_capi.RC_ERR_INVALID_ARGUMENT, "Cannot create TLAS from empty mesh list")
+    t = TLAS(device)
+    handles = [t.push(m) for m in meshes]
+    t.sync()
+    return t, handles

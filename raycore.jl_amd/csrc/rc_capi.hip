@@ -1,0 +1,503 @@
+// rc_capi.hip -- the C ABI (include/raycore_mi355x.h) and the mutable-TLAS lifecycle behind it.
+//
+// Host-side mirror of the reference's TLAS management (src/instanced-bvh.jl:334-1102): handles, dirty /
+// transforms_dirty flags, delete + compaction, sync! as the sole owner of the adapted (device) form.
+// All compute happens in the HIP kernels of rc_build.hip / rc_traverse.hip / rc_drivers.hip; there is no
+// CPU fallback -- without a device every entry point that needs one fails with RC_ERR_NO_DEVICE.
+#include <cmath>
+#include <cstring>
+
+#include "../../include/raycore_mi355x.h"
+#include "rc_internal.h"
+
+static_assert(sizeof(rc_ray) == sizeof(RcRay) && sizeof(rc_hit) == sizeof(RcHit), "wire structs");
+static_assert(sizeof(rc_bvh_node) == 60 && sizeof(rc_instance_desc) == sizeof(RcInstanceDesc) && sizeof(rc_blas_desc) == sizeof(RcBlasDesc) &&
+                  sizeof(rc_prim) == sizeof(RcPrim), "export structs");
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+template <typename F>
+int guarded(F&& f) {
+    try {
+        f();
+        return RC_OK;
+    } catch (const RcError& e) {
+        return fail(e.code, e.what());
+    } catch (const std::exception& e) {
+        return fail(RC_ERR_INVALID_ARGUMENT, e.what());
+    }
+}
+
+void use_device(rc_scene* s) { RC_HIP(hipSetDevice(s->device)); }
+
+const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+
+// is_degenerate (src/triangle_mesh.jl:14-17): ((v3-v1) x (v2-v1)) . itself == 0 exactly (isapprox against 0)
+bool is_degenerate(const float* p) {
+    float3_ a = mk3(p[0], p[1], p[2]), b = mk3(p[3], p[4], p[5]), c = mk3(p[6], p[7], p[8]);
+    float3_ v = cross3(sub3(c, a), sub3(b, a));
+    return dot3(v, v) == 0.0f;
+}
+
+// cpu_triangles of build_and_append_blas! (src/instanced-bvh.jl:593-601)
+std::vector<RcPrim> filter_triangles(const float* verts, const uint32_t* meta, uint32_t n) {
+    if (!verts && n) throw RcError(RC_ERR_INVALID_ARGUMENT, "verts is NULL");
+    std::vector<RcPrim> out;
+    out.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* p = verts + 9 * (size_t)i;
+        if (is_degenerate(p)) continue;
+        RcPrim t;
+        memcpy(t.v, p, 36);
+        t.meta = meta ? meta[i] : (i + 1);
+        out.push_back(t);
+    }
+    if (out.empty()) throw RcError(RC_ERR_EMPTY_GEOMETRY, "Geometry has no valid triangles");
+    return out;
+}
+
+HandleRange& live_range(rc_scene* s, uint32_t handle) {
+    auto it = s->handle_to_range.find(handle);
+    if (it == s->handle_to_range.end()) throw RcError(RC_ERR_INVALID_HANDLE, "Invalid handle");
+    if (s->deleted_handles.count(handle)) throw RcError(RC_ERR_INVALID_HANDLE, "Handle has been deleted");
+    return it->second;
+}
+
+// compact_instances! (src/instanced-bvh.jl:996-1065).  The reference iterates a Dict (order unspecified);
+// here surviving handles keep ascending handle-id order.
+void compact_instances(rc_scene* s) {
+    std::vector<RcInstanceDesc> fresh;
+    std::map<uint32_t, HandleRange> ranges;
+    for (auto& kv : s->handle_to_range) {
+        if (s->deleted_handles.count(kv.first)) continue;
+        HandleRange r{(uint32_t)fresh.size(), kv.second.count};
+        fresh.insert(fresh.end(), s->instances.begin() + kv.second.first, s->instances.begin() + kv.second.first + kv.second.count);
+        ranges[kv.first] = r;
+    }
+    s->deleted_handles.clear();
+    s->handle_to_range.swap(ranges);
+    std::set<uint32_t> used;
+    for (auto& in : fresh) used.insert(in.blas_index);
+    if (!s->blas.empty() && used.size() < s->blas.size()) {
+        std::map<uint32_t, uint32_t> old_to_new;
+        std::vector<Blas> kept;
+        for (uint32_t old_idx : used) {  // ascending, like sort!(collect(used_blas_indices))
+            old_to_new[old_idx] = (uint32_t)kept.size() + 1;
+            kept.push_back(std::move(s->blas[old_idx - 1]));
+        }
+        for (auto& in : fresh) in.blas_index = old_to_new[in.blas_index];
+        s->blas.swap(kept);  // dropped geometries free their device buffers here
+    }
+    s->instances.swap(fresh);
+}
+
+void require_synced(rc_scene* s) {
+    if (!s->has_static || s->dirty || s->transforms_dirty)
+        throw RcError(RC_ERR_NOT_SYNCED, "scene has pending mutations: call rc_sync before tracing (Adapt.adapt does this per dispatch)");
+}
+
+void check_status(rc_scene* s, hipStream_t stream) {
+    uint32_t st = 0;
+    RC_HIP(hipMemcpyAsync(&st, s->counters.p + 4, 4, hipMemcpyDeviceToHost, stream));
+    RC_HIP(hipStreamSynchronize(stream));
+    if (st) throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels)");
+}
+
+template <typename T>
+void export_array(const std::vector<T>& host, T* out, uint32_t capacity, uint32_t* count) {
+    if (count) *count = (uint32_t)host.size();
+    if (!out) return;
+    if (capacity < host.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
+    if (!host.empty()) memcpy(out, host.data(), sizeof(T) * host.size());
+}
+
+void export_nodes(rc_scene* s, const RcNode* d, uint32_t n, rc_bvh_node* out, uint32_t capacity, uint32_t* count) {
+    if (count) *count = n;
+    if (!out || n == 0) return;
+    if (capacity < n) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
+    std::vector<RcNode> tmp(n);
+    RC_HIP(hipMemcpy(tmp.data(), d, sizeof(RcNode) * n, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {
+        memcpy(&out[i], tmp[i].f, 48);
+        out[i].child0 = tmp[i].child0; out[i].child1 = tmp[i].child1; out[i].parent = tmp[i].parent;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rc_last_error(void) { return g_last_error.c_str(); }
+
+int rc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rc_scene_create(int device, rc_scene** out) {
+    if (!out) return fail(RC_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int n = rc_device_count();
+    if (n <= 0) return fail(RC_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= n) return fail(RC_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    rc_scene* s = nullptr;
+    int rc = guarded([&] {
+        s = new rc_scene();
+        s->device = device;
+        use_device(s);
+        hipDeviceProp_t prop;
+        RC_HIP(hipGetDeviceProperties(&prop, device));
+        s->n_cus = prop.multiProcessorCount;
+        RC_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        RC_HIP(hipEventCreate(&s->ev0));
+        RC_HIP(hipEventCreate(&s->ev1));
+    });
+    if (rc != RC_OK) { delete s; return rc; }
+    *out = s;
+    return RC_OK;
+}
+
+int rc_scene_destroy(rc_scene* s) {
+    if (!s) return RC_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return RC_OK;
+}
+
+int rc_add_blas(rc_scene* s, const float* verts, const uint32_t* meta, uint32_t n, uint32_t* blas_id) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        std::vector<RcPrim> tris = filter_triangles(verts, meta, n);
+        Blas b;
+        rc_build_blas(s, tris.data(), (uint32_t)tris.size(), b);
+        s->blas.push_back(std::move(b));
+        if (blas_id) *blas_id = (uint32_t)s->blas.size() - 1;
+    });
+}
+
+int rc_add_instances_with_inverse(rc_scene* s, uint32_t blas_id, const float* xforms, const float* inv_xforms,
+                                  const uint32_t* instance_ids, uint32_t m, uint32_t* handle) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        if (blas_id >= s->blas.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "blas_id out of range");
+        HandleRange r{(uint32_t)s->instances.size(), m};
+        for (uint32_t i = 0; i < m; ++i) {  // :670-674
+            RcInstanceDesc d;
+            d.blas_index = blas_id + 1;
+            d.instance_id = instance_ids ? instance_ids[i] : 0u;
+            memcpy(d.transform, xforms ? xforms + 12 * (size_t)i : kIdentity, 48);
+            if (inv_xforms) memcpy(d.inv_transform, inv_xforms + 12 * (size_t)i, 48);
+            else rc_mat3x4_inverse(d.transform, d.inv_transform);
+            d.flags = 0;
+            s->instances.push_back(d);
+        }
+        uint32_t h = s->next_handle_id++;  // append_instances_with_handle! (:612-623)
+        s->handle_to_range[h] = r;
+        s->dirty = true;
+        if (handle) *handle = h;
+    });
+}
+
+int rc_add_instances(rc_scene* s, uint32_t blas_id, const float* xforms, const uint32_t* instance_ids, uint32_t m, uint32_t* handle) {
+    return rc_add_instances_with_inverse(s, blas_id, xforms, nullptr, instance_ids, m, handle);
+}
+
+int rc_update_transforms(rc_scene* s, uint32_t handle, const float* xforms, uint32_t m) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        HandleRange& r = live_range(s, handle);
+        if (m != r.count) throw RcError(RC_ERR_INVALID_ARGUMENT, "Transform count (" + std::to_string(m) + ") != instance count (" + std::to_string(r.count) + ")");
+        if (!xforms) throw RcError(RC_ERR_INVALID_ARGUMENT, "xforms is NULL");
+        for (uint32_t i = 0; i < m; ++i) {  // update_instance_transforms_offset_kernel! (src/instanced-bvh-kernels.jl:455-476)
+            RcInstanceDesc& d = s->instances[r.first + i];
+            memcpy(d.transform, xforms + 12 * (size_t)i, 48);
+            rc_mat3x4_inverse(d.transform, d.inv_transform);
+        }
+        s->transforms_dirty = true;
+    });
+}
+
+int rc_update_geometry(rc_scene* s, uint32_t handle, const float* verts, const uint32_t* meta, uint32_t n) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        HandleRange& r = live_range(s, handle);
+        if (r.count == 0) throw RcError(RC_ERR_INVALID_HANDLE, "Handle has no instances");
+        uint32_t blas_idx = s->instances[r.first].blas_index;  // :814-816
+        std::vector<RcPrim> tris = filter_triangles(verts, meta, n);
+        Blas b;
+        rc_build_blas(s, tris.data(), (uint32_t)tris.size(), b);
+        s->blas[blas_idx - 1] = std::move(b);
+        s->dirty = true;
+    });
+}
+
+int rc_delete(rc_scene* s, uint32_t handle, int* deleted) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    int d = 0;
+    if (s->handle_to_range.count(handle) && !s->deleted_handles.count(handle)) {  // :690-699
+        s->deleted_handles.insert(handle);
+        s->dirty = true;
+        d = 1;
+    }
+    if (deleted) *deleted = d;
+    return RC_OK;
+}
+
+int rc_is_valid(rc_scene* s, uint32_t handle, int* valid) {
+    if (!s || !valid) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    *valid = s->handle_to_range.count(handle) && !s->deleted_handles.count(handle);
+    return RC_OK;
+}
+
+int rc_handle_instance_count(rc_scene* s, uint32_t handle, uint32_t* count) {
+    if (!s || !count) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    auto it = s->handle_to_range.find(handle);
+    *count = (it == s->handle_to_range.end() || s->deleted_handles.count(handle)) ? 0u : it->second.count;  // :533-537
+    return RC_OK;
+}
+
+int rc_get_instances(rc_scene* s, uint32_t handle, rc_instance_desc* out, uint32_t capacity, uint32_t* count) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        HandleRange& r = live_range(s, handle);
+        if (count) *count = r.count;
+        if (!out) return;
+        if (capacity < r.count) throw RcError(RC_ERR_INVALID_ARGUMENT, "buffer too small");
+        memcpy(out, s->instances.data() + r.first, sizeof(RcInstanceDesc) * r.count);
+    });
+}
+
+int rc_sync(rc_scene* s, int* action) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (action) *action = 0;
+    if (!s->dirty && !s->transforms_dirty && s->has_static) return RC_OK;  // :898-900, no device sync
+    return guarded([&] {
+        use_device(s);
+        if (s->dirty || !s->has_static) {  // rebuild_bvh! + rebuild_static_tlas! (:902-905, :911-915)
+            if (!s->deleted_handles.empty()) compact_instances(s);
+            rc_build_tlas(s);
+            s->dirty = false;
+            s->transforms_dirty = false;
+            s->has_static = true;
+            if (action) *action = 2;
+        } else {  // refit_tlas! (:906-911): in place, the adapted buffers keep their identity
+            rc_refit_tlas(s);
+            s->transforms_dirty = false;
+            if (action) *action = 1;
+        }
+    });
+}
+
+int rc_counts(rc_scene* s, uint32_t* n_live, uint32_t* n_total, uint32_t* n_geom, uint32_t* n_prims, uint32_t* n_tlas_nodes, uint32_t* n_blas_nodes) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    uint32_t pending = 0;
+    for (uint32_t h : s->deleted_handles) {
+        auto it = s->handle_to_range.find(h);
+        if (it != s->handle_to_range.end()) pending += it->second.count;
+    }
+    if (n_live) *n_live = (uint32_t)s->instances.size() - pending;  // :2391-2398
+    if (n_total) *n_total = (uint32_t)s->instances.size();
+    if (n_geom) *n_geom = (uint32_t)s->blas.size();
+    if (n_prims) *n_prims = s->has_static ? s->n_flat_prims : 0;
+    if (n_tlas_nodes) *n_tlas_nodes = s->has_static ? s->n_tlas_nodes : 0;
+    if (n_blas_nodes) *n_blas_nodes = s->has_static ? s->n_flat_nodes : 0;
+    return RC_OK;
+}
+
+int rc_world_bound(rc_scene* s, float out[6]) {
+    if (!s || !out) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    memcpy(out, s->root_min, 12);
+    memcpy(out + 3, s->root_max, 12);
+    return RC_OK;
+}
+
+int rc_wait(rc_scene* s) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] { use_device(s); RC_HIP(hipDeviceSynchronize()); });
+}
+
+int rc_export_tlas_nodes(rc_scene* s, rc_bvh_node* out, uint32_t capacity, uint32_t* count) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] { use_device(s); require_synced(s); export_nodes(s, s->tlas_nodes.p, s->n_tlas_nodes, out, capacity, count); });
+}
+int rc_export_blas_nodes(rc_scene* s, rc_bvh_node* out, uint32_t capacity, uint32_t* count) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] { use_device(s); require_synced(s); export_nodes(s, s->flat_nodes.p, s->n_flat_nodes, out, capacity, count); });
+}
+int rc_export_instances(rc_scene* s, rc_instance_desc* out, uint32_t capacity, uint32_t* count) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        require_synced(s);
+        if (count) *count = (uint32_t)s->instances.size();
+        if (!out) return;
+        if (capacity < s->instances.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
+        if (!s->instances.empty()) memcpy(out, s->instances.data(), sizeof(RcInstanceDesc) * s->instances.size());
+    });
+}
+int rc_export_blas_descs(rc_scene* s, rc_blas_desc* out, uint32_t capacity, uint32_t* count) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        require_synced(s);
+        if (count) *count = (uint32_t)s->descs.size();
+        if (!out) return;
+        if (capacity < s->descs.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
+        if (!s->descs.empty()) memcpy(out, s->descs.data(), sizeof(RcBlasDesc) * s->descs.size());
+    });
+}
+int rc_export_prims(rc_scene* s, rc_prim* out, uint32_t capacity, uint32_t* count) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        if (count) *count = s->n_flat_prims;
+        if (!out || s->n_flat_prims == 0) return;
+        if (capacity < s->n_flat_prims) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
+        RC_HIP(hipMemcpy(out, s->flat_prims.p, sizeof(RcPrim) * s->n_flat_prims, hipMemcpyDeviceToHost));
+    });
+}
+
+static int trace_host(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        if (n == 0) return;
+        if (!rays || !hits) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
+        s->ray_stage.reserve(n);
+        s->hit_stage.reserve(n);
+        RC_HIP(hipMemcpyAsync(s->ray_stage.p, rays, sizeof(RcRay) * n, hipMemcpyHostToDevice, s->stream));
+        rc_launch_trace(s, s->ray_stage.p, s->hit_stage.p, n, any, s->stream);
+        RC_HIP(hipMemcpyAsync(hits, s->hit_stage.p, sizeof(RcHit) * n, hipMemcpyDeviceToHost, s->stream));
+        check_status(s, s->stream);
+        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
+    });
+}
+int rc_trace_closest(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace_host(s, rays, hits, n, 0); }
+int rc_trace_any(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace_host(s, rays, hits, n, 1); }
+
+static int trace_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream, int any) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        rc_launch_trace(s, reinterpret_cast<const RcRay*>(d_rays), reinterpret_cast<RcHit*>(d_hits), n, any, (hipStream_t)stream);
+    });
+}
+int rc_trace_closest_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace_device(s, d_rays, d_hits, n, stream, 0); }
+int rc_trace_any_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace_device(s, d_rays, d_hits, n, stream, 1); }
+
+int rc_set_option(rc_scene* s, const char* name, int64_t value) {
+    if (!s || !name) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::string k(name);
+    if (k == "kernel") s->opt.kernel = value;
+    else if (k == "blocks_per_cu") s->opt.blocks_per_cu = value;
+    else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
+    return RC_OK;
+}
+int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
+    if (!s || !name || !value) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::string k(name);
+    if (k == "kernel") *value = s->opt.kernel;
+    else if (k == "blocks_per_cu") *value = s->opt.blocks_per_cu;
+    else if (k == "n_cus") *value = s->n_cus;
+    else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
+    return RC_OK;
+}
+
+int rc_generate_ray_grid_device(rc_scene* s, const float viewdir[3], uint32_t grid, rc_ray* d_rays, void* stream) {
+    if (!s || !viewdir) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        rc_launch_ray_grid(s, viewdir, grid, reinterpret_cast<RcRay*>(d_rays), (hipStream_t)stream);
+    });
+}
+
+int rc_get_illumination_device(rc_scene* s, const float viewdir[3], uint32_t grid, uint64_t ray_begin, uint64_t ray_end, float* d_counts, void* stream) {
+    if (!s || !viewdir) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        uint64_t n = (uint64_t)grid * grid;
+        if (ray_end > n) ray_end = n;
+        rc_launch_illumination(s, viewdir, grid, ray_begin, ray_end, d_counts, (hipStream_t)stream);
+    });
+}
+
+int rc_get_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, float* out_counts) {
+    if (!s || !viewdir || !out_counts) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        uint32_t np = s->n_flat_prims;
+        s->f32_stage.reserve(np ? np : 1);
+        RC_HIP(hipMemsetAsync(s->f32_stage.p, 0, sizeof(float) * (np ? np : 1), s->stream));
+        rc_launch_illumination(s, viewdir, grid, 0, (uint64_t)grid * grid, s->f32_stage.p, s->stream);
+        if (np) RC_HIP(hipMemcpyAsync(out_counts, s->f32_stage.p, sizeof(float) * np, hipMemcpyDeviceToHost, s->stream));
+        check_status(s, s->stream);
+        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
+    });
+}
+
+int rc_view_factors_device(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end, uint32_t ray_begin,
+                           uint32_t ray_end, uint32_t* d_matrix, uint64_t row_stride, uint64_t col_stride, uint32_t row_offset, void* stream) {
+    if (!s || !d_matrix) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        rc_launch_view_factors(s, rays_per_triangle, seed, src_begin, src_end, ray_begin, ray_end, d_matrix, row_stride, col_stride, row_offset, (hipStream_t)stream);
+    });
+}
+
+int rc_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix) {
+    if (!s || !out_matrix) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        uint64_t np = s->n_flat_prims;
+        if (np == 0) return;
+        DevBuf<uint32_t> m;
+        m.reserve(np * np);
+        RC_HIP(hipMemsetAsync(m.p, 0, sizeof(uint32_t) * np * np, s->stream));
+        rc_launch_view_factors(s, rays_per_triangle, seed, 0, (uint32_t)np, 0, rays_per_triangle, m.p, 1, np, 0, s->stream);
+        RC_HIP(hipMemcpyAsync(out_matrix, m.p, sizeof(uint32_t) * np * np, hipMemcpyDeviceToHost, s->stream));
+        check_status(s, s->stream);
+        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
+    });
+}
+
+int rc_view_factor_rays_device(rc_scene* s, uint64_t seed, uint32_t src_prim, uint32_t ray_begin, uint32_t n_rays, rc_ray* d_rays, void* stream) {
+    if (!s || !d_rays) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        if (src_prim >= s->n_flat_prims) throw RcError(RC_ERR_INVALID_ARGUMENT, "src_prim out of range");
+        rc_launch_view_factor_rays(s, seed, src_prim, ray_begin, n_rays, reinterpret_cast<RcRay*>(d_rays), (hipStream_t)stream);
+    });
+}
+
+int rc_last_kernel_ms(rc_scene* s, float* ms) {
+    if (!s || !ms) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        RC_HIP(hipEventSynchronize(s->ev1));
+        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
+        *ms = s->last_ms;
+    });
+}
+
+}  // extern "C"

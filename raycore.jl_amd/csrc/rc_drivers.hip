@@ -1,0 +1,276 @@
+// rc_drivers.hip -- the analysis drivers that sit directly on closest_hit, run on the device.
+//
+// Replaces src/kernels.jl: generate_ray_grid (:10-56), hits_from_grid (:58-72), get_illumination (:112-124)
+// and view_factors / view_factors! (:74-104) with their sampling helpers random_triangle_point,
+// random_hemisphere_uniform, get_orthogonal_basis (src/math.jl:125-174).  The reference runs these as
+// Threads.@threads CPU loops over closest_hit with a serial Dict histogram; here rays are generated in the
+// kernel that traces them (no ray I/O) and results are accumulated with integer-valued device atomics,
+// which are exact and order-independent.
+//
+// Determinism: the reference's view_factors uses the unseeded task-local RNG.  Here every (source
+// primitive, ray index) pair draws its four uniforms from Philox4x32-10 keyed by the seed, so a result does
+// not depend on the launch geometry or on how the job is sharded over GPUs.  sin/cos/acos are evaluated in
+// f64 with fixed-order polynomial kernels (fdlibm coefficients) and rounded once to f32 -- Julia's Float32
+// trig also evaluates in higher precision and rounds once -- so the CPU oracle, which uses the same formulas,
+// generates bit-identical rays.
+#include "rc_traverse_core.h"
+
+#include <cmath>
+
+namespace {
+
+using namespace rc;
+
+struct GridParams {  // everything generate_ray_grid computes before its double loop
+    float gc[3], b1[3], b2[3], dir[3];
+    float cell_w, cell_h;
+    uint32_t grid;
+};
+
+// generate_ray_grid body (:47-55): u, v and the sum are Float64 ((grid_size+1)/2 is Float64) and round
+// once into the Float32 point.
+__device__ inline RcRay grid_ray(const GridParams& g, uint64_t idx) {
+    uint32_t i = (uint32_t)(idx % g.grid) + 1, j = (uint32_t)(idx / g.grid) + 1;
+    double half = ((double)g.grid + 1.0) / 2.0;
+    double u = ((double)i - half) * (double)g.cell_w;
+    double v = ((double)j - half) * (double)g.cell_h;
+    RcRay r;
+    r.ox = (float)(((double)g.gc[0] + u * (double)g.b1[0]) + v * (double)g.b2[0]);
+    r.oy = (float)(((double)g.gc[1] + u * (double)g.b1[1]) + v * (double)g.b2[1]);
+    r.oz = (float)(((double)g.gc[2] + u * (double)g.b1[2]) + v * (double)g.b2[2]);
+    r.tmin = 0.0f; r.dx = g.dir[0]; r.dy = g.dir[1]; r.dz = g.dir[2]; r.tmax = INFINITY;
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ray_grid(GridParams g, RcRay* out) {
+    uint64_t n = (uint64_t)g.grid * g.grid;
+    for (uint64_t i = blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        RcRay r = grid_ray(g, i);
+        float4* q = reinterpret_cast<float4*>(out + i);
+        q[0] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+        q[1] = make_float4(r.dx, r.dy, r.dz, r.tmax);
+    }
+}
+
+// hits_from_grid + the histogram of get_illumination (:58-72, :112-124) fused: trace, then one f32 atomic
+// add of 1.0 on the hit primitive's metadata slot (exact while counts < 2^24, as in the reference's Float32 sums).
+__global__ __launch_bounds__(kBlock) void k_illumination(SceneView v, GridParams g, uint64_t ray_begin, uint64_t ray_end, float* counts) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    LaneStack st{lds_stack + threadIdx.x, v.overflow + gtid, v.total_threads, v.status};
+    for (uint64_t i = ray_begin + gtid; i < ray_end; i += v.total_threads) {
+        RayState s;
+        trace_ray<false>(s, grid_ray(g, i), v, st);
+        if (s.closest_inst >= 0) {
+            uint32_t meta = v.prims[hit_prim_index(s, v)].meta;
+            if (meta >= 1 && meta <= v.n_prims) atomicAdd(&counts[meta - 1], 1.0f);
+        }
+    }
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------------
+__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ inline float u32_to_unit(uint32_t x) { return (float)(x >> 8) * 0x1.0p-24f; }
+
+// ---- f64 trig with a fixed operation order (fdlibm kernels), valid for the ranges the sampler needs -----
+__device__ inline void sincos_f64(double x, double& s, double& c) {  // 0 <= x <= 2 pi
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, two_over_pi = 6.36619772367581382433e-01;
+    int k = (int)(x * two_over_pi + 0.5);
+    double r = (x - (double)k * pio2_hi) - (double)k * pio2_lo;
+    double z = r * r;
+    double sp = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    double ks = r + (z * r) * (-1.66666666666666324348e-01 + z * sp);
+    double cp = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    double kc = 1.0 - (0.5 * z - z * cp);
+    switch (k & 3) {
+        case 0: s = ks; c = kc; break;
+        case 1: s = kc; c = -ks; break;
+        case 2: s = -ks; c = -kc; break;
+        default: s = -kc; c = ks; break;
+    }
+}
+__device__ inline double acos_f64(double x) {  // 0 <= x < 1
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+                 pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+                 qS4 = 7.70381505559019352791e-02;
+    if (x < 0.5) {
+        double z = x * x;
+        double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        double r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    double z = (1.0 - x) * 0.5;
+    double s = __dsqrt_rn(z);
+    double df = __longlong_as_double(__double_as_longlong(s) & 0xFFFFFFFF00000000ll);
+    double c = (z - df * df) / (s + df);
+    double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    double r = p / q;
+    double w = r * s + c;
+    return 2.0 * (df + w);
+}
+
+// norm(a) = sqrt(dot(a,a)); normalize(a) = a ./ norm(a) (GeometryBasics 0.5 fixed_arrays)
+__device__ inline float3_ normalize3(float3_ a) {
+    float n = __fsqrt_rn(dot3(a, a));
+    return mk3(__fdiv_rn(a.x, n), __fdiv_rn(a.y, n), __fdiv_rn(a.z, n));
+}
+
+// The ray view_factors! shoots for (source primitive, ray index) (:83-92 + src/math.jl:125-174)
+__device__ inline RcRay view_factor_ray(const RcPrim& tri, uint32_t src, uint32_t ray_idx, uint32_t k0, uint32_t k1) {
+    float3_ p1 = mk3(tri.v[0], tri.v[1], tri.v[2]), p2 = mk3(tri.v[3], tri.v[4], tri.v[5]), p3 = mk3(tri.v[6], tri.v[7], tri.v[8]);
+    float3_ normal = normalize3(cross3(sub3(p2, p1), sub3(p3, p1)));  // GB.orthogonal_vector + normalize (:86-87)
+    // get_orthogonal_basis (src/math.jl:143-156)
+    float3_ n = normalize3(normal);
+    float ax = fabsf(normal.x), ay = fabsf(normal.y), az = fabsf(normal.z);
+    int mi = 1; float mv = ax;
+    if (ay < mv) { mi = 2; mv = ay; }
+    if (az < mv) { mi = 3; mv = az; }
+    float3_ cand = mi == 1 ? mk3(1, 0, 0) : (mi == 2 ? mk3(0, 1, 0) : mk3(0, 0, 1));
+    float3_ bv = normalize3(cross3(n, cand));
+    float3_ bu = normalize3(cross3(bv, n));
+    uint32_t rnd[4];
+    philox4x32_10(ray_idx, src, 0u, 0u, k0, k1, rnd);
+    float r1 = u32_to_unit(rnd[0]), r2 = u32_to_unit(rnd[1]), xi1 = u32_to_unit(rnd[2]), xi2 = u32_to_unit(rnd[3]);
+    // random_triangle_point (src/math.jl:158-174)
+    float sqrt_r1 = __fsqrt_rn(r1);
+    float wu = 1.0f - sqrt_r1, wv = sqrt_r1 * (1.0f - r2), ww = sqrt_r1 * r2;
+    float3_ pt = add3(add3(scale3(p1, wu), scale3(p2, wv)), scale3(p3, ww));
+    float3_ o = add3(pt, scale3(normal, 0.01f));  // :91
+    // random_hemisphere_uniform (src/math.jl:125-141)
+    float theta = (float)acos_f64((double)xi1);
+    float phi = (2.0f * 3.1415927f) * xi2;
+    double st, ct, sp, cp;
+    sincos_f64((double)theta, st, ct);
+    sincos_f64((double)phi, sp, cp);
+    float sin_t = (float)st, cos_t = (float)ct, sin_p = (float)sp, cos_p = (float)cp;
+    float xl = sin_t * cos_p, yl = sin_t * sin_p, zl = cos_t;
+    float3_ d = add3(add3(scale3(bu, xl), scale3(bv, yl)), scale3(normal, zl));
+    return RcRay{o.x, o.y, o.z, 0.0f, d.x, d.y, d.z, INFINITY};
+}
+
+// view_factors! (:80-104): work item = (source primitive, ray); result[src_meta, hit_meta] += 1 when the
+// hit primitive's metadata differs.  One u32 atomic per counted ray.
+__global__ __launch_bounds__(kBlock) void k_view_factors(SceneView v, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t n_src,
+                                                          uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
+                                                          uint64_t col_stride, uint32_t row_offset) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    LaneStack st{lds_stack + threadIdx.x, v.overflow + gtid, v.total_threads, v.status};
+    const uint64_t total = (uint64_t)n_src * n_ray;
+    for (uint64_t w = gtid; w < total; w += v.total_threads) {
+        uint32_t src = src_begin + (uint32_t)(w / n_ray), ray_idx = ray_begin + (uint32_t)(w % n_ray);
+        const RcPrim tri = v.prims[src];
+        RayState s;
+        trace_ray<false>(s, view_factor_ray(tri, src, ray_idx, k0, k1), v, st);
+        if (s.closest_inst >= 0) {
+            uint32_t hit_meta = v.prims[hit_prim_index(s, v)].meta, src_meta = tri.meta;
+            if (hit_meta != src_meta && src_meta >= 1 && src_meta <= v.n_prims && hit_meta >= 1 && hit_meta <= v.n_prims)
+                atomicAdd(&matrix[(uint64_t)(src_meta - 1 - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride], 1u);
+        }
+    }
+}
+
+__global__ void k_view_factor_rays(SceneView v, uint32_t k0, uint32_t k1, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_ray) out[i] = view_factor_ray(v.prims[src], src, ray_begin + i, k0, k1);
+}
+
+float3_ h_normalize(float3_ a) {
+    float n = sqrtf(dot3(a, a));
+    return mk3(a.x / n, a.y / n, a.z / n);
+}
+
+// generate_ray_grid up to its loop (:10-46), as called from hits_from_grid (:58-61).  Host code compiled
+// with -ffp-contract=off; jl_min/jl_max give extrema() its Julia semantics.
+GridParams grid_params(rc_scene* s, const float viewdir[3], uint32_t grid) {
+    float3_ ray_direction = h_normalize(mk3(viewdir[0], viewdir[1], viewdir[2]));
+    float3_ direction = h_normalize(ray_direction);
+    float3_ o = mk3(s->root_min[0], s->root_min[1], s->root_min[2]);
+    float3_ w = sub3(mk3(s->root_max[0], s->root_max[1], s->root_max[2]), o);
+    float3_ temp = fabsf(direction.x) < 0.9f ? mk3(1, 0, 0) : mk3(0, 1, 0);
+    float3_ b1 = h_normalize(cross3(direction, temp));
+    float3_ b2 = h_normalize(cross3(direction, b1));
+    float min1 = INFINITY, max1 = -INFINITY, min2 = INFINITY, max2 = -INFINITY, mind = INFINITY;
+    for (int c = 0; c < 8; ++c) {
+        float3_ p = mk3(o.x + ((c & 1) ? 1.0f : 0.0f) * w.x, o.y + ((c & 2) ? 1.0f : 0.0f) * w.y, o.z + ((c & 4) ? 1.0f : 0.0f) * w.z);
+        float p1 = dot3(p, b1), p2 = dot3(p, b2), pd = dot3(p, direction);
+        min1 = jl_min(min1, p1); max1 = jl_max(max1, p1);
+        min2 = jl_min(min2, p2); max2 = jl_max(max2, p2);
+        mind = jl_min(mind, pd);
+    }
+    float margin = 0.05f * jl_max(max1 - min1, max2 - min2);
+    float grid_width = max1 - min1 + 2.0f * margin, grid_height = max2 - min2 + 2.0f * margin;
+    float min_depth = mind - margin;
+    float c1 = (min1 + max1) / 2.0f, c2 = (min2 + max2) / 2.0f;
+    float3_ gc = add3(add3(add3(mk3(0, 0, 0), scale3(direction, min_depth)), scale3(b1, c1)), scale3(b2, c2));
+    GridParams g;
+    g.gc[0] = gc.x; g.gc[1] = gc.y; g.gc[2] = gc.z;
+    g.b1[0] = b1.x; g.b1[1] = b1.y; g.b1[2] = b1.z;
+    g.b2[0] = b2.x; g.b2[1] = b2.y; g.b2[2] = b2.z;
+    g.dir[0] = ray_direction.x; g.dir[1] = ray_direction.y; g.dir[2] = ray_direction.z;
+    g.cell_w = grid_width / (float)grid; g.cell_h = grid_height / (float)grid;
+    g.grid = grid;
+    return g;
+}
+
+}  // namespace
+
+void rc_launch_ray_grid(rc_scene* s, const float viewdir[3], uint32_t grid, RcRay* d_rays, hipStream_t stream) {
+    GridParams g = grid_params(s, viewdir, grid);
+    uint64_t n = (uint64_t)grid * grid;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)s->n_cus * 8);
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_ray_grid, dim3(blocks), dim3(kBlock), 0, stream, g, d_rays);
+    RC_HIP(hipGetLastError());
+}
+
+void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, uint64_t ray_begin, uint64_t ray_end,
+                            float* d_counts, hipStream_t stream) {
+    if (ray_end <= ray_begin) return;
+    GridParams g = grid_params(s, viewdir, grid);
+    uint32_t blocks = rc_persistent_blocks(s, ray_end - ray_begin);
+    rc_prepare_launch(s, stream);
+    SceneView v = rc_scene_view(s, blocks * kBlock);
+    RC_HIP(hipEventRecord(s->ev0, stream));
+    hipLaunchKernelGGL(k_illumination, dim3(blocks), dim3(kBlock), 0, stream, v, g, ray_begin, ray_end, d_counts);
+    RC_HIP(hipEventRecord(s->ev1, stream));
+    RC_HIP(hipGetLastError());
+}
+
+void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end,
+                            uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix, uint64_t row_stride, uint64_t col_stride,
+                            uint32_t row_offset, hipStream_t stream) {
+    if (src_end > s->n_flat_prims) src_end = s->n_flat_prims;
+    if (ray_end > rays_per_triangle) ray_end = rays_per_triangle;
+    if (src_begin >= src_end || ray_begin >= ray_end) return;
+    uint64_t total = (uint64_t)(src_end - src_begin) * (ray_end - ray_begin);
+    uint32_t blocks = rc_persistent_blocks(s, total);
+    rc_prepare_launch(s, stream);
+    SceneView v = rc_scene_view(s, blocks * kBlock);
+    RC_HIP(hipEventRecord(s->ev0, stream));
+    hipLaunchKernelGGL(k_view_factors, dim3(blocks), dim3(kBlock), 0, stream, v, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
+                       src_end - src_begin, ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset);
+    RC_HIP(hipEventRecord(s->ev1, stream));
+    RC_HIP(hipGetLastError());
+}
+
+void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream) {
+    if (n_ray == 0) return;
+    SceneView v = rc_scene_view(s, 0);
+    hipLaunchKernelGGL(k_view_factor_rays, dim3((n_ray + 255) / 256), dim3(256), 0, stream, v, (uint32_t)seed, (uint32_t)(seed >> 32), src, ray_begin, n_ray, d_out);
+    RC_HIP(hipGetLastError());
+}

