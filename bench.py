@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of closest_hit on the 1M-triangle instanced TLAS (BASELINE.json config C3).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one closest_hit pass over one batch of 4 194 304 synthetic primary rays (2048 x 2048 pinhole) against
+256 transformed instances of one 4 096-triangle BLAS (1 048 576 triangles), rays and scene already resident in
+HBM.  One process per GPU; rays are independent, so ranks are replicas of the scene tracing their own batch
+(no data-path collective; "scaling": "weak").  Rank 0 prints ONE JSON line.
+
+roofline: achieved = algorithmic bytes per launch / average launch duration (HIP events on the launch stream,
+recorded inside the timed region).  Algorithmic bytes per ray = 32 (RTRay) + 32 (RTHitResult) + 60 x BVHNode2
+fetches + 140 x TLAS-leaf entries of the REFERENCE algorithm on this exact ray set, counted
+by the instrumented CPU oracle in the cpu_baseline leg (N=1); at N>1 the committed count for this workload is used.
+cpu_baseline: the reference algorithm's C restatement (oracle/), all host cores, same rays.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+# Reference-algorithm fetch counts for this workload (avg per ray), measured by the oracle; refreshed by the
+# cpu_baseline leg whenever it runs.  Used only when the oracle leg is skipped (N > 1).
+C3_NODE_FETCHES_PER_RAY = 32.98
+C3_INST_ENTRIES_PER_RAY = 1.92
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--res", type=int, default=2048, help="primary rays = res x res")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    import raycore_jl_amd as rc
+    sc = rc.scenes
+    cfg = sc.config_c3()
+    t = rc.TLAS(local_rank)
+    for verts, meta in cfg["blas"]:
+        t.add_geometry(verts, meta)
+    for b, xf, ids in cfg["instances"]:
+        t.push_instances(b, xf, ids)
+    t.sync()
+    n_tris = t.n_primitives() * t.n_instances()
+
+    rays = sc.c3_primary_rays(cfg, args.res, args.res)
+    n = len(rays)
+    d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+    d_hits = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        t.trace_device(d_rays.data_ptr(), d_hits.data_ptr(), n, mode="closest", stream=stream.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    hits = d_hits.cpu().numpy().view(rc.HIT_DT)
+    hit_frac = float(hits["hit"].mean())
+
+    extras = {}
+    if not args.no_extras and rank == 0:
+        def timed(rs, mode, reps=3):
+            dr = torch.from_numpy(rs.view(np.uint8).reshape(-1)).cuda()
+            dh = torch.empty(len(rs) * 32, dtype=torch.uint8, device="cuda")
+            best = 1e30
+            for _ in range(reps):
+                t.trace_device(dr.data_ptr(), dh.data_ptr(), len(rs), mode=mode, stream=stream.cuda_stream)
+                best = min(best, t.last_kernel_ms())
+            return round(len(rs) / best / 1e3, 1)
+        shadow = sc.c3_shadow_rays(cfg, rays, hits)
+        extras["c3_any_hit_shadow_mrays_s"] = timed(shadow, "any")
+        bounce = sc.c4_bounce_rays(cfg, rays, hits, 4 * n)
+        extras["c4_incoherent_16M_closest_mrays_s"] = timed(bounce, "closest")
+        del bounce, shadow
+        cfg2 = sc.config_c2()
+        t2 = rc.TLAS(local_rank)
+        t2.add_geometry(*cfg2["blas"][0])
+        t2.push_instances(1, cfg2["instances"][0][1], cfg2["instances"][0][2])
+        t2.sync()
+        extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"]), "closest", reps=5)
+        t2.free()
+
+    node_f, inst_f = C3_NODE_FETCHES_PER_RAY, C3_INST_ENTRIES_PER_RAY
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # The oracle is the checker / CPU baseline only; nothing above this line touches it.
+        from oracle import pyoracle as po
+        o = po.Scene()
+        for verts, meta in cfg["blas"]:
+            o.add_blas(verts, meta)
+        for b, xf, ids in cfg["instances"]:
+            for x, i in zip(xf, ids):
+                o.add_instance(b, x, int(i))
+        o.build()
+        cores = os.cpu_count() or 1
+        o.trace(rays[:65536], nthreads=cores)  # warm
+        c0 = time.perf_counter()
+        ohits, cnt = o.trace(rays, nthreads=cores, counters=True)
+        cdt = time.perf_counter() - c0
+        node_f, inst_f = float(cnt[:, 0].mean()), float(cnt[:, 1].mean())
+        same = bool(np.array_equal(ohits["primitive_id"], hits["primitive_id"]) and np.array_equal(ohits["instance_id"], hits["instance_id"])
+                    and np.array_equal(ohits["t"].view(np.uint32), hits["t"].view(np.uint32)))
+        cpu_baseline = {"value": round(n / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                        "sample": f"all {n} primary rays of the workload, closest_hit, C restatement of the reference algorithm "
+                                  f"(oracle/, gcc -O2, {cores} pthreads), {cdt:.1f} s", "gpu_matches_bit_exact": same}
+
+    if rank == 0:
+        bytes_per_ray = 32 + 32 + 60.0 * node_f + 140.0 * inst_f
+        achieved = bytes_per_ray * n / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("c3_closest_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s closest_hit (1M-tri TLAS)", "value": round(world * n * args.steps / elapsed / 1e6, 1), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: TLAS of 256 rotated/scaled instances of one 4096-triangle BLAS (1 048 576 triangles), "
+                                   f"{n} pinhole primary rays per GPU per step, closest_hit",
+                       "triangles": int(n_tris), "rays_per_step_per_gpu": n, "hit_fraction": round(hit_frac, 4),
+                       "kernel": "persistent" if t.get_option("kernel") == 1 else "simple", "parallelism": f"replicas x{world} (rays sharded, no collective)"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "kernel": "k_trace_*<closest>", "avg_launch_ms": round(launch_ms, 4),
+                         "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3)},
+            "cpu_baseline": cpu_baseline,
+            "extras": extras,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

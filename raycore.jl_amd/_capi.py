@@ -86,6 +86,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RaycoreError(-1, f"{LIB_PATH} is missing: build it with `make -C raycore.jl_amd/csrc` "
                                    "(or __graft_entry__.build()); there is no fallback path")
+        try:
+            # PyTorch ships its own libamdhip64; a process must initialise ONE HIP runtime, and device
+            # pointers are shared with torch tensors (torch.distributed / RCCL), so let torch load first.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             f = getattr(L, name)  # AttributeError here = the library does not export a declared symbol
