@@ -301,7 +301,7 @@ __global__ void k_tlas_leaves(RcNode* nodes, const uint32_t* sorted, const RcIns
 }
 
 // Traversal-side instance records: inverse transform + the BLAS offsets it would otherwise chase.
-__global__ void k_inst_recs(const RcInstanceDesc* inst, const RcBlasDesc* descs, uint32_t n, RcInstRec* out) {
+__global__ void k_inst_recs(const RcInstanceDesc* inst, const RcBlasDesc* descs, const uint32_t* blas_nprims, uint32_t n, RcInstRec* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const RcInstanceDesc& in = inst[i];
@@ -311,7 +311,7 @@ __global__ void k_inst_recs(const RcInstanceDesc* inst, const RcBlasDesc* descs,
     r.nodes_offset = descs[in.blas_index - 1].nodes_offset;
     r.prims_offset = descs[in.blas_index - 1].primitives_offset;
     r.custom_index = in.instance_id;
-    r.blas_id = in.blas_index - 1;
+    r.n_prims = blas_nprims[in.blas_index - 1];
     out[i] = r;
 }
 
@@ -420,6 +420,10 @@ void rc_build_tlas(rc_scene* s) {
         RC_HIP(hipMemcpyAsync(s->flat_prims.p + s->descs[i].primitives_offset, s->blas[i].prims.p, sizeof(RcPrim) * s->blas[i].n_prims, hipMemcpyDeviceToDevice, s->stream));
     }
     if (nb) RC_HIP(hipMemcpyAsync(s->d_descs.p, s->descs.data(), sizeof(RcBlasDesc) * nb, hipMemcpyHostToDevice, s->stream));
+    s->blas_nprims.resize(nb);
+    for (uint32_t i = 0; i < nb; ++i) s->blas_nprims[i] = s->blas[i].n_prims;
+    s->d_blas_nprims.reserve(nb ? nb : 1);
+    if (nb) RC_HIP(hipMemcpyAsync(s->d_blas_nprims.p, s->blas_nprims.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, s->stream));
     s->n_static_instances = n;
     if (n == 0) {  // :969-977
         s->n_tlas_nodes = 0;
@@ -432,7 +436,7 @@ void rc_build_tlas(rc_scene* s) {
     s->tlas_nodes.reserve(2 * (size_t)n - 1);
     s->n_tlas_nodes = 2 * n - 1;
     RC_HIP(hipMemcpyAsync(s->d_instances.p, s->instances.data(), sizeof(RcInstanceDesc) * n, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, n, s->inst_recs.p);
+    hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p);
     hipLaunchKernelGGL(k_init_scene_enc, dim3(1), dim3(64), 0, s->stream, s->scene_enc.p);
     hipLaunchKernelGGL(k_instance_aabbs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, n, s->aabb_tmp.p, s->scene_enc.p);
     hipLaunchKernelGGL(k_tlas_morton, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, n, s->scene_enc.p, s->keys_a.p, s->vals_a.p);
@@ -454,7 +458,7 @@ void rc_refit_tlas(rc_scene* s) {
     if (n == 0) return;
     reserve_build_scratch(s, n);
     RC_HIP(hipMemcpyAsync(s->d_instances.p, s->instances.data(), sizeof(RcInstanceDesc) * n, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, n, s->inst_recs.p);
+    hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p);
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, (const uint32_t*)nullptr, s->d_instances.p, s->d_descs.p, n);
     run_refit(s, s->tlas_nodes.p, n, 1);
     RcNode root;

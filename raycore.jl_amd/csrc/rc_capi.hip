@@ -405,6 +405,11 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     std::string k(name);
     if (k == "kernel") s->opt.kernel = value;
     else if (k == "blocks_per_cu") s->opt.blocks_per_cu = value;
+    else if (k == "lds_stack") s->opt.lds_stack = value;
+    else if (k == "refill") s->opt.refill = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (k == "stats") s->opt.stats = value;
+    else if (k == "pool") s->opt.pool = value;
+    else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
     return RC_OK;
 }
@@ -414,6 +419,15 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     if (k == "kernel") *value = s->opt.kernel;
     else if (k == "blocks_per_cu") *value = s->opt.blocks_per_cu;
     else if (k == "n_cus") *value = s->n_cus;
+    else if (k == "lds_stack") *value = s->opt.lds_stack;
+    else if (k == "refill") *value = s->opt.refill;
+    else if (k.rfind("stat", 0) == 0 && k.size() == 5 && k[4] >= '0' && k[4] <= '7') {
+        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipSetDevice(s->device);
+        (void)hipDeviceSynchronize();
+        if (s->counters.p && hipMemcpy(st, s->counters.p + 8, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "stats read failed");
+        *value = (int64_t)st[k[4] - '0'];
+    }
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
     return RC_OK;
 }

@@ -24,7 +24,7 @@ static_assert(sizeof(RcNode) == 64, "RcNode must be 64 bytes");
 // reference's 108-byte + 32-byte pair.
 struct __attribute__((aligned(64))) RcInstRec {
     float inv[12];  // inv_transform, Vulkan row-major 3x4
-    uint32_t nodes_offset, prims_offset, custom_index, blas_id;
+    uint32_t nodes_offset, prims_offset, custom_index, n_prims;  // n_prims of the instance's BLAS: node index >= n_prims <=> leaf
 };
 static_assert(sizeof(RcInstRec) == 64, "RcInstRec must be 64 bytes");
 

@@ -62,9 +62,13 @@ struct HandleRange {
 };
 
 struct TraceOptions {
-    int64_t kernel = 1;        // 0 = one-ray-per-lane baseline, 1 = persistent wave-refill kernel
-    int64_t block = 256;
-    int64_t blocks_per_cu = 0; // 0 = derive from occupancy
+    int64_t kernel = -1;       // -1 = auto, 0 = one-ray-per-lane, 1 = persistent wave-refill, 2 = persistent + per-wave path scheduling
+    int64_t blocks_per_cu = 0; // 0 = derive from the LDS stack depth
+    int64_t lds_stack = 24;    // per-lane stack entries kept in LDS: 12, 16, 24 or 32
+    int64_t pool = 0;          // persistent kernels: ray indices per atomic claim (0 = auto 64..512)
+    int64_t refill = 20;       // persistent kernel: refill when this many lanes of a wave are idle
+    int64_t sched_thr = 16;    // scheduled kernel: lanes that must wait for a leaf/entry batch before it runs
+    int64_t stats = 0;         // dev instrumentation (persistent kernels only)
 };
 
 struct rc_scene {
@@ -94,6 +98,8 @@ struct rc_scene {
     uint32_t n_flat_prims = 0;
     DevBuf<RcBlasDesc> d_descs;
     std::vector<RcBlasDesc> descs;
+    DevBuf<uint32_t> d_blas_nprims;
+    std::vector<uint32_t> blas_nprims;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 
     // scratch

@@ -19,7 +19,7 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
     const RcPrim* prims;
     uint32_t n_tlas_nodes;
     uint32_t n_prims;
-    uint32_t* overflow;       // [kTotalStack - kLdsStack][total_threads] spill area of the lane stacks
+    uint32_t* overflow;       // [kTotalStack][total_threads] spill area of the lane stacks (entries below the LDS depth unused)
     uint32_t total_threads;
     uint32_t* status;         // [0] = stack overflow flag
 };
@@ -30,24 +30,30 @@ struct TraceArgs {
     RcHit* hits;
     uint64_t n_rays;
     unsigned long long* work_counter;  // persistent kernel: next unclaimed ray index
+    int refill;                        // persistent kernel: refill when this many lanes are idle
+    uint32_t pool;                     // persistent kernels: ray indices claimed per atomic
+    int sched_thr;                     // scheduled kernel: run a leaf/entry batch once this many lanes wait for it
+    unsigned long long* stats;         // optional instrumentation (dev builds), else nullptr
 };
 
-struct LaneStack {
+template <int LDS_N>
+struct LaneStackT {
     uint32_t* lds;       // &lds_stack[threadIdx.x]
     uint32_t* ovf;       // &overflow[global thread id]
     uint32_t ovf_stride;
     uint32_t* status;
     __device__ inline void push(int& sp, uint32_t v) {
-        if (sp < kLdsStack) lds[sp * kBlock] = v;
-        else if (sp < kTotalStack) ovf[(size_t)(sp - kLdsStack) * ovf_stride] = v;
+        if (sp < LDS_N) lds[sp * kBlock] = v;
+        else if (sp < kTotalStack) ovf[(size_t)(sp - LDS_N) * ovf_stride] = v;
         else { *status = 1u; return; }
         ++sp;
     }
     __device__ inline uint32_t pop(int& sp) {
         --sp;
-        return sp < kLdsStack ? lds[sp * kBlock] : ovf[(size_t)(sp - kLdsStack) * ovf_stride];
+        return sp < LDS_N ? lds[sp * kBlock] : ovf[(size_t)(sp - LDS_N) * ovf_stride];
     }
 };
+using LaneStack = LaneStackT<kLdsStack>;
 
 struct NodeRegs {
     float4 a, b, c;
@@ -75,7 +81,8 @@ struct RayState {
     int sp;
 };
 
-__device__ inline void init_ray(RayState& s, const RcRay& r, bool any_hit, LaneStack& st) {
+template <class Stack>
+__device__ inline void init_ray(RayState& s, const RcRay& r, bool any_hit, Stack& st) {
     // check_direction (src/ray.jl:39-49): -0 and +0 both become +0
     s.wo = mk3(r.ox, r.oy, r.oz);
     s.wd = mk3(r.dx == 0.0f ? 0.0f : r.dx, r.dy == 0.0f ? 0.0f : r.dy, r.dz == 0.0f ? 0.0f : r.dz);
@@ -105,8 +112,8 @@ __device__ inline void slab(const RayState& s, float mnx, float mny, float mnz, 
 }
 
 // One iteration of the reference's while loop (:1936-2007).  Returns false when the ray has terminated.
-template <bool ANY>
-__device__ inline bool step(RayState& s, const SceneView& a, LaneStack& st) {
+template <bool ANY, class Stack>
+__device__ inline bool step(RayState& s, const SceneView& a, Stack& st) {
     const RcNode* np = (s.cur_inst < 0) ? (a.tlas_nodes + (s.node - 1)) : (a.blas_nodes + (s.blas_off + s.node - 1));
     NodeRegs nd = load_node(np);
     if (nd.d.x != RC_INVALID_NODE) {
@@ -192,8 +199,8 @@ __device__ inline RcRay load_ray(const RcRay* rays, uint64_t i) {
 
 
 // Whole-ray traversal for callers that do not interleave rays (drivers).
-template <bool ANY>
-__device__ inline void trace_ray(RayState& s, const RcRay& r, const SceneView& a, LaneStack& st) {
+template <bool ANY, class Stack>
+__device__ inline void trace_ray(RayState& s, const RcRay& r, const SceneView& a, Stack& st) {
     init_ray(s, r, ANY, st);
     if (a.n_tlas_nodes != 0)
         while (step<ANY>(s, a, st)) {}

@@ -42,12 +42,11 @@ def build(cfg):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernels", default="0,1")
-    ap.add_argument("--bpc", default="0")
+    ap.add_argument("--variants", default="kernel=0;kernel=1", help="';'-separated option sets, each 'k=v,k=v'")
     ap.add_argument("--c3res", type=int, default=2048)
+    ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--workloads", default="c2,c3,shadow,c4")
     args = ap.parse_args()
-    kernels = [int(k) for k in args.kernels.split(",")]
-    bpcs = [int(k) for k in args.bpc.split(",")]
     sc = rc.scenes
     cfg2 = sc.config_c2()
     t0 = time.time(); t2 = build(cfg2); print(f"C2 build+sync {time.time()-t0:.3f}s")
@@ -58,14 +57,33 @@ def main():
     ms, hits3 = time_trace(t3, rays3, "closest", 1)
     shadow = sc.c3_shadow_rays(cfg3, rays3, hits3)
     bounce = sc.c4_bounce_rays(cfg3, rays3, hits3, 4 * len(rays3))
-    for k in kernels:
-        for bpc in bpcs:
-            for t in (t2, t3):
-                t.set_option("kernel", k); t.set_option("blocks_per_cu", bpc)
-            for name, t, rays, mode in (("C2 closest", t2, rays2, "closest"), ("C3 primary", t3, rays3, "closest"),
-                                        ("C3 shadow-any", t3, shadow, "any"), ("C4 bounce", t3, bounce, "closest")):
-                ms, hits = time_trace(t, rays, mode)
-                print(f"kernel={k} bpc={bpc} {name:14s} n={len(rays):9d} {ms:9.3f} ms  {len(rays)/ms/1e3:9.1f} Mrays/s  hit={hits['hit'].mean():.3f}", flush=True)
+    wl = {"c2": ("C2 closest", t2, rays2, "closest"), "c3": ("C3 primary", t3, rays3, "closest"),
+          "shadow": ("C3 shadow-any", t3, shadow, "any"), "c4": ("C4 bounce", t3, bounce, "closest")}
+    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 16, "pool": 0}
+    for var in args.variants.split(";"):
+        opts = dict(defaults)
+        for kv in var.split(","):
+            if kv:
+                k, v = kv.split("=")
+                opts[k] = int(v)
+        for t in (t2, t3):
+            for k, v in opts.items():
+                t.set_option(k, v)
+        for w in args.workloads.split(","):
+            name, t, rays, mode = wl[w]
+            ms, hits = time_trace(t, rays, mode)
+            extra = ""
+            if args.stats and opts["kernel"] in (1, 2):
+                t.set_option("stats", 1)
+                time_trace(t, rays, mode, 1)
+                v = [t.get_option(f"stat{i}") for i in range(8)]
+                t.set_option("stats", 0)
+                if opts["kernel"] == 1:
+                    extra = f" wave_steps={v[0]} lanes/step={v[1]/max(v[0],1):.1f} max_sp={v[2]}"
+                else:
+                    extra = (f" iters={v[0]} live/iter={v[1]/max(v[0],1):.1f} | I {v[2]} x{v[3]/max(v[2],1):.1f} | L {v[4]} x{v[5]/max(v[4],1):.1f}"
+                             f" | E {v[6]} x{v[7]/max(v[6],1):.1f}")
+            print(f"[{var:40s}] {name:14s} n={len(rays):9d} {ms:9.3f} ms  {len(rays)/ms/1e3:9.1f} Mrays/s  hit={hits['hit'].mean():.3f}{extra}", flush=True)
 
 
 if __name__ == "__main__":
