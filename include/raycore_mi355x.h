@@ -175,12 +175,16 @@ int rc_get_illumination_device(rc_scene* scene, const float viewdir[3], uint32_t
  * by Philox4x32-10: key = seed, counter = (ray_idx, src_prim_index, 0, 0) -> (r1, r2, xi1, xi2), so a result
  * does not depend on how the work is sharded.  Shoots rays [ray_begin, ray_end) of source primitives
  * [src_begin, src_end) and ACCUMULATES into d_matrix (device, u32): element (src_meta-1, hit_meta-1) lives
- * at (src_meta-1-row_offset)*row_stride + (hit_meta-1)*col_stride.  Julia's column-major N x N Matrix is
- * row_stride=1, col_stride=N, row_offset=0; a row-sharded block is row_stride=N, col_stride=1,
- * row_offset=src_begin (metadata == primitive index + 1 assumed for row shards). */
+ * at (row - row_offset)*row_stride + (hit_meta-1)*col_stride with row = src_meta-1, or -- with
+ * RC_VF_ROW_BY_PRIMITIVE in flags -- row = the source's index in the flat (Morton-sorted) primitive array,
+ * which is what makes a contiguous source range own a contiguous row block.  Julia's column-major N x N
+ * Matrix is row_stride=1, col_stride=N, row_offset=0, flags=0; a row-sharded block is row_stride=N,
+ * col_stride=1, row_offset=src_begin, flags=RC_VF_ROW_BY_PRIMITIVE (the gatherer then permutes rows by
+ * metadata once). */
+#define RC_VF_ROW_BY_PRIMITIVE 1u
 int rc_view_factors_device(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin,
                            uint32_t src_end, uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix,
-                           uint64_t row_stride, uint64_t col_stride, uint32_t row_offset, void* stream);
+                           uint64_t row_stride, uint64_t col_stride, uint32_t row_offset, uint32_t flags, void* stream);
 /* Whole job into a host N x N column-major matrix (the Julia return value). */
 int rc_view_factors(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix);
 /* The rays view_factors shoots for one source primitive (ray indices [ray_begin, ray_begin + n_rays)),

@@ -63,7 +63,7 @@ SYMBOLS = [
     ("rc_generate_ray_grid_device", _int, [_vp, _vp, _u32, _vp, _vp]),
     ("rc_get_illumination", _int, [_vp, _vp, _u32, _vp]),
     ("rc_get_illumination_device", _int, [_vp, _vp, _u32, _u64, _u64, _vp, _vp]),
-    ("rc_view_factors_device", _int, [_vp, _u32, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _u64, _u32, _vp]),
+    ("rc_view_factors_device", _int, [_vp, _u32, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _u64, _u32, _u32, _vp]),
     ("rc_view_factors", _int, [_vp, _u32, _u64, _vp]),
     ("rc_view_factor_rays_device", _int, [_vp, _u64, _u32, _u32, _u32, _vp, _vp]),
     ("rc_last_kernel_ms", _int, [_vp, _pf]),

@@ -468,12 +468,12 @@ int rc_get_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, floa
 }
 
 int rc_view_factors_device(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end, uint32_t ray_begin,
-                           uint32_t ray_end, uint32_t* d_matrix, uint64_t row_stride, uint64_t col_stride, uint32_t row_offset, void* stream) {
+                           uint32_t ray_end, uint32_t* d_matrix, uint64_t row_stride, uint64_t col_stride, uint32_t row_offset, uint32_t flags, void* stream) {
     if (!s || !d_matrix) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {
         use_device(s);
         require_synced(s);
-        rc_launch_view_factors(s, rays_per_triangle, seed, src_begin, src_end, ray_begin, ray_end, d_matrix, row_stride, col_stride, row_offset, (hipStream_t)stream);
+        rc_launch_view_factors(s, rays_per_triangle, seed, src_begin, src_end, ray_begin, ray_end, d_matrix, row_stride, col_stride, row_offset, flags, (hipStream_t)stream);
     });
 }
 
@@ -487,7 +487,7 @@ int rc_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint
         DevBuf<uint32_t> m;
         m.reserve(np * np);
         RC_HIP(hipMemsetAsync(m.p, 0, sizeof(uint32_t) * np * np, s->stream));
-        rc_launch_view_factors(s, rays_per_triangle, seed, 0, (uint32_t)np, 0, rays_per_triangle, m.p, 1, np, 0, s->stream);
+        rc_launch_view_factors(s, rays_per_triangle, seed, 0, (uint32_t)np, 0, rays_per_triangle, m.p, 1, np, 0, 0, s->stream);
         RC_HIP(hipMemcpyAsync(out_matrix, m.p, sizeof(uint32_t) * np * np, hipMemcpyDeviceToHost, s->stream));
         check_status(s, s->stream);
         RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));

@@ -166,7 +166,7 @@ __device__ inline RcRay view_factor_ray(const RcPrim& tri, uint32_t src, uint32_
 // hit primitive's metadata differs.  One u32 atomic per counted ray.
 __global__ __launch_bounds__(kBlock) void k_view_factors(SceneView v, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t n_src,
                                                           uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
-                                                          uint64_t col_stride, uint32_t row_offset) {
+                                                          uint64_t col_stride, uint32_t row_offset, uint32_t flags) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     LaneStack st{lds_stack + threadIdx.x, v.overflow + gtid, v.total_threads, v.status};
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_view_factors(SceneView v, uint32_t k
         if (s.closest_inst >= 0) {
             uint32_t hit_meta = v.prims[hit_prim_index(s, v)].meta, src_meta = tri.meta;
             if (hit_meta != src_meta && src_meta >= 1 && src_meta <= v.n_prims && hit_meta >= 1 && hit_meta <= v.n_prims)
-                atomicAdd(&matrix[(uint64_t)(src_meta - 1 - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride], 1u);
+                atomicAdd(&matrix[(uint64_t)(((flags & 1u) ? src : src_meta - 1) - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride], 1u);
         }
     }
 }
@@ -253,7 +253,7 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
 
 void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end,
                             uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix, uint64_t row_stride, uint64_t col_stride,
-                            uint32_t row_offset, hipStream_t stream) {
+                            uint32_t row_offset, uint32_t flags, hipStream_t stream) {
     if (src_end > s->n_flat_prims) src_end = s->n_flat_prims;
     if (ray_end > rays_per_triangle) ray_end = rays_per_triangle;
     if (src_begin >= src_end || ray_begin >= ray_end) return;
@@ -263,7 +263,7 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     SceneView v = rc_scene_view(s, blocks * kBlock);
     RC_HIP(hipEventRecord(s->ev0, stream));
     hipLaunchKernelGGL(k_view_factors, dim3(blocks), dim3(kBlock), 0, stream, v, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
-                       src_end - src_begin, ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset);
+                       src_end - src_begin, ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
 }

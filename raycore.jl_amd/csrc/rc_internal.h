@@ -131,7 +131,7 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
                             float* d_counts, hipStream_t stream);
 void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end,
                             uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix, uint64_t row_stride,
-                            uint64_t col_stride, uint32_t row_offset, hipStream_t stream);
+                            uint64_t col_stride, uint32_t row_offset, uint32_t flags, hipStream_t stream);
 
 // rc_traverse.hip helpers shared with rc_drivers.hip
 namespace rc { struct SceneView; }

@@ -266,11 +266,20 @@ def test_view_factors_parity(rc, oracle):
     import torch
     m = torch.zeros(n * n, dtype=torch.int32, device="cuda")
     from raycore_jl_amd._capi import check, lib, ptr
-    check(lib().rc_view_factors_device(t._h, 256, 1234, 0, n // 2, 0, 256, ptr(m.data_ptr()), 1, n, 0, None))
-    check(lib().rc_view_factors_device(t._h, 256, 1234, n // 2, n, 0, 100, ptr(m.data_ptr()), 1, n, 0, None))
-    check(lib().rc_view_factors_device(t._h, 256, 1234, n // 2, n, 100, 256, ptr(m.data_ptr()), 1, n, 0, None))
+    check(lib().rc_view_factors_device(t._h, 256, 1234, 0, n // 2, 0, 256, ptr(m.data_ptr()), 1, n, 0, 0, None))
+    check(lib().rc_view_factors_device(t._h, 256, 1234, n // 2, n, 0, 100, ptr(m.data_ptr()), 1, n, 0, 0, None))
+    check(lib().rc_view_factors_device(t._h, 256, 1234, n // 2, n, 100, 256, ptr(m.data_ptr()), 1, n, 0, 0, None))
     torch.cuda.synchronize()
     assert np.array_equal(m.cpu().numpy().view(np.uint32).reshape(n, n).T, got)  # column-major [src + N*dst]
+    # the multi-GPU driver on one rank: both partitions reproduce the matrix (row-major [src][dst])
+    from raycore_jl_amd import distributed as rd
+    for mode in ("rays", "rows"):
+        out = rd.view_factors_distributed(t, 256, 1234, mode=mode)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), got), mode
+    il = rd.get_illumination_distributed(t, [0.3, 0.2, 1.0], 128)
+    torch.cuda.synchronize()
+    assert np.array_equal(il.cpu().numpy(), rc.get_illumination(t, [0.3, 0.2, 1.0], 128))
 
 
 # ---- lifecycle (handles, dirty flags, refit identity, errors) -------------------------------------------------

@@ -1,0 +1,90 @@
+"""Independent checks of the oracle itself: BVH traversal vs an all-pairs brute-force Moeller-Trumbore,
+structural invariants of the LBVH, determinism of the drivers."""
+import numpy as np
+import pytest
+
+from helpers import build_oracle, random_rays
+
+
+@pytest.fixture(scope="module")
+def rc():
+    import raycore_jl_amd
+    return raycore_jl_amd
+
+
+def small_scene(rc):
+    sc = rc.scenes
+    xf, _, _ = sc.lattice_transforms(2, 2, 2, 1.3, 5)
+    return {"blas": [(sc.random_triangles(300, 3, lo=-0.5, hi=0.5, edge=0.15), None), (sc.fan_sphere(10, 6), None)],
+            "instances": [(1, xf[:4], np.arange(4, dtype=np.uint32)), (2, xf[4:], np.arange(4, dtype=np.uint32) + 10)]}
+
+
+def test_traversal_matches_brute_force(rc, oracle):
+    o = build_oracle(oracle, small_scene(rc))
+    wb = o.world_bound
+    rays = random_rays(rc, 3000, 1, wb[:3], wb[3:])
+    bvh, brute = o.trace(rays), o.brute(rays)
+    assert np.array_equal(bvh["hit"], brute["hit"])
+    hit = bvh["hit"] == 1
+    assert 0.1 < hit.mean() < 0.95
+    # same arithmetic on the same local ray => the closest t is bit-identical; ids may differ only on exact ties
+    assert np.array_equal(bvh["t"][hit].view(np.uint32), brute["t"][hit].view(np.uint32))
+    same = (bvh["primitive_id"] == brute["primitive_id"]) & (bvh["instance_id"] == brute["instance_id"])
+    assert same[hit].mean() > 0.999
+
+
+def test_any_hit_consistent_with_closest(rc, oracle):
+    o = build_oracle(oracle, small_scene(rc))
+    wb = o.world_bound
+    rays = random_rays(rc, 5000, 2, wb[:3], wb[3:])
+    closest, anyh = o.trace(rays), o.trace(rays, mode="any")
+    assert np.array_equal(closest["hit"], anyh["hit"])          # t_min = 0 in both
+    assert np.all(anyh["t"][anyh["hit"] == 1] >= closest["t"][closest["hit"] == 1])
+    rays["tmin"] = 0.75                                         # closest_hit honours t_min, any_hit ignores it
+    assert np.array_equal(o.trace(rays, mode="any")["hit"], anyh["hit"])
+    assert o.trace(rays)["hit"].sum() <= closest["hit"].sum()
+
+
+def test_lbvh_structure(rc, oracle):
+    o = build_oracle(oracle, rc.scenes.config_c1())
+    nodes, prims = o.blas_nodes, o.blas_prims
+    n = len(prims)
+    assert len(nodes) == 2 * n - 1 and n == 1012                # 1058 faces - 46 degenerate pole faces
+    codes = o.blas_morton(1)
+    assert np.all(np.diff(codes.astype(np.int64)) >= 0)
+    interior, leaves = nodes[:n - 1], nodes[n - 1:]
+    assert np.all(interior["child0"] != oracle.INVALID_NODE) and np.all(leaves["child0"] == oracle.INVALID_NODE)
+    assert np.array_equal(leaves["child1"], np.arange(1, n + 1))
+    # every node except the root has exactly one parent, and parent links agree with child links
+    kids = np.concatenate([interior["child0"], interior["child1"]])
+    assert sorted(kids.tolist()) == list(range(2, 2 * n))
+    for i in (0, 5, n - 2):
+        for c in (interior[i]["child0"], interior[i]["child1"]):
+            assert nodes[c - 1]["parent"] == i + 1
+    # a parent's child boxes contain the grandchildren's boxes (refit is a min/max union)
+    for i in range(0, n - 1, 37):
+        c0 = interior[i]["child0"]
+        if c0 < n:
+            ch = nodes[c0 - 1]
+            assert np.all(interior[i]["aabb0_min"] == np.minimum(ch["aabb0_min"], ch["aabb1_min"]))
+            assert np.all(interior[i]["aabb0_max"] == np.maximum(ch["aabb0_max"], ch["aabb1_max"]))
+
+
+def test_view_factors_shard_sum_and_determinism(rc, oracle):
+    sc = rc.scenes
+    verts = np.concatenate([sc.fan_sphere(8, 5, radius=0.5), sc.box_room((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5), 1)])
+    n = len(verts)
+    o = oracle.Scene()
+    b = o.add_blas(verts, np.arange(1, n + 1, dtype=np.uint32))
+    o.add_instance(b)
+    o.build()
+    full = o.view_factors(128, seed=7, nthreads=4)
+    assert np.array_equal(full, o.view_factors(128, seed=7, nthreads=1))
+    parts = o.view_factors(128, seed=7, src=(0, n // 3)) + o.view_factors(128, seed=7, src=(n // 3, n), rays=(0, 50)) \
+        + o.view_factors(128, seed=7, src=(n // 3, n), rays=(50, 128))
+    assert np.array_equal(full, parts)
+    assert not np.array_equal(full, o.view_factors(128, seed=8))
+    # closed room: every ray from the sphere hits a wall; rays from walls hit sphere or another wall
+    assert np.all(full.sum(axis=1)[:len(sc.fan_sphere(8, 5))] == 128)
+    r = o.view_factor_ray(0, 0, seed=7)
+    assert np.isfinite(r["o"]).all() and abs(np.linalg.norm(r["d"]) - 1) < 1e-5
