@@ -122,6 +122,32 @@ def main():
         extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"]), "closest", reps=5)
         t2.free()
 
+    if not args.no_extras:
+        # view_factors (BASELINE config C5: ~50k-triangle closed scene, rays_per_triangle = 4096 => 204.9 M rays, N x N
+        # u32 = 10 GB) through the multi-GPU driver: every rank takes part; both partitions are timed.
+        from raycore_jl_amd import distributed as rd
+        cfg5 = sc.config_c5()
+        t5 = rc.TLAS(local_rank)
+        t5.add_geometry(*cfg5["blas"][0])
+        t5.push_instances(1, cfg5["instances"][0][1], cfg5["instances"][0][2])
+        t5.sync()
+        n5, rpt = t5.n_primitives(), cfg5["rays_per_triangle"]
+        vf = {"n_prims": n5, "rays_per_triangle": rpt, "n_rays": n5 * rpt, "matrix_bytes": 4 * n5 * n5}
+        for mode in ("rows", "rays"):
+            rd.view_factors_distributed(t5, 4, 7, mode=mode)  # warm-up: allocator, RCCL channels
+            fence()
+            v0 = time.perf_counter()
+            m = rd.view_factors_distributed(t5, rpt, 7, mode=mode)
+            fence()
+            vdt = time.perf_counter() - v0
+            if rank == 0:
+                vf[mode] = {"seconds": round(vdt, 4), "Mrays_s": round(n5 * rpt / vdt / 1e6, 1), "counted": int(m.sum(dtype=torch.int64).item())}
+            del m
+            torch.cuda.empty_cache()
+        t5.free()
+        if rank == 0:
+            extras["view_factors_c5"] = vf
+
     node_f, inst_f = C3_NODE_FETCHES_PER_RAY, C3_INST_ENTRIES_PER_RAY
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
