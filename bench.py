@@ -189,7 +189,7 @@ def main():
             "config": {"workload": "C3: TLAS of 256 rotated/scaled instances of one 4096-triangle BLAS (1 048 576 triangles), "
                                    f"{n} pinhole primary rays per GPU per step, closest_hit",
                        "triangles": int(n_tris), "rays_per_step_per_gpu": n, "hit_fraction": round(hit_frac, 4),
-                       "kernel": {-1: "auto", 0: "simple", 1: "persistent", 2: "scheduled"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
+                       "kernel": {-1: "auto (phased persistent)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": "k_trace_*<closest>", "avg_launch_ms": round(launch_ms, 4),
                          "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3)},

@@ -539,6 +539,11 @@ static inline void intersect_internal_node(const rco_node* node, v3 inv_d, v3 ra
  * there.  The restatement uses 512 entries so every tree it can build is defined. */
 #define RCO_STACK 512
 
+/* dev instrumentation: per-node visit histograms (not thread-safe; used single-threaded) */
+static uint32_t* g_hist_tlas = NULL;
+static uint32_t* g_hist_blas = NULL;
+void rco_set_histograms(uint32_t* tlas, uint32_t* blas) { g_hist_tlas = tlas; g_hist_blas = blas; }
+
 static void set_miss(rco_hit* h) {
     h->hit = 0; h->t = 0.0f; h->primitive_id = 0xFFFFFFFFu; h->instance_custom_index = 0;
     h->bary_u = 0.0f; h->bary_v = 0.0f; h->instance_id = 0xFFFFFFFFu; h->_pad = 0;
@@ -571,6 +576,7 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
         const rco_node* node = (current_instance < 0) ? &s->nodes[node_index - 1]
                                                       : &s->blas_nodes[current_blas_offset + node_index - 1];
         ++n_node;
+        if (g_hist_tlas) { if (current_instance < 0) g_hist_tlas[node_index - 1]++; else g_hist_blas[current_blas_offset + node_index - 1]++; }
         int is_leaf = node->child0 == RCO_INVALID_NODE;
         if (!is_leaf) {
             uint32_t near_c, far_c;

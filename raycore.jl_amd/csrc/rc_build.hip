@@ -414,7 +414,9 @@ void rc_build_tlas(rc_scene* s) {
         tn += s->blas[i].n_nodes; tp += s->blas[i].n_prims;
     }
     s->n_flat_nodes = tn; s->n_flat_prims = tp;
-    s->flat_nodes.reserve(tn ? tn : 1); s->flat_prims.reserve(tp ? tp : 1); s->d_descs.reserve(nb ? nb : 1);
+    s->flat_nodes.reserve((size_t)tn + 2 * (size_t)n + 1);  // + room for the TLAS copy behind the BLAS nodes
+    s->flat_prims.reserve(tp ? tp : 1);
+    s->d_descs.reserve(nb ? nb : 1);
     for (uint32_t i = 0; i < nb; ++i) {
         RC_HIP(hipMemcpyAsync(s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].nodes.p, sizeof(RcNode) * s->blas[i].n_nodes, hipMemcpyDeviceToDevice, s->stream));
         RC_HIP(hipMemcpyAsync(s->flat_prims.p + s->descs[i].primitives_offset, s->blas[i].prims.p, sizeof(RcPrim) * s->blas[i].n_prims, hipMemcpyDeviceToDevice, s->stream));
@@ -445,6 +447,7 @@ void rc_build_tlas(rc_scene* s) {
     // n == 1 (:1553-1570): the single leaf holds the scene AABB == the instance's world AABB (same min/max set)
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->vals_b.p, s->d_instances.p, s->d_descs.p, n);
     run_refit(s, s->tlas_nodes.p, n, 1);
+    RC_HIP(hipMemcpyAsync(s->flat_nodes.p + s->n_flat_nodes, s->tlas_nodes.p, sizeof(RcNode) * s->n_tlas_nodes, hipMemcpyDeviceToDevice, s->stream));
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, s->tlas_nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));
     RC_HIP(hipStreamSynchronize(s->stream));
@@ -461,6 +464,7 @@ void rc_refit_tlas(rc_scene* s) {
     hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p);
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, (const uint32_t*)nullptr, s->d_instances.p, s->d_descs.p, n);
     run_refit(s, s->tlas_nodes.p, n, 1);
+    RC_HIP(hipMemcpyAsync(s->flat_nodes.p + s->n_flat_nodes, s->tlas_nodes.p, sizeof(RcNode) * s->n_tlas_nodes, hipMemcpyDeviceToDevice, s->stream));
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, s->tlas_nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));
     RC_HIP(hipStreamSynchronize(s->stream));

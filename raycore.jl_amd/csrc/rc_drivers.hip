@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_ray_grid(GridParams g, RcRay* out) {
 __global__ __launch_bounds__(kBlock) void k_illumination(SceneView v, GridParams g, uint64_t ray_begin, uint64_t ray_end, float* counts) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    LaneStack st{lds_stack + threadIdx.x, v.overflow + gtid, v.total_threads, v.status};
+    LaneStack st(lds_stack + threadIdx.x, v.overflow + gtid, v.total_threads, v.status);
     for (uint64_t i = ray_begin + gtid; i < ray_end; i += v.total_threads) {
         RayState s;
         trace_ray<false>(s, grid_ray(g, i), v, st);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void k_view_factors(SceneView v, uint32_t k
                                                           uint64_t col_stride, uint32_t row_offset, uint32_t flags) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    LaneStack st{lds_stack + threadIdx.x, v.overflow + gtid, v.total_threads, v.status};
+    LaneStack st(lds_stack + threadIdx.x, v.overflow + gtid, v.total_threads, v.status);
     const uint64_t total = (uint64_t)n_src * n_ray;
     for (uint64_t w = gtid; w < total; w += v.total_threads) {
         uint32_t src = src_begin + (uint32_t)(w / n_ray), ray_idx = ray_begin + (uint32_t)(w % n_ray);

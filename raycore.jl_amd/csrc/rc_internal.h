@@ -62,12 +62,12 @@ struct HandleRange {
 };
 
 struct TraceOptions {
-    int64_t kernel = -1;       // -1 = auto, 0 = one-ray-per-lane, 1 = persistent wave-refill, 2 = persistent + per-wave path scheduling
+    int64_t kernel = -1;       // -1 = auto, 0 = one-ray-per-lane, 1 = persistent wave-refill, 2 = persistent + voted path scheduling, 3 = persistent + phased (while-while)
     int64_t blocks_per_cu = 0; // 0 = derive from the LDS stack depth
     int64_t lds_stack = 24;    // per-lane stack entries kept in LDS: 12, 16, 24 or 32
     int64_t pool = 0;          // persistent kernels: ray indices per atomic claim (0 = auto 64..512)
     int64_t refill = 20;       // persistent kernel: refill when this many lanes of a wave are idle
-    int64_t sched_thr = 16;    // scheduled kernel: lanes that must wait for a leaf/entry batch before it runs
+    int64_t sched_thr = 32;    // kernel 2: lanes that must wait for a leaf/switch batch; kernel 3: interior lanes below which the wave serves the waiting lanes
     int64_t stats = 0;         // dev instrumentation (persistent kernels only)
 };
 

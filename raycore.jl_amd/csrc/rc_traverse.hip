@@ -22,7 +22,7 @@ template <bool ANY, int LDS_N, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_simple(TraceArgs a) {
     __shared__ uint32_t lds_stack[LDS_N * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    LaneStackT<LDS_N> st{lds_stack + threadIdx.x, a.v.overflow + gtid, a.v.total_threads, a.v.status};
+    LaneStackT<LDS_N> st(lds_stack + threadIdx.x, a.v.overflow + gtid, a.v.total_threads, a.v.status);
     for (uint64_t i = gtid; i < a.n_rays; i += a.v.total_threads) {
         RayState s;
         init_ray(s, load_ray(a.rays, i), ANY, st);
@@ -43,7 +43,7 @@ template <bool ANY, int LDS_N, int MINW, bool STATS>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) {
     __shared__ uint32_t lds_stack[LDS_N * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    LaneStackT<LDS_N> st{lds_stack + threadIdx.x, a.v.overflow + gtid, a.v.total_threads, a.v.status};
+    LaneStackT<LDS_N> st(lds_stack + threadIdx.x, a.v.overflow + gtid, a.v.total_threads, a.v.status);
     const int lane = threadIdx.x & 63;
     if (a.v.n_tlas_nodes == 0) {  // empty TLAS: every ray misses (test/test_tlas_stress.jl:808-831)
         RayState miss;
@@ -108,49 +108,29 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
 
 // ---- kernel 2: persistent waves + per-wave path scheduling --------------------------------------------
 // Kernel 1 runs the reference's three-way loop body as written, so a wave executes the interior-node,
-// triangle and instance-entry blocks whenever ANY of its lanes needs them -- measured (round 1, C3): ~100
-// VALU instructions per wave step where a pure interior step needs ~45, i.e. the vector ALU (the actual
-// limiter; the tree is cache resident) spends most of its issue slots on masked-off lanes.
+// triangle, instance-entry and hit-write blocks whenever ANY of its lanes needs them.  Measured on C3
+// (round 1): ~95 % of wave steps run the instance-entry block for 1-3 lanes -- half of all vector-memory
+// instructions and ~45 % of the VALU issue slots go to masked-off lanes, and both the texture path
+// (TA/TD ~75-85 % busy) and the VALU (~85 %) are what bound the kernel (the tree is cache resident).
 //
-// Here every lane carries the KIND of its next visit, known before the fetch because the node numbering
-// encodes it (internal nodes 1..n-1, leaves n..2n-1, src/instanced-bvh.jl:1293-1295): interior (TLAS or
-// BLAS), BLAS leaf (triangle), TLAS leaf (instance entry).  Per iteration the wave ballots the three
-// kinds and runs ONLY the block most lanes are waiting for; the other lanes simply hold their state for
-// a later iteration.  A lane's own sequence of visits, box tests, pushes and pops is unchanged -- only WHEN
-// it happens relative to other lanes moves -- so results stay bit-identical to the reference order.
-// Leaf blocks fetch just what they use (36 B of vertices; the primitive index is idx - n + 1).
-enum : int { K_IDLE = 0, K_INTERIOR = 1, K_LEAF = 2, K_ENTRY = 3 };
-
-struct SchedState {
-    RayState r;
-    uint32_t n_level;  // leaf threshold of the current level: n_instances (TLAS) or the BLAS's n_prims
-    int kind;
-};
-
-__device__ inline int classify(const SchedState& s) {
-    if (s.r.node == RC_INVALID_NODE) return K_IDLE;
-    const bool leaf = s.r.node >= s.n_level;
-    return leaf ? (s.r.cur_inst < 0 ? K_ENTRY : K_LEAF) : K_INTERIOR;
-}
-
-// pop (:1991-2006) incl. the return to the top level
-template <class Stack>
-__device__ inline void pop_next(SchedState& s, Stack& st, uint32_t n_instances) {
-    s.r.node = st.pop(s.r.sp);
-    if (s.r.node == RC_TOP_LEVEL_SENTINEL) {
-        s.r.node = st.pop(s.r.sp);
-        s.r.cur_inst = -1;
-        s.r.o = s.r.wo; s.r.d = s.r.wd; s.r.inv = s.r.winv;
-        s.r.ox = mk3(-s.r.o.x * s.r.inv.x, -s.r.o.y * s.r.inv.y, -s.r.o.z * s.r.inv.z);
-        s.n_level = n_instances;
-    }
-}
+// Here every lane carries the KIND of its next action, known before the fetch because the node numbering
+// encodes it (internal nodes 1..n-1, leaves n..2n-1, src/instanced-bvh.jl:1293-1295):
+//   INTERIOR  box tests of a TLAS/BLAS interior node          LEAF    Moeller-Trumbore on a BLAS leaf
+//   SWITCH    enter an instance (TLAS leaf) or return to the top level (sentinel popped)
+//   DONE      traversal finished, result not yet written      EMPTY   no ray
+// Per iteration the wave ballots the kinds and runs ONE block: a LEAF / SWITCH batch once `sched_thr` lanes
+// wait for it, otherwise the interior block; DONE lanes are written out and refilled together.  Waiting
+// lanes cost no issue slots.  A lane's own sequence of visits, box tests, pushes and pops is exactly the
+// reference's -- only WHEN it happens relative to other lanes moves -- so results stay bit-identical.
+// TLAS and BLAS nodes live in one array (TLAS appended) so a lane needs a single offset, and the interior
+// and leaf blocks never touch the ray registers (only SWITCH does), which keeps them free of copies.
+enum : int { K_EMPTY = 0, K_INTERIOR = 1, K_LEAF = 2, K_SWITCH = 3, K_DONE = 4 };
 
 template <bool ANY, int LDS_N, int MINW, bool STATS>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
     __shared__ uint32_t lds_stack[LDS_N * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    LaneStackT<LDS_N> st{lds_stack + threadIdx.x, a.v.overflow + gtid, a.v.total_threads, a.v.status};
+    LaneStackT<LDS_N> st(lds_stack + threadIdx.x, a.v.overflow + gtid, a.v.total_threads, a.v.status);
     const int lane = threadIdx.x & 63;
     if (a.v.n_tlas_nodes == 0) {
         RayState miss;
@@ -159,25 +139,54 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
         return;
     }
     const uint32_t n_instances = (a.v.n_tlas_nodes + 1u) >> 1;
+    const uint32_t tlas_off = a.v.tlas_off;          // TLAS nodes sit behind the BLAS nodes in a.v.blas_nodes
+    const RcNode* const nodes = a.v.blas_nodes;
     unsigned long long pool_next = 0, pool_end = 0;
     bool exhausted = false;
     uint64_t my_ray = 0;
-    SchedState s;
-    s.r.node = RC_INVALID_NODE;
-    s.kind = K_IDLE;
+    // per-lane ray state (see RayState); kept in scalars so each block touches only what it owns
+    float3_ wo = mk3(0, 0, 0), wd = mk3(0, 0, 0);
+    float3_ o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0), ox = mk3(0, 0, 0);
+    float tmin = 0.f, closest_t = 0.f, cull_t = 0.f, hit_u = 0.f, hit_v = 0.f;
+    uint32_t closest_prim = RC_INVALID_NODE, node = RC_INVALID_NODE, cur_off = 0, n_level = 0;
+    int closest_inst = -1, cur_inst = -1, sp = 0, kind = K_EMPTY;
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0};
+
+    auto classify = [&](uint32_t nd) -> int {
+        if (nd == RC_INVALID_NODE) return K_DONE;
+        if (nd == RC_TOP_LEVEL_SENTINEL) return K_SWITCH;
+        if (nd < n_level) return K_INTERIOR;
+        return cur_inst < 0 ? K_SWITCH : K_LEAF;
+    };
+
     for (;;) {
-        const unsigned long long m_int = __ballot(s.kind == K_INTERIOR), m_leaf = __ballot(s.kind == K_LEAF),
-                                 m_ent = __ballot(s.kind == K_ENTRY);
-        const int n_int = __popcll(m_int), n_leaf = __popcll(m_leaf), n_ent = __popcll(m_ent);
-        int n_idle = 64 - n_int - n_leaf - n_ent;
+        const unsigned long long m_int = __ballot(kind == K_INTERIOR), m_leaf = __ballot(kind == K_LEAF),
+                                 m_sw = __ballot(kind == K_SWITCH), m_done = __ballot(kind == K_DONE);
+        const int n_int = __popcll(m_int), n_leaf = __popcll(m_leaf), n_sw = __popcll(m_sw), n_done = __popcll(m_done);
+        const int n_live = n_int + n_leaf + n_sw;
         const bool can_refill = !(exhausted && pool_next == pool_end);
-        if (n_idle == 64 && !can_refill) break;
-        if (can_refill && n_idle >= a.refill) {
+        if (n_live == 0 && n_done == 0 && !can_refill) break;
+        if ((can_refill && 64 - n_live >= a.refill) || n_live == 0) {
+            // write out finished lanes together, then hand the free lanes new rays
+            if (kind == K_DONE) {
+                uint4 w0, w1;
+                if (closest_inst >= 0) {  // :2010-2017
+                    const uint4 m3 = *(reinterpret_cast<const uint4*>(a.v.inst + closest_inst) + 3);
+                    w0 = make_uint4(1u, __float_as_uint(closest_t), m3.y + closest_prim - 1u, m3.z);
+                    w1 = make_uint4(__float_as_uint(hit_u), __float_as_uint(hit_v), (uint32_t)closest_inst, 0u);
+                } else {  // :2018-2023
+                    w0 = make_uint4(0u, 0u, RC_INVALID_NODE, 0u);
+                    w1 = make_uint4(0u, 0u, RC_INVALID_NODE, 0u);
+                }
+                uint4* out = reinterpret_cast<uint4*>(a.hits + my_ray);
+                out[0] = w0;
+                out[1] = w1;
+                kind = K_EMPTY;
+            }
             for (;;) {
-                unsigned long long idle_mask = __ballot(s.kind == K_IDLE);
-                n_idle = __popcll(idle_mask);
-                if (n_idle == 0) break;
+                const unsigned long long free_mask = __ballot(kind == K_EMPTY);
+                const int n_free = __popcll(free_mask);
+                if (n_free == 0) break;
                 if (pool_next == pool_end) {
                     if (exhausted) break;
                     unsigned long long base = 0;
@@ -191,94 +200,314 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                     if (pool_end >= a.n_rays) { pool_end = a.n_rays; exhausted = true; }
                 }
                 const unsigned long long left = pool_end - pool_next;
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
-                if (s.kind == K_IDLE && rank < left) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)free_mask, 0u));
+                if (kind == K_EMPTY && rank < left) {
                     my_ray = pool_next + rank;
-                    init_ray(s.r, load_ray(a.rays, my_ray), ANY, st);
-                    s.n_level = n_instances;
-                    s.kind = classify(s);
+                    const RcRay r = load_ray(a.rays, my_ray);
+                    // init (:1904-1927); check_direction (src/ray.jl:39-49)
+                    wo = mk3(r.ox, r.oy, r.oz);
+                    wd = mk3(r.dx == 0.0f ? 0.0f : r.dx, r.dy == 0.0f ? 0.0f : r.dy, r.dz == 0.0f ? 0.0f : r.dz);
+                    o = wo; d = wd;
+                    inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
+                    ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                    tmin = ANY ? 0.0f : r.tmin;
+                    closest_t = r.tmax;
+                    cull_t = (r.tmax != r.tmax) ? -INFINITY : r.tmax;
+                    hit_u = hit_v = 0.0f;
+                    closest_prim = RC_INVALID_NODE;
+                    closest_inst = -1; cur_inst = -1;
+                    cur_off = tlas_off; n_level = n_instances;
+                    sp = 0;
+                    st.push(sp, RC_INVALID_NODE);
+                    node = 1;
+                    kind = classify(node);
                 }
-                pool_next += ((unsigned long long)n_idle < left) ? (unsigned long long)n_idle : left;
+                pool_next += ((unsigned long long)n_free < left) ? (unsigned long long)n_free : left;
             }
             continue;
         }
-        // pick a block: a leaf / entry batch runs once `thr` lanes wait for it (or nothing else can run);
-        // otherwise the wave keeps walking interior nodes.  Waiting lanes cost no issue slots.
         int path;
-        if (n_leaf >= a.sched_thr && n_leaf >= n_ent) path = K_LEAF;
-        else if (n_ent >= a.sched_thr) path = K_ENTRY;
+        if (n_leaf >= a.sched_thr && n_leaf >= n_sw) path = K_LEAF;
+        else if (n_sw >= a.sched_thr) path = K_SWITCH;
         else if (n_int > 0) path = K_INTERIOR;
-        else path = (n_leaf >= n_ent) ? K_LEAF : K_ENTRY;
-        if (STATS) { st_iter[path] += 1; st_lane[path] += (s.kind == path) ? 1 : 0; st_lane[0] += (s.kind != K_IDLE) ? 1 : 0; st_iter[0] += 1; }
+        else path = (n_leaf >= n_sw) ? K_LEAF : K_SWITCH;
+        if (STATS) { st_iter[path] += 1; st_lane[path] += (kind == path) ? 1 : 0; st_lane[0] += (kind >= K_INTERIOR && kind <= K_SWITCH) ? 1 : 0; st_iter[0] += 1; }
+
         if (path == K_INTERIOR) {
-            if (s.kind == K_INTERIOR) {
-                const RcNode* np = (s.r.cur_inst < 0) ? (a.v.tlas_nodes + (s.r.node - 1)) : (a.v.blas_nodes + (s.r.blas_off + s.r.node - 1));
-                const float4* q = reinterpret_cast<const float4*>(np);
+            if (kind == K_INTERIOR) {
+                // intersect_internal_node (:1807-1832) + push far / descend near / pop (:1946-1960, 1991-1993)
+                const float4* q = reinterpret_cast<const float4*>(nodes + (cur_off + node - 1));
                 const float4 na = q[0], nb = q[1], nc = q[2];
                 const uint2 ch = *reinterpret_cast<const uint2*>(q + 3);
-                float t0_min, t0_max, t1_min, t1_max;
-                slab(s.r, na.x, na.y, na.z, na.w, nb.x, nb.y, t0_min, t0_max);
-                slab(s.r, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w, t1_min, t1_max);
+                const float f0x = na.w * inv.x + ox.x, f0y = nb.x * inv.y + ox.y, f0z = nb.y * inv.z + ox.z;
+                const float n0x = na.x * inv.x + ox.x, n0y = na.y * inv.y + ox.y, n0z = na.z * inv.z + ox.z;
+                const float f1x = nc.y * inv.x + ox.x, f1y = nc.z * inv.y + ox.y, f1z = nc.w * inv.z + ox.z;
+                const float n1x = nb.z * inv.x + ox.x, n1y = nb.w * inv.y + ox.y, n1z = nc.x * inv.z + ox.z;
+                const float t0_max = fminf(fminf(fminf(fmaxf(f0x, n0x), fmaxf(f0y, n0y)), fmaxf(f0z, n0z)), cull_t);
+                const float t0_min = fmaxf(fmaxf(fmaxf(fminf(f0x, n0x), fminf(f0y, n0y)), fminf(f0z, n0z)), tmin);
+                const float t1_max = fminf(fminf(fminf(fmaxf(f1x, n1x), fmaxf(f1y, n1y)), fmaxf(f1z, n1z)), cull_t);
+                const float t1_min = fmaxf(fmaxf(fmaxf(fminf(f1x, n1x), fminf(f1y, n1y)), fminf(f1z, n1z)), tmin);
                 const uint32_t trav0 = (t0_min <= t0_max) ? ch.x : RC_INVALID_NODE;
                 const uint32_t trav1 = (t1_min <= t1_max) ? ch.y : RC_INVALID_NODE;
                 const bool first0 = (t0_min < t1_min) && (trav0 != RC_INVALID_NODE);
                 const uint32_t near_c = first0 ? trav0 : trav1, far_c = first0 ? trav1 : trav0;
-                if (far_c != RC_INVALID_NODE) st.push(s.r.sp, far_c);
-                if (near_c != RC_INVALID_NODE) s.r.node = near_c;
-                else pop_next(s, st, n_instances);
-                s.kind = classify(s);
-                if (s.kind == K_IDLE) write_hit(s.r, a.v, a.hits, my_ray);
+                if (far_c != RC_INVALID_NODE) st.push(sp, far_c);
+                node = (near_c != RC_INVALID_NODE) ? near_c : st.pop(sp);
+                kind = classify(node);
             }
         } else if (path == K_LEAF) {
-            if (s.kind == K_LEAF) {
-                const RcNode* np = a.v.blas_nodes + (s.r.blas_off + s.r.node - 1);
+            if (kind == K_LEAF) {
+                // intersect_leaf_node -> fast_intersect_triangle (:1756-1797, 1868-1881), then pop
+                const RcNode* np = nodes + (cur_off + node - 1);
                 const float4* q = reinterpret_cast<const float4*>(np);
                 const float4 na = q[0], nb = q[1];
                 const float v2z = np->f[8];
-                float3_ v0 = mk3(na.x, na.y, na.z), v1 = mk3(na.w, nb.x, nb.y), v2 = mk3(nb.z, nb.w, v2z);
-                float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
-                float3_ s1 = cross3(s.r.d, e2);
-                float det = dot3(s1, e1);
-                float invd = 1.0f / det;
-                float3_ dd = sub3(s.r.o, v0);
-                float u = dot3(dd, s1) * invd;
-                float3_ s2 = cross3(dd, e1);
-                float v = dot3(s.r.d, s2) * invd;
-                float t = dot3(e2, s2) * invd;
-                const bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || (u + v) > 1.0f) && !(t < s.r.tmin || t > s.r.closest_t);
-                bool done = false;
+                const float3_ v0 = mk3(na.x, na.y, na.z), v1 = mk3(na.w, nb.x, nb.y), v2 = mk3(nb.z, nb.w, v2z);
+                const float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
+                const float3_ s1 = cross3(d, e2);
+                const float det = dot3(s1, e1);
+                const float invd = 1.0f / det;
+                const float3_ dd = sub3(o, v0);
+                const float u = dot3(dd, s1) * invd;
+                const float3_ s2 = cross3(dd, e1);
+                const float v = dot3(d, s2) * invd;
+                const float t = dot3(e2, s2) * invd;
+                const bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || (u + v) > 1.0f) && !(t < tmin || t > closest_t);
                 if (hit) {
-                    s.r.closest_t = t;
-                    s.r.cull_t = (t != t) ? -INFINITY : t;
-                    s.r.closest_inst = s.r.cur_inst;
-                    s.r.closest_prim = s.r.node - s.n_level + 1u;  // leaf of sorted primitive j sits at n-1+j
-                    s.r.hit_u = u; s.r.hit_v = v;
-                    done = ANY;
+                    closest_t = t;
+                    cull_t = (t != t) ? -INFINITY : t;
+                    closest_inst = cur_inst;
+                    closest_prim = node - n_level + 1u;  // leaf of sorted primitive j sits at n-1+j (child1 = j)
+                    hit_u = u; hit_v = v;
                 }
-                if (done) s.r.node = RC_INVALID_NODE;
-                else pop_next(s, st, n_instances);
-                s.kind = classify(s);
-                if (s.kind == K_IDLE) write_hit(s.r, a.v, a.hits, my_ray);
+                if (ANY && hit) node = RC_INVALID_NODE;  // :2106-2115
+                else node = st.pop(sp);
+                kind = classify(node);
             }
         } else {
-            if (s.kind == K_ENTRY) {
-                s.r.cur_inst = (int)(a.v.tlas_nodes + (s.r.node - 1))->child1;
-                st.push(s.r.sp, RC_TOP_LEVEL_SENTINEL);
-                s.r.node = 1;
-                const float4* q = reinterpret_cast<const float4*>(a.v.inst + s.r.cur_inst);
+            if (kind == K_SWITCH) {
+                if (node == RC_TOP_LEVEL_SENTINEL) {
+                    // back to the top level (:1996-2006)
+                    node = st.pop(sp);
+                    cur_inst = -1;
+                    cur_off = tlas_off; n_level = n_instances;
+                    o = wo; d = wd;
+                    inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
+                    ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                } else {
+                    // top-level leaf: enter the instance (:1961-1977)
+                    cur_inst = (int)(nodes + (cur_off + node - 1))->child1;
+                    st.push(sp, RC_TOP_LEVEL_SENTINEL);
+                    node = 1;
+                    const float4* q = reinterpret_cast<const float4*>(a.v.inst + cur_inst);
+                    const float4 m0 = q[0], m1 = q[1], m2 = q[2];
+                    const uint4 m3 = *reinterpret_cast<const uint4*>(q + 3);
+                    cur_off = m3.x;
+                    n_level = m3.w;
+                    o = mk3(m0.x * wo.x + m0.y * wo.y + m0.z * wo.z + m0.w, m1.x * wo.x + m1.y * wo.y + m1.z * wo.z + m1.w,
+                            m2.x * wo.x + m2.y * wo.y + m2.z * wo.z + m2.w);
+                    d = mk3(m0.x * wd.x + m0.y * wd.y + m0.z * wd.z, m1.x * wd.x + m1.y * wd.y + m1.z * wd.z,
+                            m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
+                    inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
+                    ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                }
+                kind = classify(node);
+            }
+        }
+    }
+    if (STATS) {
+        for (int k = 0; k < 4; ++k) {
+            if (lane == 0) atomicAdd(&a.stats[2 * k], st_iter[k]);
+            atomicAdd(&a.stats[2 * k + 1], st_lane[k]);
+        }
+    }
+}
+
+// ---- kernel 3: persistent waves, phase-structured ("while-while") scheduling --------------------------
+// Same idea as kernel 2 -- run one block at a time for the lanes that need it -- but with a fixed phase order
+// instead of a per-iteration vote: an inner loop walks interior nodes for as long as at least `int_thr`
+// lanes have one pending (always at least once), then ONE pass each over the BLAS-leaf lanes, the level-switch
+// lanes (instance entry / return to top level) and the finished lanes (write-out + refill).  The inner loop
+// only touches {node, sp} so the compiler keeps the ray registers untouched across it.  Per-lane order of
+// visits, tests, pushes and pops is the reference's; only the interleaving between lanes differs.
+template <bool ANY, int LDS_N, int MINW, bool STATS>
+__global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
+    __shared__ uint32_t lds_stack[LDS_N * kBlock];
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    LaneStackT<LDS_N> st(lds_stack + threadIdx.x, a.v.overflow + gtid, a.v.total_threads, a.v.status);
+    const int lane = threadIdx.x & 63;
+    if (a.v.n_tlas_nodes == 0) {
+        RayState miss;
+        miss.closest_inst = -1;
+        for (uint64_t i = gtid; i < a.n_rays; i += a.v.total_threads) write_hit(miss, a.v, a.hits, i);
+        return;
+    }
+    const uint32_t n_instances = (a.v.n_tlas_nodes + 1u) >> 1;
+    const uint32_t tlas_off = a.v.tlas_off;
+    const RcNode* const nodes = a.v.blas_nodes;
+    unsigned long long pool_next = 0, pool_end = 0;
+    bool exhausted = false;
+    uint64_t my_ray = 0;
+    float3_ wo = mk3(0, 0, 0), wd = mk3(0, 0, 0), winv = mk3(0, 0, 0);
+    float3_ o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0), ox = mk3(0, 0, 0);
+    float tmin = 0.f, closest_t = 0.f, cull_t = 0.f, hit_u = 0.f, hit_v = 0.f;
+    uint32_t closest_prim = RC_INVALID_NODE, cur_off = 0, n_level = 0;
+    uint32_t node = RC_INVALID_NODE;  // INVALID + !live = empty lane; INVALID + live = finished, result pending
+    int closest_inst = -1, cur_inst = -1, sp = 0;
+    bool live = false;
+    unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0};
+
+    for (;;) {
+        // ---- interior phase: intersect_internal_node (:1807-1832) + push far / descend near / pop (:1946-1960, 1991-1993)
+        for (;;) {
+            const bool is_int = node < n_level;  // sentinels and INVALID are >= 0xFFFFFFFE, never below a leaf threshold
+            const int n_int = __popcll(__ballot(is_int));
+            if (n_int == 0) break;
+            if (STATS) { st_iter[1] += 1; st_lane[1] += is_int ? 1 : 0; }
+            if (is_int) {
+                const float4* q = reinterpret_cast<const float4*>(nodes + (cur_off + node - 1));
+                const float4 na = q[0], nb = q[1], nc = q[2];
+                const uint2 ch = *reinterpret_cast<const uint2*>(q + 3);
+                const float f0x = na.w * inv.x + ox.x, f0y = nb.x * inv.y + ox.y, f0z = nb.y * inv.z + ox.z;
+                const float n0x = na.x * inv.x + ox.x, n0y = na.y * inv.y + ox.y, n0z = na.z * inv.z + ox.z;
+                const float f1x = nc.y * inv.x + ox.x, f1y = nc.z * inv.y + ox.y, f1z = nc.w * inv.z + ox.z;
+                const float n1x = nb.z * inv.x + ox.x, n1y = nb.w * inv.y + ox.y, n1z = nc.x * inv.z + ox.z;
+                const float t0_max = fminf(fminf(fminf(fmaxf(f0x, n0x), fmaxf(f0y, n0y)), fmaxf(f0z, n0z)), cull_t);
+                const float t0_min = fmaxf(fmaxf(fmaxf(fminf(f0x, n0x), fminf(f0y, n0y)), fminf(f0z, n0z)), tmin);
+                const float t1_max = fminf(fminf(fminf(fmaxf(f1x, n1x), fmaxf(f1y, n1y)), fmaxf(f1z, n1z)), cull_t);
+                const float t1_min = fmaxf(fmaxf(fmaxf(fminf(f1x, n1x), fminf(f1y, n1y)), fminf(f1z, n1z)), tmin);
+                const uint32_t trav0 = (t0_min <= t0_max) ? ch.x : RC_INVALID_NODE;
+                const uint32_t trav1 = (t1_min <= t1_max) ? ch.y : RC_INVALID_NODE;
+                const bool first0 = (t0_min < t1_min) && (trav0 != RC_INVALID_NODE);
+                const uint32_t near_c = first0 ? trav0 : trav1, far_c = first0 ? trav1 : trav0;
+                if (far_c != RC_INVALID_NODE) st.push(sp, far_c);
+                node = (near_c != RC_INVALID_NODE) ? near_c : st.pop(sp);
+            }
+            if (n_int < a.sched_thr) break;  // too few interior lanes left: serve the waiting ones first
+        }
+        // ---- leaf phase: fast_intersect_triangle (:1756-1797) on BLAS leaves, then pop
+        {
+            const bool is_leaf = cur_inst >= 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
+            if (STATS && __ballot(is_leaf)) { st_iter[2] += 1; st_lane[2] += is_leaf ? 1 : 0; }
+            if (is_leaf) {
+                const RcNode* np = nodes + (cur_off + node - 1);
+                const float4* q = reinterpret_cast<const float4*>(np);
+                const float4 na = q[0], nb = q[1];
+                const float v2z = np->f[8];
+                const float3_ v0 = mk3(na.x, na.y, na.z), v1 = mk3(na.w, nb.x, nb.y), v2 = mk3(nb.z, nb.w, v2z);
+                const float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
+                const float3_ s1 = cross3(d, e2);
+                const float det = dot3(s1, e1);
+                const float invd = 1.0f / det;
+                const float3_ dd = sub3(o, v0);
+                const float u = dot3(dd, s1) * invd;
+                const float3_ s2 = cross3(dd, e1);
+                const float v = dot3(d, s2) * invd;
+                const float t = dot3(e2, s2) * invd;
+                const bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || (u + v) > 1.0f) && !(t < tmin || t > closest_t);
+                closest_prim = hit ? node - n_level + 1u : closest_prim;  // leaf of sorted primitive j sits at n-1+j
+                closest_inst = hit ? cur_inst : closest_inst;
+                closest_t = hit ? t : closest_t;
+                cull_t = hit ? ((t != t) ? -INFINITY : t) : cull_t;
+                hit_u = hit ? u : hit_u;
+                hit_v = hit ? v : hit_v;
+                if (ANY && hit) node = RC_INVALID_NODE;  // :2106-2115
+                else node = st.pop(sp);
+            }
+        }
+        // ---- switch phase: return to the top level (:1996-2006) or enter an instance (:1961-1977)
+        {
+            const bool is_exit = node == RC_TOP_LEVEL_SENTINEL;
+            const bool is_entry = cur_inst < 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
+            if (STATS && __ballot(is_exit || is_entry)) { st_iter[3] += 1; st_lane[3] += (is_exit || is_entry) ? 1 : 0; }
+            if (is_exit) {
+                node = st.pop(sp);
+                cur_inst = -1;
+                cur_off = tlas_off; n_level = n_instances;
+                o = wo; d = wd; inv = winv;
+                ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+            } else if (is_entry) {
+                cur_inst = (int)(nodes + (cur_off + node - 1))->child1;
+                st.push(sp, RC_TOP_LEVEL_SENTINEL);
+                node = 1;
+                const float4* q = reinterpret_cast<const float4*>(a.v.inst + cur_inst);
                 const float4 m0 = q[0], m1 = q[1], m2 = q[2];
                 const uint4 m3 = *reinterpret_cast<const uint4*>(q + 3);
-                s.r.blas_off = m3.x;
-                s.n_level = m3.w;
-                const float3_ wo = s.r.wo, wd = s.r.wd;
-                s.r.o = mk3(m0.x * wo.x + m0.y * wo.y + m0.z * wo.z + m0.w, m1.x * wo.x + m1.y * wo.y + m1.z * wo.z + m1.w,
-                            m2.x * wo.x + m2.y * wo.y + m2.z * wo.z + m2.w);
-                s.r.d = mk3(m0.x * wd.x + m0.y * wd.y + m0.z * wd.z, m1.x * wd.x + m1.y * wd.y + m1.z * wd.z,
-                            m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
-                s.r.inv = mk3(safe_inv1(s.r.d.x), safe_inv1(s.r.d.y), safe_inv1(s.r.d.z));
-                s.r.ox = mk3(-s.r.o.x * s.r.inv.x, -s.r.o.y * s.r.inv.y, -s.r.o.z * s.r.inv.z);
-                s.kind = classify(s);
+                cur_off = m3.x;
+                n_level = m3.w;
+                o = mk3(m0.x * wo.x + m0.y * wo.y + m0.z * wo.z + m0.w, m1.x * wo.x + m1.y * wo.y + m1.z * wo.z + m1.w,
+                        m2.x * wo.x + m2.y * wo.y + m2.z * wo.z + m2.w);
+                d = mk3(m0.x * wd.x + m0.y * wd.y + m0.z * wd.z, m1.x * wd.x + m1.y * wd.y + m1.z * wd.z,
+                        m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
+                inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
+                ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+            }
+        }
+        // ---- finished lanes: write out; refill when enough lanes are free
+        {
+            const bool fin = live && node == RC_INVALID_NODE;
+            const int n_free = __popcll(__ballot(fin || !live));
+            const bool can_refill = !(exhausted && pool_next == pool_end);
+            if (n_free == 64 && !can_refill && !__ballot(fin)) break;
+            if (n_free >= a.refill || n_free == 64 || !can_refill) {
+                if (fin) {
+                    uint4 w0, w1;
+                    if (closest_inst >= 0) {  // :2010-2017
+                        const uint4 m3 = *(reinterpret_cast<const uint4*>(a.v.inst + closest_inst) + 3);
+                        w0 = make_uint4(1u, __float_as_uint(closest_t), m3.y + closest_prim - 1u, m3.z);
+                        w1 = make_uint4(__float_as_uint(hit_u), __float_as_uint(hit_v), (uint32_t)closest_inst, 0u);
+                    } else {  // :2018-2023
+                        w0 = make_uint4(0u, 0u, RC_INVALID_NODE, 0u);
+                        w1 = make_uint4(0u, 0u, RC_INVALID_NODE, 0u);
+                    }
+                    uint4* out = reinterpret_cast<uint4*>(a.hits + my_ray);
+                    out[0] = w0;
+                    out[1] = w1;
+                    live = false;
+                }
+                if (STATS) { st_iter[0] += 1; }
+                while (can_refill) {
+                    const unsigned long long free_mask = __ballot(!live);
+                    const int nf = __popcll(free_mask);
+                    if (nf == 0) break;
+                    if (pool_next == pool_end) {
+                        if (exhausted) break;
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)a.pool);
+                        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+                        unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+                        base = ((unsigned long long)hi << 32) | lo;
+                        if (base >= a.n_rays) { exhausted = true; break; }
+                        pool_next = base;
+                        pool_end = base + a.pool;
+                        if (pool_end >= a.n_rays) { pool_end = a.n_rays; exhausted = true; }
+                    }
+                    const unsigned long long left = pool_end - pool_next;
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)free_mask, 0u));
+                    if (!live && rank < left) {
+                        my_ray = pool_next + rank;
+                        const RcRay r = load_ray(a.rays, my_ray);
+                        wo = mk3(r.ox, r.oy, r.oz);  // init (:1904-1927); check_direction (src/ray.jl:39-49)
+                        wd = mk3(r.dx == 0.0f ? 0.0f : r.dx, r.dy == 0.0f ? 0.0f : r.dy, r.dz == 0.0f ? 0.0f : r.dz);
+                        winv = mk3(safe_inv1(wd.x), safe_inv1(wd.y), safe_inv1(wd.z));
+                        o = wo; d = wd; inv = winv;
+                        ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                        tmin = ANY ? 0.0f : r.tmin;
+                        closest_t = r.tmax;
+                        cull_t = (r.tmax != r.tmax) ? -INFINITY : r.tmax;
+                        hit_u = hit_v = 0.0f;
+                        closest_prim = RC_INVALID_NODE;
+                        closest_inst = -1; cur_inst = -1;
+                        cur_off = tlas_off; n_level = n_instances;
+                        sp = 0;
+                        st.push(sp, RC_INVALID_NODE);
+                        node = 1;
+                        live = true;
+                    }
+                    pool_next += ((unsigned long long)nf < left) ? (unsigned long long)nf : left;
+                }
             }
         }
     }
@@ -303,7 +532,7 @@ void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     rc::SceneView v;
     v.tlas_nodes = s->tlas_nodes.p; v.blas_nodes = s->flat_nodes.p; v.inst = s->inst_recs.p; v.prims = s->flat_prims.p;
-    v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims;
+    v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims; v.tlas_off = s->n_flat_nodes;
     v.overflow = s->overflow_stack.p; v.total_threads = total_threads;
     v.status = s->counters.p + 4;
     return v;
@@ -321,7 +550,10 @@ static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hip
     const bool stats = s->opt.stats != 0;
 #define RC_LAUNCH_P(L, W) hipLaunchKernelGGL((k_trace_persistent<ANY, L, W, false>), dim3(blocks), dim3(kBlock), 0, stream, a)
 #define RC_LAUNCH_S(L, W) hipLaunchKernelGGL((k_trace_simple<ANY, L, W>), dim3(blocks), dim3(kBlock), 0, stream, a)
-    if (s->opt.kernel == 2) {
+    if (s->opt.kernel == 3) {
+        if (stats) hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
+    } else if (s->opt.kernel == 2) {
         if (stats) hipLaunchKernelGGL((k_trace_sched<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else if (lds == 16) hipLaunchKernelGGL((k_trace_sched<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else hipLaunchKernelGGL((k_trace_sched<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
@@ -361,7 +593,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.stats = reinterpret_cast<unsigned long long*>(s->counters.p + 8);
     RC_HIP(hipEventRecord(s->ev0, stream));
     const int64_t saved_kernel = s->opt.kernel;
-    if (saved_kernel < 0) s->opt.kernel = (n < (uint64_t)total_threads * 4) ? 0 : 1;  // auto: tiny batches gain nothing from refilling
+    if (saved_kernel < 0) s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : 3;  // auto: tiny batches gain nothing from refilling
     if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
     s->opt.kernel = saved_kernel;
     RC_HIP(hipEventRecord(s->ev1, stream));

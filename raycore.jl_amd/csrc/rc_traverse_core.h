@@ -19,6 +19,7 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
     const RcPrim* prims;
     uint32_t n_tlas_nodes;
     uint32_t n_prims;
+    uint32_t tlas_off;        // a copy of the TLAS nodes sits at blas_nodes[tlas_off ...] (single-base addressing)
     uint32_t* overflow;       // [kTotalStack][total_threads] spill area of the lane stacks (entries below the LDS depth unused)
     uint32_t total_threads;
     uint32_t* status;         // [0] = stack overflow flag
@@ -36,21 +37,30 @@ struct TraceArgs {
     unsigned long long* stats;         // optional instrumentation (dev builds), else nullptr
 };
 
+// Address-space-qualified pointers keep the two halves of the stack on their own instruction paths
+// (ds_read/ds_write_b32 for LDS, global_load/store for the spill area); with generic pointers the compiler
+// if-converts push/pop into a pointer select + flat_load, which sends every pop through the texture path.
+typedef uint32_t __attribute__((address_space(3))) lds_u32;
+typedef uint32_t __attribute__((address_space(1))) glb_u32;
+
 template <int LDS_N>
 struct LaneStackT {
-    uint32_t* lds;       // &lds_stack[threadIdx.x]
-    uint32_t* ovf;       // &overflow[global thread id]
+    lds_u32* lds;        // &lds_stack[threadIdx.x]
+    glb_u32* ovf;        // &overflow[global thread id]
     uint32_t ovf_stride;
     uint32_t* status;
+    __device__ inline LaneStackT(uint32_t* lds_base, uint32_t* ovf_base, uint32_t stride, uint32_t* st)
+        : lds((lds_u32*)lds_base), ovf((glb_u32*)ovf_base), ovf_stride(stride), status(st) {}
     __device__ inline void push(int& sp, uint32_t v) {
-        if (sp < LDS_N) lds[sp * kBlock] = v;
+        if (__builtin_expect(sp < LDS_N, 1)) lds[sp * kBlock] = v;
         else if (sp < kTotalStack) ovf[(size_t)(sp - LDS_N) * ovf_stride] = v;
         else { *status = 1u; return; }
         ++sp;
     }
     __device__ inline uint32_t pop(int& sp) {
         --sp;
-        return sp < LDS_N ? lds[sp * kBlock] : ovf[(size_t)(sp - LDS_N) * ovf_stride];
+        if (__builtin_expect(sp < LDS_N, 1)) return lds[sp * kBlock];
+        return ovf[(size_t)(sp - LDS_N) * ovf_stride];
     }
 };
 using LaneStack = LaneStackT<kLdsStack>;

@@ -144,7 +144,7 @@ def test_build_parity_100k(rc, oracle):
 
 
 # ---- traversal parity -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_trace_parity_c1(rc, oracle, kernel):
     cfg = rc.scenes.config_c1()
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
@@ -156,7 +156,7 @@ def test_trace_parity_c1(rc, oracle, kernel):
     assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any"), "C1 any")
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_trace_parity_random_scene(rc, oracle, kernel):
     sc = rc.scenes
     xf, _, _ = sc.lattice_transforms(3, 3, 2, 1.2, 77)
@@ -174,7 +174,7 @@ def test_trace_parity_random_scene(rc, oracle, kernel):
     assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any", nthreads=8), "random any")
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_trace_parity_c3_and_shadow(rc, oracle, kernel):
     cfg = rc.scenes.config_c3()
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
@@ -207,7 +207,7 @@ def test_trace_edge_cases(rc, oracle):
             os_.append([x, 0.5, 0.0]); ds.append([1.0, 0.0, 0.0])      # in the plane of the quad
     rays = rc.scenes.make_rays(os_, ds)
     want = o.trace(rays)
-    for k in (0, 1, 2):
+    for k in (0, 1, 2, 3):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(rays), want, f"edge closest k{k}")
         assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any"), f"edge any k{k}")
@@ -231,7 +231,7 @@ def test_full_size_c2_properties(rc, oracle):
     perm = rc.scenes.rng(5).permutation(len(rays))
     assert_hits_equal(t.trace(rays[perm]), got[perm], "C2 permuted")
     # every kernel variant agrees
-    for k in (0, 1, 2):
+    for k in (0, 1, 2, 3):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(rays), got, f"C2 kernel {k}")
         assert np.array_equal(t.trace(rays, mode="any")["hit"], got["hit"])

@@ -59,7 +59,7 @@ def main():
     bounce = sc.c4_bounce_rays(cfg3, rays3, hits3, 4 * len(rays3))
     wl = {"c2": ("C2 closest", t2, rays2, "closest"), "c3": ("C3 primary", t3, rays3, "closest"),
           "shadow": ("C3 shadow-any", t3, shadow, "any"), "c4": ("C4 bounce", t3, bounce, "closest")}
-    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 16, "pool": 0}
+    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 32, "pool": 0}
     for var in args.variants.split(";"):
         opts = dict(defaults)
         for kv in var.split(","):
@@ -73,13 +73,15 @@ def main():
             name, t, rays, mode = wl[w]
             ms, hits = time_trace(t, rays, mode)
             extra = ""
-            if args.stats and opts["kernel"] in (1, 2):
+            if args.stats and opts["kernel"] in (1, 2, 3):
                 t.set_option("stats", 1)
                 time_trace(t, rays, mode, 1)
                 v = [t.get_option(f"stat{i}") for i in range(8)]
                 t.set_option("stats", 0)
                 if opts["kernel"] == 1:
                     extra = f" wave_steps={v[0]} lanes/step={v[1]/max(v[0],1):.1f} max_sp={v[2]}"
+                elif opts["kernel"] == 3:
+                    extra = f" | I {v[2]} x{v[3]/max(v[2],1):.1f} | L {v[4]} x{v[5]/max(v[4],1):.1f} | S {v[6]} x{v[7]/max(v[6],1):.1f} | refills {v[0]}"
                 else:
                     extra = (f" iters={v[0]} live/iter={v[1]/max(v[0],1):.1f} | I {v[2]} x{v[3]/max(v[2],1):.1f} | L {v[4]} x{v[5]/max(v[4],1):.1f}"
                              f" | E {v[6]} x{v[7]/max(v[6],1):.1f}")
