@@ -300,6 +300,12 @@ __global__ void k_tlas_leaves(RcNode* nodes, const uint32_t* sorted, const RcIns
     nd->child1 = orig;
 }
 
+// Traversal copy of a node array in the packed order of rc_pack_node.
+__global__ void k_pack_nodes(const RcNode* src, RcNode* dst, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = rc_pack_node(src[i]);
+}
+
 // Traversal-side instance records: inverse transform + the BLAS offsets it would otherwise chase.
 __global__ void k_inst_recs(const RcInstanceDesc* inst, const RcBlasDesc* descs, const uint32_t* blas_nprims, uint32_t n, RcInstRec* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -418,7 +424,7 @@ void rc_build_tlas(rc_scene* s) {
     s->flat_prims.reserve(tp ? tp : 1);
     s->d_descs.reserve(nb ? nb : 1);
     for (uint32_t i = 0; i < nb; ++i) {
-        RC_HIP(hipMemcpyAsync(s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].nodes.p, sizeof(RcNode) * s->blas[i].n_nodes, hipMemcpyDeviceToDevice, s->stream));
+        hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes);
         RC_HIP(hipMemcpyAsync(s->flat_prims.p + s->descs[i].primitives_offset, s->blas[i].prims.p, sizeof(RcPrim) * s->blas[i].n_prims, hipMemcpyDeviceToDevice, s->stream));
     }
     if (nb) RC_HIP(hipMemcpyAsync(s->d_descs.p, s->descs.data(), sizeof(RcBlasDesc) * nb, hipMemcpyHostToDevice, s->stream));
@@ -447,7 +453,7 @@ void rc_build_tlas(rc_scene* s) {
     // n == 1 (:1553-1570): the single leaf holds the scene AABB == the instance's world AABB (same min/max set)
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->vals_b.p, s->d_instances.p, s->d_descs.p, n);
     run_refit(s, s->tlas_nodes.p, n, 1);
-    RC_HIP(hipMemcpyAsync(s->flat_nodes.p + s->n_flat_nodes, s->tlas_nodes.p, sizeof(RcNode) * s->n_tlas_nodes, hipMemcpyDeviceToDevice, s->stream));
+    hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes);
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, s->tlas_nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));
     RC_HIP(hipStreamSynchronize(s->stream));
@@ -464,7 +470,7 @@ void rc_refit_tlas(rc_scene* s) {
     hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p);
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, (const uint32_t*)nullptr, s->d_instances.p, s->d_descs.p, n);
     run_refit(s, s->tlas_nodes.p, n, 1);
-    RC_HIP(hipMemcpyAsync(s->flat_nodes.p + s->n_flat_nodes, s->tlas_nodes.p, sizeof(RcNode) * s->n_tlas_nodes, hipMemcpyDeviceToDevice, s->stream));
+    hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes);
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, s->tlas_nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));
     RC_HIP(hipStreamSynchronize(s->stream));

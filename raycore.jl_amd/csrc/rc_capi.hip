@@ -336,7 +336,15 @@ int rc_export_tlas_nodes(rc_scene* s, rc_bvh_node* out, uint32_t capacity, uint3
 }
 int rc_export_blas_nodes(rc_scene* s, rc_bvh_node* out, uint32_t capacity, uint32_t* count) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
-    return guarded([&] { use_device(s); require_synced(s); export_nodes(s, s->flat_nodes.p, s->n_flat_nodes, out, capacity, count); });
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        if (count) *count = s->n_flat_nodes;
+        if (!out || s->n_flat_nodes == 0) return;
+        if (capacity < s->n_flat_nodes) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
+        for (size_t i = 0; i < s->blas.size(); ++i)  // the flat device array is the packed traversal copy; the reference layout lives per BLAS
+            export_nodes(s, s->blas[i].nodes.p, s->blas[i].n_nodes, out + s->descs[i].nodes_offset, s->blas[i].n_nodes, nullptr);
+    });
 }
 int rc_export_instances(rc_scene* s, rc_instance_desc* out, uint32_t capacity, uint32_t* count) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");

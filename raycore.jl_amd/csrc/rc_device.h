@@ -19,6 +19,24 @@ struct __attribute__((aligned(64))) RcNode {
 };
 static_assert(sizeof(RcNode) == 64, "RcNode must be 64 bytes");
 
+// Traversal copy of a node: the same 12 floats, permuted so that the box test runs on packed-f32 pairs that
+// are already adjacent (and 8-byte aligned) in the fetched registers:
+//   dword 0..3  = aabb0_min.x, aabb0_min.y, aabb0_max.x, aabb0_max.y     (x,y of child 0)
+//   dword 4..7  = aabb1_min.x, aabb1_min.y, aabb1_max.x, aabb1_max.y     (x,y of child 1)
+//   dword 8..11 = aabb0_min.z, aabb0_max.z, aabb1_min.z, aabb1_max.z     (z of both children)
+// so six v_pk_mul_f32 + six v_pk_add_f32 against (inv.x,inv.y)/(ox.x,ox.y) and a broadcast inv.z/ox.z replace
+// twelve multiplies and twelve adds; each product/sum is the same IEEE operation as before (no fusion).
+// A BLAS leaf (v0,v1,v2 in the canonical f[0..8]) therefore reads v0=(p0,p1,p8) v1=(p2,p3,p9) v2=(p4,p5,p10).
+// The canonical (reference-layout) arrays are kept next to it for rc_export_* and the build kernels.
+__host__ __device__ inline RcNode rc_pack_node(const RcNode& n) {
+    RcNode p;
+    p.f[0] = n.f[0]; p.f[1] = n.f[1]; p.f[2] = n.f[3]; p.f[3] = n.f[4];
+    p.f[4] = n.f[6]; p.f[5] = n.f[7]; p.f[6] = n.f[9]; p.f[7] = n.f[10];
+    p.f[8] = n.f[2]; p.f[9] = n.f[5]; p.f[10] = n.f[8]; p.f[11] = n.f[11];
+    p.child0 = n.child0; p.child1 = n.child1; p.parent = n.parent; p.pad = 0;
+    return p;
+}
+
 // What the traversal needs of an InstanceDescriptor (src/instanced-bvh.jl:90-96) + its BLASDescriptor
 // (:132-136), folded into one 64-byte record: one aligned fetch per TLAS-leaf entry instead of the
 // reference's 108-byte + 32-byte pair.

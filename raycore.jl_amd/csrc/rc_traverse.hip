@@ -17,6 +17,8 @@ namespace {
 
 using namespace rc;
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // ---- kernel 0: one ray per lane, grid-stride --------------------------------------------------------
 template <bool ANY, int LDS_N, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_simple(TraceArgs a) {
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_simple(TraceArgs a) {
     LaneStackT<LDS_N> st(lds_stack + threadIdx.x, a.v.overflow + gtid, a.v.total_threads, a.v.status);
     for (uint64_t i = gtid; i < a.n_rays; i += a.v.total_threads) {
         RayState s;
-        init_ray(s, load_ray(a.rays, i), ANY, st);
+        init_ray(s, load_ray(a.rays, i), ANY, st, a.v.tlas_off);
         if (a.v.n_tlas_nodes != 0)
             while (step<ANY>(s, a.v, st)) {}
         write_hit(s, a.v, a.hits, i);
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
                 if (!active && rank < left) {
                     my_ray = pool_next + rank;
-                    init_ray(s, load_ray(a.rays, my_ray), ANY, st);
+                    init_ray(s, load_ray(a.rays, my_ray), ANY, st, a.v.tlas_off);
                     active = true;
                 }
                 pool_next += ((unsigned long long)n_idle < left) ? (unsigned long long)n_idle : left;
@@ -240,10 +242,13 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                 const float4* q = reinterpret_cast<const float4*>(nodes + (cur_off + node - 1));
                 const float4 na = q[0], nb = q[1], nc = q[2];
                 const uint2 ch = *reinterpret_cast<const uint2*>(q + 3);
-                const float f0x = na.w * inv.x + ox.x, f0y = nb.x * inv.y + ox.y, f0z = nb.y * inv.z + ox.z;
-                const float n0x = na.x * inv.x + ox.x, n0y = na.y * inv.y + ox.y, n0z = na.z * inv.z + ox.z;
-                const float f1x = nc.y * inv.x + ox.x, f1y = nc.z * inv.y + ox.y, f1z = nc.w * inv.z + ox.z;
-                const float n1x = nb.z * inv.x + ox.x, n1y = nb.w * inv.y + ox.y, n1z = nc.x * inv.z + ox.z;
+                // packed node (rc_pack_node): na = child-0 (min.x,min.y,max.x,max.y), nb = child-1 likewise, nc = z of both
+                const v2f ixy = {inv.x, inv.y}, oxy = {ox.x, ox.y}, izz = {inv.z, inv.z}, ozz = {ox.z, ox.z};
+                const v2f n0xy = v2f{na.x, na.y} * ixy + oxy, f0xy = v2f{na.z, na.w} * ixy + oxy;
+                const v2f n1xy = v2f{nb.x, nb.y} * ixy + oxy, f1xy = v2f{nb.z, nb.w} * ixy + oxy;
+                const v2f nf0z = v2f{nc.x, nc.y} * izz + ozz, nf1z = v2f{nc.z, nc.w} * izz + ozz;
+                const float f0x = f0xy.x, f0y = f0xy.y, f0z = nf0z.y, n0x = n0xy.x, n0y = n0xy.y, n0z = nf0z.x;
+                const float f1x = f1xy.x, f1y = f1xy.y, f1z = nf1z.y, n1x = n1xy.x, n1y = n1xy.y, n1z = nf1z.x;
                 const float t0_max = fminf(fminf(fminf(fmaxf(f0x, n0x), fmaxf(f0y, n0y)), fmaxf(f0z, n0z)), cull_t);
                 const float t0_min = fmaxf(fmaxf(fmaxf(fminf(f0x, n0x), fminf(f0y, n0y)), fminf(f0z, n0z)), tmin);
                 const float t1_max = fminf(fminf(fminf(fmaxf(f1x, n1x), fmaxf(f1y, n1y)), fmaxf(f1z, n1z)), cull_t);
@@ -261,9 +266,10 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                 // intersect_leaf_node -> fast_intersect_triangle (:1756-1797, 1868-1881), then pop
                 const RcNode* np = nodes + (cur_off + node - 1);
                 const float4* q = reinterpret_cast<const float4*>(np);
-                const float4 na = q[0], nb = q[1];
-                const float v2z = np->f[8];
-                const float3_ v0 = mk3(na.x, na.y, na.z), v1 = mk3(na.w, nb.x, nb.y), v2 = mk3(nb.z, nb.w, v2z);
+                const float4 na = q[0];
+                const float2 nb = *reinterpret_cast<const float2*>(q + 1);
+                const float4 nc = q[2];
+                const float3_ v0 = mk3(na.x, na.y, nc.x), v1 = mk3(na.z, na.w, nc.y), v2 = mk3(nb.x, nb.y, nc.z);  // packed order
                 const float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
                 const float3_ s1 = cross3(d, e2);
                 const float det = dot3(s1, e1);
@@ -369,10 +375,13 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
                 const float4* q = reinterpret_cast<const float4*>(nodes + (cur_off + node - 1));
                 const float4 na = q[0], nb = q[1], nc = q[2];
                 const uint2 ch = *reinterpret_cast<const uint2*>(q + 3);
-                const float f0x = na.w * inv.x + ox.x, f0y = nb.x * inv.y + ox.y, f0z = nb.y * inv.z + ox.z;
-                const float n0x = na.x * inv.x + ox.x, n0y = na.y * inv.y + ox.y, n0z = na.z * inv.z + ox.z;
-                const float f1x = nc.y * inv.x + ox.x, f1y = nc.z * inv.y + ox.y, f1z = nc.w * inv.z + ox.z;
-                const float n1x = nb.z * inv.x + ox.x, n1y = nb.w * inv.y + ox.y, n1z = nc.x * inv.z + ox.z;
+                // packed node (rc_pack_node): na = child-0 (min.x,min.y,max.x,max.y), nb = child-1 likewise, nc = z of both
+                const v2f ixy = {inv.x, inv.y}, oxy = {ox.x, ox.y}, izz = {inv.z, inv.z}, ozz = {ox.z, ox.z};
+                const v2f n0xy = v2f{na.x, na.y} * ixy + oxy, f0xy = v2f{na.z, na.w} * ixy + oxy;
+                const v2f n1xy = v2f{nb.x, nb.y} * ixy + oxy, f1xy = v2f{nb.z, nb.w} * ixy + oxy;
+                const v2f nf0z = v2f{nc.x, nc.y} * izz + ozz, nf1z = v2f{nc.z, nc.w} * izz + ozz;
+                const float f0x = f0xy.x, f0y = f0xy.y, f0z = nf0z.y, n0x = n0xy.x, n0y = n0xy.y, n0z = nf0z.x;
+                const float f1x = f1xy.x, f1y = f1xy.y, f1z = nf1z.y, n1x = n1xy.x, n1y = n1xy.y, n1z = nf1z.x;
                 const float t0_max = fminf(fminf(fminf(fmaxf(f0x, n0x), fmaxf(f0y, n0y)), fmaxf(f0z, n0z)), cull_t);
                 const float t0_min = fmaxf(fmaxf(fmaxf(fminf(f0x, n0x), fminf(f0y, n0y)), fminf(f0z, n0z)), tmin);
                 const float t1_max = fminf(fminf(fminf(fmaxf(f1x, n1x), fmaxf(f1y, n1y)), fmaxf(f1z, n1z)), cull_t);
@@ -393,9 +402,10 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
             if (is_leaf) {
                 const RcNode* np = nodes + (cur_off + node - 1);
                 const float4* q = reinterpret_cast<const float4*>(np);
-                const float4 na = q[0], nb = q[1];
-                const float v2z = np->f[8];
-                const float3_ v0 = mk3(na.x, na.y, na.z), v1 = mk3(na.w, nb.x, nb.y), v2 = mk3(nb.z, nb.w, v2z);
+                const float4 na = q[0];
+                const float2 nb = *reinterpret_cast<const float2*>(q + 1);
+                const float4 nc = q[2];
+                const float3_ v0 = mk3(na.x, na.y, nc.x), v1 = mk3(na.z, na.w, nc.y), v2 = mk3(nb.x, nb.y, nc.z);  // packed order
                 const float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
                 const float3_ s1 = cross3(d, e2);
                 const float det = dot3(s1, e1);

@@ -92,7 +92,7 @@ struct RayState {
 };
 
 template <class Stack>
-__device__ inline void init_ray(RayState& s, const RcRay& r, bool any_hit, Stack& st) {
+__device__ inline void init_ray(RayState& s, const RcRay& r, bool any_hit, Stack& st, uint32_t tlas_off) {
     // check_direction (src/ray.jl:39-49): -0 and +0 both become +0
     s.wo = mk3(r.ox, r.oy, r.oz);
     s.wd = mk3(r.dx == 0.0f ? 0.0f : r.dx, r.dy == 0.0f ? 0.0f : r.dy, r.dz == 0.0f ? 0.0f : r.dz);
@@ -105,7 +105,7 @@ __device__ inline void init_ray(RayState& s, const RcRay& r, bool any_hit, Stack
     s.hit_u = s.hit_v = 0.0f;
     s.closest_prim = RC_INVALID_NODE;
     s.closest_inst = -1; s.cur_inst = -1;
-    s.node = 1; s.blas_off = 0;
+    s.node = 1; s.blas_off = tlas_off;
     s.sp = 0;
     st.push(s.sp, RC_INVALID_NODE);
 }
@@ -124,13 +124,13 @@ __device__ inline void slab(const RayState& s, float mnx, float mny, float mnz, 
 // One iteration of the reference's while loop (:1936-2007).  Returns false when the ray has terminated.
 template <bool ANY, class Stack>
 __device__ inline bool step(RayState& s, const SceneView& a, Stack& st) {
-    const RcNode* np = (s.cur_inst < 0) ? (a.tlas_nodes + (s.node - 1)) : (a.blas_nodes + (s.blas_off + s.node - 1));
+    const RcNode* np = a.blas_nodes + (s.blas_off + s.node - 1);  // packed traversal copy; TLAS nodes sit at blas_off = tlas_off
     NodeRegs nd = load_node(np);
     if (nd.d.x != RC_INVALID_NODE) {
         // intersect_internal_node (:1807-1832)
         float t0_min, t0_max, t1_min, t1_max;
-        slab(s, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y, t0_min, t0_max);
-        slab(s, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w, t1_min, t1_max);
+        slab(s, nd.a.x, nd.a.y, nd.c.x, nd.a.z, nd.a.w, nd.c.y, t0_min, t0_max);  // packed order, see rc_pack_node
+        slab(s, nd.b.x, nd.b.y, nd.c.z, nd.b.z, nd.b.w, nd.c.w, t1_min, t1_max);
         uint32_t trav0 = (t0_min <= t0_max) ? nd.d.x : RC_INVALID_NODE;
         uint32_t trav1 = (t1_min <= t1_max) ? nd.d.y : RC_INVALID_NODE;
         bool first0 = (t0_min < t1_min) && (trav0 != RC_INVALID_NODE);
@@ -155,7 +155,7 @@ __device__ inline bool step(RayState& s, const SceneView& a, Stack& st) {
         return true;
     } else {
         // bottom-level leaf: fast_intersect_triangle (:1756-1797) on the vertices stored in the node
-        float3_ v0 = mk3(nd.a.x, nd.a.y, nd.a.z), v1 = mk3(nd.a.w, nd.b.x, nd.b.y), v2 = mk3(nd.b.z, nd.b.w, nd.c.x);
+        float3_ v0 = mk3(nd.a.x, nd.a.y, nd.c.x), v1 = mk3(nd.a.z, nd.a.w, nd.c.y), v2 = mk3(nd.b.x, nd.b.y, nd.c.z);
         float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
         float3_ s1 = cross3(s.d, e2);
         float det = dot3(s1, e1);
@@ -180,6 +180,7 @@ __device__ inline bool step(RayState& s, const SceneView& a, Stack& st) {
     if (s.node == RC_TOP_LEVEL_SENTINEL) {
         s.node = st.pop(s.sp);
         s.cur_inst = -1;
+        s.blas_off = a.tlas_off;
         s.o = s.wo; s.d = s.wd; s.inv = s.winv;
         s.ox = mk3(-s.o.x * s.inv.x, -s.o.y * s.inv.y, -s.o.z * s.inv.z);
     }
@@ -211,7 +212,7 @@ __device__ inline RcRay load_ray(const RcRay* rays, uint64_t i) {
 // Whole-ray traversal for callers that do not interleave rays (drivers).
 template <bool ANY, class Stack>
 __device__ inline void trace_ray(RayState& s, const RcRay& r, const SceneView& a, Stack& st) {
-    init_ray(s, r, ANY, st);
+    init_ray(s, r, ANY, st, a.tlas_off);
     if (a.n_tlas_nodes != 0)
         while (step<ANY>(s, a, st)) {}
 }
