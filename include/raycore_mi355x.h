@@ -100,6 +100,9 @@ int rc_scene_destroy(rc_scene* scene);
  * degenerate filter, :595).  Degenerate faces (is_degenerate, src/triangle_mesh.jl:14-17) are dropped,
  * the LBVH is built on the device (build_blas, :1376-1443).  *blas_id receives the 0-based geometry id. */
 int rc_add_blas(rc_scene* scene, const float* verts, const uint32_t* meta, uint32_t n, uint32_t* blas_id);
+/* Same with the triangle soup already in device memory (the reference builds BLASes "directly on the backend",
+ * src/instanced-bvh.jl:16-21): no host staging; filter, sort and tree construction all run on the GPU. */
+int rc_add_blas_device(rc_scene* scene, const float* d_verts, const uint32_t* d_meta, uint32_t n, uint32_t* blas_id);
 
 /* push!(tlas, mesh, transforms; instance_ids) once the geometry exists (src/instanced-bvh.jl:639-676,
  * append_instances_with_handle! :612-623): m instances of blas_id.  xforms = m x 12 f32 (Mat3x4f bytes)
@@ -193,7 +196,7 @@ int rc_view_factors(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, 
 int rc_view_factor_rays_device(rc_scene* scene, uint64_t seed, uint32_t src_prim, uint32_t ray_begin, uint32_t n_rays,
                                rc_ray* d_rays, void* stream);
 
-/* Timing of the most recent trace / driver launch on this scene, measured with HIP events on the launch
+/* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);
 

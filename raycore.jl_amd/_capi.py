@@ -37,6 +37,7 @@ SYMBOLS = [
     ("rc_scene_create", _int, [_int, C.POINTER(_vp)]),
     ("rc_scene_destroy", _int, [_vp]),
     ("rc_add_blas", _int, [_vp, _vp, _vp, _u32, _pu32]),
+    ("rc_add_blas_device", _int, [_vp, _vp, _vp, _u32, _pu32]),
     ("rc_add_instances", _int, [_vp, _u32, _vp, _vp, _u32, _pu32]),
     ("rc_add_instances_with_inverse", _int, [_vp, _u32, _vp, _vp, _vp, _u32, _pu32]),
     ("rc_update_transforms", _int, [_vp, _u32, _vp, _u32]),

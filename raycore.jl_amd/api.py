@@ -163,6 +163,13 @@ class TLAS:
         self._prims_cache = None
         return blas_id.value + 1
 
+    def add_geometry_device(self, d_verts, n, d_meta=None):
+        """build_and_append_blas! from device-resident soup (d_verts: device pointer to n x 9 f32); returns the 1-based BLAS index."""
+        blas_id = C.c_uint32()
+        check(lib().rc_add_blas_device(self._h, ptr(d_verts), ptr(d_meta) if d_meta else None, int(n), C.byref(blas_id)))
+        self._prims_cache = None
+        return blas_id.value + 1
+
     def delete(self, handle):  # delete!, :690-699
         d = C.c_int()
         check(lib().rc_delete(self._h, handle.id, C.byref(d)))

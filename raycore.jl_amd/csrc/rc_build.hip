@@ -11,6 +11,7 @@
 // per internal node, refit is the classic second-arrival walk with agent-scope acq_rel counters.
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -64,11 +65,38 @@ __device__ inline void tri_bounds(const RcPrim& p, float3_& mn, float3_& mx) {
     mx = max3v(max3v(v0, v1), v2);
 }
 
+// is_degenerate_face (src/instanced-bvh.jl:573-577, src/triangle_mesh.jl:14-17): ((v3-v1) x (v2-v1)) . itself == 0
+// exactly (isapprox against an exact 0 with the default tolerances).  flags[i] = 1 keeps face i.
+__global__ void k_flag_valid_faces(const float* verts, uint32_t n, uint32_t* flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = verts + 9 * (size_t)i;
+    float3_ a = mk3(p[0], p[1], p[2]), b = mk3(p[3], p[4], p[5]), c = mk3(p[6], p[7], p[8]);
+    float3_ v = cross3(sub3(c, a), sub3(b, a));
+    flags[i] = dot3(v, v) == 0.0f ? 0u : 1u;
+}
+
+// cpu_triangles of build_and_append_blas! (:593-600) as a stream compaction: face i goes to slot pos[i] (exclusive scan
+// of the flags), order preserved; default metadata = face index BEFORE filtering (:595).
+__global__ void k_compact_faces(const float* verts, const uint32_t* meta, const uint32_t* flags, const uint32_t* pos, uint32_t n, RcPrim* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    RcPrim t;
+    const float* p = verts + 9 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t.v[k] = p[k];
+    t.meta = meta ? meta[i] : (i + 1);
+    out[pos[i]] = t;
+}
+
 // mapreduce(world_bound, U, primitives) (src/instanced-bvh.jl:1386)
 __global__ void k_blas_scene_bounds(const RcPrim* prims, uint32_t n, uint32_t* enc) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float3_ mn = mk3(INFINITY, INFINITY, INFINITY), mx = mk3(-INFINITY, -INFINITY, -INFINITY);
-    if (i < n) tri_bounds(prims[i], mn, mx);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {  // grid-stride: few atomics
+        float3_ a, b;
+        tri_bounds(prims[i], a, b);
+        mn = min3v(mn, a); mx = max3v(mx, b);
+    }
     wave_reduce_bounds(mn, mx, enc);
 }
 
@@ -200,38 +228,58 @@ __device__ inline void node_aabb(const RcNode& nd, bool interior, bool tlas, flo
     }
 }
 
-// Coherent 64-byte node read for data another workgroup (possibly on another XCD) has just published.
-__device__ inline RcNode load_node_agent(const RcNode* p) {
-    RcNode r;
-    const uint32_t* s = reinterpret_cast<const uint32_t*>(p);
-    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = __hip_atomic_load(s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return r;
+// Device-coherent 8/16-byte accesses for data exchanged between workgroups inside one launch: sc0 sc1 loads and
+// stores on both sides go past the (non-coherent) per-CU L1 and per-XCD L2 (CDNA guide, Guideline 16).
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ inline void store_coherent(float* p, f4v v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ inline void store_coherent(float* p, f2v v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ inline f4v load4_coherent(const float* p) {
+    f4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ inline f2v load2_coherent(const float* p) {
+    f2v v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
 }
 
-// refit_aabbs_kernel! / refit_tlas_aabbs_kernel! (src/instanced-bvh-kernels.jl:239-286, 381-428).
-// One thread per leaf walks up; the second arrival at a node (acq_rel agent-scope counter) computes it.
-__global__ void k_refit(RcNode* nodes, uint32_t* flags, uint32_t n, int tlas) {
-    uint32_t prim = blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (prim > n) return;
-    uint32_t parent = nodes[(n - 1 + prim) - 1].parent;
+// refit_aabbs_kernel! / refit_tlas_aabbs_kernel! (src/instanced-bvh-kernels.jl:239-286, 381-428): one thread per
+// leaf walks up; the SECOND arrival at a node (atomic counter) continues.  The reference's second arrival re-reads
+// both children and writes both child boxes; here every arriving thread carries its subtree box in registers and
+// publishes it straight into its slot of the parent (aabb0 if it came from child0, aabb1 otherwise), so the second
+// arrival only has to read the sibling's 24 bytes.  Same min/max over the same values => identical node contents.
+__global__ void k_refit(RcNode* nodes, const RcPrim* prims, uint32_t* flags, uint32_t n, int tlas) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (j > n) return;
+    uint32_t cur = n - 1 + j;
+    float3_ mn, mx;
+    if (tlas) {
+        const RcNode& lf = nodes[cur - 1];  // leaf boxes were written by an earlier launch
+        mn = mk3(lf.f[0], lf.f[1], lf.f[2]); mx = mk3(lf.f[3], lf.f[4], lf.f[5]);
+    } else {
+        tri_bounds(prims[j - 1], mn, mx);   // get_node_aabb of a BLAS leaf (:1149-1158)
+    }
+    uint32_t parent = nodes[cur - 1].parent;
     while (parent != RC_INVALID_NODE) {
-        uint32_t old = __hip_atomic_fetch_add(&flags[parent - 1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old != 1u) break;
         RcNode* nd = &nodes[parent - 1];
-        uint32_t c0 = nd->child0, c1 = nd->child1, up = nd->parent;  // written by earlier launches
-        RcNode n0 = load_node_agent(&nodes[c0 - 1]);
-        RcNode n1 = load_node_agent(&nodes[c1 - 1]);
-        float3_ mn0, mx0, mn1, mx1;
-        node_aabb(n0, c0 < n, tlas != 0, mn0, mx0);
-        node_aabb(n1, c1 < n, tlas != 0, mn1, mx1);
-        float out[12] = {mn0.x, mn0.y, mn0.z, mx0.x, mx0.y, mx0.z, mn1.x, mn1.y, mn1.z, mx1.x, mx1.y, mx1.z};
-        uint32_t* dst = reinterpret_cast<uint32_t*>(nd->f);
-#pragma unroll
-        for (int k = 0; k < 12; ++k)
-            __hip_atomic_store(dst + k, __builtin_bit_cast(uint32_t, out[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        parent = up;
+        const bool first_slot = nd->child0 == cur;  // topology was written by earlier launches
+        float* mine = nd->f + (first_slot ? 0 : 6);
+        const float* sib = nd->f + (first_slot ? 6 : 0);
+        if (first_slot) { store_coherent(mine, f4v{mn.x, mn.y, mn.z, mx.x}); store_coherent(mine + 4, f2v{mx.y, mx.z}); }
+        else { store_coherent(mine, f2v{mn.x, mn.y}); store_coherent(mine + 2, f4v{mn.z, mx.x, mx.y, mx.z}); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my box is out before my arrival is counted
+        uint32_t old = __hip_atomic_fetch_add(&flags[parent - 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old != 1u) break;
+        float3_ smn, smx;
+        if (first_slot) { f2v a = load2_coherent(sib); f4v b = load4_coherent(sib + 2); smn = mk3(a.x, a.y, b.x); smx = mk3(b.y, b.z, b.w); }
+        else { f4v a = load4_coherent(sib); f2v b = load2_coherent(sib + 4); smn = mk3(a.x, a.y, a.z); smx = mk3(a.w, b.x, b.y); }
+        // union in the reference's operand order: min.(aabb0, aabb1) (:1144-1147)
+        mn = first_slot ? min3v(mn, smn) : min3v(smn, mn);
+        mx = first_slot ? max3v(mx, smx) : max3v(smx, mx);
+        cur = parent;
+        parent = nd->parent;
     }
 }
 
@@ -344,10 +392,10 @@ void emit_tree(rc_scene* s, RcNode* nodes, uint32_t n) {
     }
 }
 
-void run_refit(rc_scene* s, RcNode* nodes, uint32_t n, int tlas) {
+void run_refit(rc_scene* s, RcNode* nodes, const RcPrim* prims, uint32_t n, int tlas) {
     if (n < 2) return;
     RC_HIP(hipMemsetAsync(s->flags.p, 0, sizeof(uint32_t) * (n - 1), s->stream));
-    hipLaunchKernelGGL(k_refit, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, nodes, s->flags.p, n, tlas);
+    hipLaunchKernelGGL(k_refit, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, nodes, prims, s->flags.p, n, tlas);
 }
 
 void host_root_aabb(const RcNode& root, bool tlas, float mn[3], float mx[3]) {
@@ -382,27 +430,49 @@ void rc_mat3x4_inverse(const float m[12], float out[12]) {
     out[8] = y0.z; out[9] = y1.z; out[10] = y2.z; out[11] = -(y0.z * tx + y1.z * ty + y2.z * tz);
 }
 
-// build_blas (src/instanced-bvh.jl:1376-1443)
-void rc_build_blas(rc_scene* s, const RcPrim* host_prims, uint32_t n, Blas& out) {
+// Triangle ingestion on the device (build_and_append_blas! minus mesh decomposition, :581-601): raw n x 9 f32 soup
+// (+ optional metadata) already in device memory -> degenerate filter -> compacted RcPrim array in s->prim_tmp.
+// Returns the number of valid triangles (one 4-byte read-back).
+uint32_t rc_ingest_faces(rc_scene* s, const float* d_verts, const uint32_t* d_meta, uint32_t n) {
+    if (n == 0) return 0;
     reserve_build_scratch(s, n);
     s->prim_tmp.reserve(n);
+    hipLaunchKernelGGL(k_flag_valid_faces, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, d_verts, n, s->keys_a.p);
+    size_t tmp = 0;
+    RC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, s->keys_a.p, s->keys_b.p, (int)n, s->stream));
+    s->sort_tmp.reserve(tmp ? tmp : 1);
+    RC_HIP(hipcub::DeviceScan::ExclusiveSum(s->sort_tmp.p, tmp, s->keys_a.p, s->keys_b.p, (int)n, s->stream));
+    hipLaunchKernelGGL(k_compact_faces, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, d_verts, d_meta, s->keys_a.p, s->keys_b.p, n, s->prim_tmp.p);
+    uint32_t last[2];
+    RC_HIP(hipMemcpyAsync(&last[0], s->keys_b.p + (n - 1), 4, hipMemcpyDeviceToHost, s->stream));
+    RC_HIP(hipMemcpyAsync(&last[1], s->keys_a.p + (n - 1), 4, hipMemcpyDeviceToHost, s->stream));
+    RC_HIP(hipStreamSynchronize(s->stream));
+    RC_HIP(hipGetLastError());
+    return last[0] + last[1];
+}
+
+// build_blas (src/instanced-bvh.jl:1376-1443) over the n compacted primitives waiting in s->prim_tmp
+void rc_build_blas(rc_scene* s, uint32_t n, Blas& out) {
+    reserve_build_scratch(s, n);
     out.prims.reserve(n);
     out.nodes.reserve(2 * (size_t)n - 1);
     out.n_prims = n;
     out.n_nodes = 2 * n - 1;
-    RC_HIP(hipMemcpyAsync(s->prim_tmp.p, host_prims, sizeof(RcPrim) * n, hipMemcpyHostToDevice, s->stream));
+    RC_HIP(hipEventRecord(s->ev0, s->stream));
     hipLaunchKernelGGL(k_init_scene_enc, dim3(1), dim3(64), 0, s->stream, s->scene_enc.p);
-    hipLaunchKernelGGL(k_blas_scene_bounds, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->prim_tmp.p, n, s->scene_enc.p);
+    hipLaunchKernelGGL(k_blas_scene_bounds, dim3(std::min(grid_for(n), 1024u)), dim3(kBlock), 0, s->stream, s->prim_tmp.p, n, s->scene_enc.p);
     hipLaunchKernelGGL(k_blas_morton, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->prim_tmp.p, n, s->scene_enc.p, s->keys_a.p, s->vals_a.p);
     sort_pairs(s, n);
     hipLaunchKernelGGL(k_gather_prims, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->prim_tmp.p, s->vals_b.p, n, out.prims.p);
     emit_tree(s, out.nodes.p, n);
     hipLaunchKernelGGL(k_blas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, out.nodes.p, out.prims.p, n);
-    run_refit(s, out.nodes.p, n, 0);
+    run_refit(s, out.nodes.p, out.prims.p, n, 0);
+    RC_HIP(hipEventRecord(s->ev1, s->stream));
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, out.nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));
     RC_HIP(hipStreamSynchronize(s->stream));
     RC_HIP(hipGetLastError());
+    RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
     host_root_aabb(root, false, out.root_min, out.root_max);
 }
 
@@ -452,7 +522,7 @@ void rc_build_tlas(rc_scene* s) {
     emit_tree(s, s->tlas_nodes.p, n);
     // n == 1 (:1553-1570): the single leaf holds the scene AABB == the instance's world AABB (same min/max set)
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->vals_b.p, s->d_instances.p, s->d_descs.p, n);
-    run_refit(s, s->tlas_nodes.p, n, 1);
+    run_refit(s, s->tlas_nodes.p, nullptr, n, 1);
     hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes);
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, s->tlas_nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));
@@ -469,7 +539,7 @@ void rc_refit_tlas(rc_scene* s) {
     RC_HIP(hipMemcpyAsync(s->d_instances.p, s->instances.data(), sizeof(RcInstanceDesc) * n, hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p);
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, (const uint32_t*)nullptr, s->d_instances.p, s->d_descs.p, n);
-    run_refit(s, s->tlas_nodes.p, n, 1);
+    run_refit(s, s->tlas_nodes.p, nullptr, n, 1);
     hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes);
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, s->tlas_nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));

@@ -39,30 +39,6 @@ void use_device(rc_scene* s) { RC_HIP(hipSetDevice(s->device)); }
 
 const float kIdentity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 
-// is_degenerate (src/triangle_mesh.jl:14-17): ((v3-v1) x (v2-v1)) . itself == 0 exactly (isapprox against 0)
-bool is_degenerate(const float* p) {
-    float3_ a = mk3(p[0], p[1], p[2]), b = mk3(p[3], p[4], p[5]), c = mk3(p[6], p[7], p[8]);
-    float3_ v = cross3(sub3(c, a), sub3(b, a));
-    return dot3(v, v) == 0.0f;
-}
-
-// cpu_triangles of build_and_append_blas! (src/instanced-bvh.jl:593-601)
-std::vector<RcPrim> filter_triangles(const float* verts, const uint32_t* meta, uint32_t n) {
-    if (!verts && n) throw RcError(RC_ERR_INVALID_ARGUMENT, "verts is NULL");
-    std::vector<RcPrim> out;
-    out.reserve(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const float* p = verts + 9 * (size_t)i;
-        if (is_degenerate(p)) continue;
-        RcPrim t;
-        memcpy(t.v, p, 36);
-        t.meta = meta ? meta[i] : (i + 1);
-        out.push_back(t);
-    }
-    if (out.empty()) throw RcError(RC_ERR_EMPTY_GEOMETRY, "Geometry has no valid triangles");
-    return out;
-}
-
 HandleRange& live_range(rc_scene* s, uint32_t handle) {
     auto it = s->handle_to_range.find(handle);
     if (it == s->handle_to_range.end()) throw RcError(RC_ERR_INVALID_HANDLE, "Invalid handle");
@@ -176,13 +152,43 @@ int rc_scene_destroy(rc_scene* s) {
     return RC_OK;
 }
 
+// faces (device pointers) -> degenerate filter -> LBVH, all on the device
+static void build_from_device_faces(rc_scene* s, const float* d_verts, const uint32_t* d_meta, uint32_t n, Blas& b) {
+    if (n && !d_verts) throw RcError(RC_ERR_INVALID_ARGUMENT, "verts is NULL");
+    uint32_t valid = rc_ingest_faces(s, d_verts, d_meta, n);
+    if (valid == 0) throw RcError(RC_ERR_EMPTY_GEOMETRY, "Geometry has no valid triangles");  // :601
+    rc_build_blas(s, valid, b);
+}
+
+// host soup -> staging buffers on the device
+static void stage_faces(rc_scene* s, const float* verts, const uint32_t* meta, uint32_t n) {
+    if (n && !verts) throw RcError(RC_ERR_INVALID_ARGUMENT, "verts is NULL");
+    s->vert_stage.reserve(9 * (size_t)(n ? n : 1));
+    if (n) RC_HIP(hipMemcpyAsync(s->vert_stage.p, verts, sizeof(float) * 9 * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    if (meta) {
+        s->meta_stage.reserve(n ? n : 1);
+        if (n) RC_HIP(hipMemcpyAsync(s->meta_stage.p, meta, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    }
+}
+
 int rc_add_blas(rc_scene* s, const float* verts, const uint32_t* meta, uint32_t n, uint32_t* blas_id) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
     return guarded([&] {
         use_device(s);
-        std::vector<RcPrim> tris = filter_triangles(verts, meta, n);
+        stage_faces(s, verts, meta, n);
         Blas b;
-        rc_build_blas(s, tris.data(), (uint32_t)tris.size(), b);
+        build_from_device_faces(s, s->vert_stage.p, meta ? s->meta_stage.p : nullptr, n, b);
+        s->blas.push_back(std::move(b));
+        if (blas_id) *blas_id = (uint32_t)s->blas.size() - 1;
+    });
+}
+
+int rc_add_blas_device(rc_scene* s, const float* d_verts, const uint32_t* d_meta, uint32_t n, uint32_t* blas_id) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        Blas b;
+        build_from_device_faces(s, d_verts, d_meta, n, b);
         s->blas.push_back(std::move(b));
         if (blas_id) *blas_id = (uint32_t)s->blas.size() - 1;
     });
@@ -237,9 +243,9 @@ int rc_update_geometry(rc_scene* s, uint32_t handle, const float* verts, const u
         HandleRange& r = live_range(s, handle);
         if (r.count == 0) throw RcError(RC_ERR_INVALID_HANDLE, "Handle has no instances");
         uint32_t blas_idx = s->instances[r.first].blas_index;  // :814-816
-        std::vector<RcPrim> tris = filter_triangles(verts, meta, n);
+        stage_faces(s, verts, meta, n);
         Blas b;
-        rc_build_blas(s, tris.data(), (uint32_t)tris.size(), b);
+        build_from_device_faces(s, s->vert_stage.p, meta ? s->meta_stage.p : nullptr, n, b);
         s->blas[blas_idx - 1] = std::move(b);
         s->dirty = true;
     });

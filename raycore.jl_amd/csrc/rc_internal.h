@@ -112,12 +112,15 @@ struct rc_scene {
     DevBuf<RcRay> ray_stage;
     DevBuf<RcHit> hit_stage;
     DevBuf<float> f32_stage;
+    DevBuf<float> vert_stage;
+    DevBuf<uint32_t> meta_stage;
 
     TraceOptions opt;
 };
 
 // rc_build.hip
-void rc_build_blas(rc_scene* s, const RcPrim* host_prims, uint32_t n, Blas& out);
+uint32_t rc_ingest_faces(rc_scene* s, const float* d_verts, const uint32_t* d_meta, uint32_t n);  // -> s->prim_tmp
+void rc_build_blas(rc_scene* s, uint32_t n, Blas& out);  // builds from s->prim_tmp
 void rc_build_tlas(rc_scene* s);   // build_tlas_topology + flat arrays -> StaticTLAS
 void rc_refit_tlas(rc_scene* s);   // refit_tlas!
 void rc_mat3x4_inverse(const float m[12], float out[12]);

@@ -137,6 +137,23 @@ def test_build_parity(rc, oracle, cfg_name):
     assert np.array_equal(np.concatenate([wb.p_min, wb.p_max]), o.world_bound)
 
 
+def test_build_from_device_buffers(rc, oracle):
+    """rc_add_blas_device: soup (with degenerate faces and explicit metadata) already in device memory."""
+    import torch
+    verts = rc.scenes.uv_sphere_grid(40, 30, centre=(1, 2, 3), radius=2.0)   # has exactly-degenerate pole faces
+    meta = (np.arange(len(verts), dtype=np.uint32) * 7 + 3)
+    t = rc.TLAS()
+    dv, dm = torch.from_numpy(verts).cuda(), torch.from_numpy(meta.view(np.int32)).cuda()
+    assert t.add_geometry_device(dv.data_ptr(), len(verts), dm.data_ptr()) == 1
+    t.push_instances(1)
+    o = oracle.Scene()
+    o.add_instance(o.add_blas(verts, meta))
+    o.build()
+    st = t.adapt()
+    assert len(st.all_blas_prims) < len(verts)
+    assert st.all_blas_prims.tobytes() == o.blas_prims.tobytes() and nodes_equal(st.all_blas_nodes, o.blas_nodes)
+
+
 def test_build_parity_100k(rc, oracle):
     cfg = rc.scenes.config_c2()
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)

@@ -1,0 +1,75 @@
+// Dev microbenchmark: cost of wave-level 16-byte gathers from a cache-resident table as a function of
+// the number of active lanes, and the same through LDS.  Informs the traversal kernel's fetch design.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int LOADS>
+__global__ __launch_bounds__(256) void k_gather(const float4* table, unsigned mask, int active, int iters, float* out) {
+    const int lane = threadIdx.x & 63;
+    unsigned idx = (blockIdx.x * 256 + threadIdx.x) * 2654435761u;
+    float acc = 0.f;
+    if (lane < active) {
+        for (int i = 0; i < iters; ++i) {
+            idx = idx * 1664525u + 1013904223u;
+            const float4* p = table + ((idx >> 8) & mask) * 4;   // 64-byte aligned record
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) { float4 v = p[k]; acc += v.x + v.w; }
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(1024) void k_gather_lds(const float4* table, unsigned mask, int active, int iters, float* out) {
+    extern __shared__ float4 cache[];
+    for (unsigned i = threadIdx.x; i < (mask + 1) * 4; i += 1024) cache[i] = table[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned idx = (blockIdx.x * 1024 + threadIdx.x) * 2654435761u;
+    float acc = 0.f;
+    if (lane < active) {
+        for (int i = 0; i < iters; ++i) {
+            idx = idx * 1664525u + 1013904223u;
+            const float4* p = cache + ((idx >> 8) & mask) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { float4 v = p[k]; acc += v.x + v.w; }
+        }
+    }
+    out[blockIdx.x * 1024 + threadIdx.x] = acc;
+}
+
+int main() {
+    const int iters = 2000;
+    float4* table; float* out;
+    CK(hipMalloc(&table, 64u << 20)); CK(hipMalloc(&out, 4u << 20));
+    CK(hipMemset(table, 0, 64u << 20));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const unsigned masks[] = {255, 8191, 262143};   // 16 KB (L1), 512 KB (L2), 16 MB (MALL/L2 mix)
+    for (unsigned mask : masks) {
+        for (int active : {64, 48, 32, 16, 8, 4}) {
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_gather<4>, dim3(256 * 6), dim3(256), 0, 0, table, mask, active, iters, out);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            }
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            double waves = 256.0 * 6 * 4, insts = waves * iters * 4;
+            // cycles of one CU's TA/TD per wave-level dwordx4 instruction, assuming 2.1 GHz and 24 waves sharing one CU
+            printf("global table %6u KB active %2d: %.3f ms  -> %.1f clk/CU per load instr, %.1f GB/s useful\n", (mask + 1) / 16, active, ms,
+                   ms * 1e-3 * 2.1e9 * 256 / insts, waves * iters * active * 64.0 / (ms * 1e-3) / 1e9);
+        }
+    }
+    for (int active : {64, 32, 16, 8}) {
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_gather_lds, dim3(256), dim3(1024), 64 * 1024, 0, table, 1023u, active, iters, out);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        }
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double waves = 256.0 * 16, insts = waves * iters * 4;
+        printf("LDS 64 KB active %2d: %.3f ms -> %.1f clk/CU per ds_read_b128, %.1f GB/s useful\n", active, ms, ms * 1e-3 * 2.1e9 * 256 / insts,
+               waves * iters * active * 64.0 / (ms * 1e-3) / 1e9);
+    }
+    return 0;
+}
