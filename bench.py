@@ -122,6 +122,22 @@ def main():
         extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"]), "closest", reps=5)
         t2.free()
 
+    if not args.no_extras and rank == 0:
+        # LBVH build (row a14): device pipeline time for triangle soup already in HBM; the reference publishes
+        # 4.93 / 7.46 / 16.16 ms for 250k / 1M / 4M triangles on an RX 7900 XTX (benchmarks/implicitbvh_comparison.md:12-14).
+        builds = {}
+        for nt, ref_ms in ((250_000, 4.93), (1_000_000, 7.46), (4_000_000, 16.16)):
+            dv = torch.from_numpy(sc.random_triangles(nt, 42, edge=0.01)).cuda()
+            tb = rc.TLAS(local_rank)
+            best = 1e30
+            for _ in range(3):
+                tb.add_geometry_device(dv.data_ptr(), nt)
+                best = min(best, tb.last_kernel_ms())
+            builds[str(nt)] = {"ms": round(best, 3), "Mtris_s": round(nt / best / 1e3, 1), "reference_rx7900xtx_ms": ref_ms}
+            tb.free()
+            del dv
+        extras["blas_build_device"] = builds
+        torch.cuda.empty_cache()
     if not args.no_extras:
         # view_factors (BASELINE config C5: ~50k-triangle closed scene, rays_per_triangle = 4096 => 204.9 M rays, N x N
         # u32 = 10 GB) through the multi-GPU driver: every rank takes part; both partitions are timed.

@@ -52,20 +52,29 @@ __global__ __launch_bounds__(kBlock) void k_ray_grid(GridParams g, RcRay* out) {
     }
 }
 
-// hits_from_grid + the histogram of get_illumination (:58-72, :112-124) fused: trace, then one f32 atomic
-// add of 1.0 on the hit primitive's metadata slot (exact while counts < 2^24, as in the reference's Float32 sums).
-__global__ __launch_bounds__(kBlock) void k_illumination(SceneView v, GridParams g, uint64_t ray_begin, uint64_t ray_end, float* counts) {
-    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    LaneStack st(lds_stack + threadIdx.x, v.overflow + gtid, v.total_threads, v.status);
-    for (uint64_t i = ray_begin + gtid; i < ray_end; i += v.total_threads) {
-        RayState s;
-        trace_ray<false>(s, grid_ray(g, i), v, st);
-        if (s.closest_inst >= 0) {
-            uint32_t meta = v.prims[hit_prim_index(s, v)].meta;
-            if (meta >= 1 && meta <= v.n_prims) atomicAdd(&counts[meta - 1], 1.0f);
-        }
+// hits_from_grid + the histogram of get_illumination (:58-72, :112-124) fused on the persistent phased traversal
+// core: the ray is generated when a lane is refilled, and a finished ray does one f32 atomic add of 1.0 on the hit
+// primitive's metadata slot (exact while counts < 2^24, as in the reference's Float32 sums).
+struct GridSource {
+    GridParams g;
+    uint64_t first;
+    __device__ inline RcRay operator()(uint64_t i) const { return grid_ray(g, first + i); }
+};
+struct HistogramSink {
+    const RcInstRec* inst;
+    const RcPrim* prims;
+    uint32_t n_prims;
+    float* counts;
+    __device__ inline void operator()(uint64_t, bool hit, float, float, float, uint32_t prim, int instance) const {
+        if (!hit) return;
+        const uint4 m3 = *(reinterpret_cast<const uint4*>(inst + instance) + 3);
+        const uint32_t meta = prims[m3.y + prim - 1u].meta;
+        if (meta >= 1 && meta <= n_prims) atomicAdd(&counts[meta - 1], 1.0f);
     }
+};
+__global__ __launch_bounds__(kBlock, 6) void k_illumination(SceneView v, PersistArgs p, GridParams g, uint64_t ray_begin, float* counts) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    phased_trace<false, kLdsStack, false>(v, p, lds_stack, GridSource{g, ray_begin}, HistogramSink{v.inst, v.prims, v.n_prims, counts});
 }
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------------
@@ -162,26 +171,38 @@ __device__ inline RcRay view_factor_ray(const RcPrim& tri, uint32_t src, uint32_
     return RcRay{o.x, o.y, o.z, 0.0f, d.x, d.y, d.z, INFINITY};
 }
 
-// view_factors! (:80-104): work item = (source primitive, ray); result[src_meta, hit_meta] += 1 when the
-// hit primitive's metadata differs.  One u32 atomic per counted ray.
-__global__ __launch_bounds__(kBlock) void k_view_factors(SceneView v, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t n_src,
-                                                          uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
-                                                          uint64_t col_stride, uint32_t row_offset, uint32_t flags) {
-    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    LaneStack st(lds_stack + threadIdx.x, v.overflow + gtid, v.total_threads, v.status);
-    const uint64_t total = (uint64_t)n_src * n_ray;
-    for (uint64_t w = gtid; w < total; w += v.total_threads) {
-        uint32_t src = src_begin + (uint32_t)(w / n_ray), ray_idx = ray_begin + (uint32_t)(w % n_ray);
-        const RcPrim tri = v.prims[src];
-        RayState s;
-        trace_ray<false>(s, view_factor_ray(tri, src, ray_idx, k0, k1), v, st);
-        if (s.closest_inst >= 0) {
-            uint32_t hit_meta = v.prims[hit_prim_index(s, v)].meta, src_meta = tri.meta;
-            if (hit_meta != src_meta && src_meta >= 1 && src_meta <= v.n_prims && hit_meta >= 1 && hit_meta <= v.n_prims)
-                atomicAdd(&matrix[(uint64_t)(((flags & 1u) ? src : src_meta - 1) - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride], 1u);
-        }
+// view_factors! (:80-104): work item = (source primitive, ray); result[src_meta, hit_meta] += 1 when the hit
+// primitive's metadata differs.  One u32 atomic per counted ray.  Runs on the persistent phased traversal core.
+struct ViewFactorSource {
+    const RcPrim* prims;
+    uint32_t k0, k1, src_begin, ray_begin, n_ray;
+    __device__ inline RcRay operator()(uint64_t w) const {
+        const uint32_t src = src_begin + (uint32_t)(w / n_ray), ray_idx = ray_begin + (uint32_t)(w % n_ray);
+        return view_factor_ray(prims[src], src, ray_idx, k0, k1);
     }
+};
+struct ViewFactorSink {
+    const RcInstRec* inst;
+    const RcPrim* prims;
+    uint32_t n_prims, src_begin, n_ray;
+    uint32_t* matrix;
+    uint64_t row_stride, col_stride;
+    uint32_t row_offset, flags;
+    __device__ inline void operator()(uint64_t w, bool hit, float, float, float, uint32_t prim, int instance) const {
+        if (!hit) return;
+        const uint32_t src = src_begin + (uint32_t)(w / n_ray);
+        const uint4 m3 = *(reinterpret_cast<const uint4*>(inst + instance) + 3);
+        const uint32_t hit_meta = prims[m3.y + prim - 1u].meta, src_meta = prims[src].meta;
+        if (hit_meta != src_meta && src_meta >= 1 && src_meta <= n_prims && hit_meta >= 1 && hit_meta <= n_prims)
+            atomicAdd(&matrix[(uint64_t)(((flags & 1u) ? src : src_meta - 1) - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride], 1u);
+    }
+};
+__global__ __launch_bounds__(kBlock, 6) void k_view_factors(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin,
+                                                             uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
+                                                             uint64_t col_stride, uint32_t row_offset, uint32_t flags) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    phased_trace<false, kLdsStack, false>(v, p, lds_stack, ViewFactorSource{v.prims, k0, k1, src_begin, ray_begin, n_ray},
+                                          ViewFactorSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags});
 }
 
 __global__ void k_view_factor_rays(SceneView v, uint32_t k0, uint32_t k1, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* out) {
@@ -245,8 +266,9 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
     uint32_t blocks = rc_persistent_blocks(s, ray_end - ray_begin);
     rc_prepare_launch(s, stream);
     SceneView v = rc_scene_view(s, blocks * kBlock);
+    PersistArgs p = rc_persist_args(s, ray_end - ray_begin, blocks * kBlock);
     RC_HIP(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_illumination, dim3(blocks), dim3(kBlock), 0, stream, v, g, ray_begin, ray_end, d_counts);
+    hipLaunchKernelGGL(k_illumination, dim3(blocks), dim3(kBlock), 0, stream, v, p, g, ray_begin, d_counts);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
 }
@@ -261,9 +283,10 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     uint32_t blocks = rc_persistent_blocks(s, total);
     rc_prepare_launch(s, stream);
     SceneView v = rc_scene_view(s, blocks * kBlock);
+    PersistArgs p = rc_persist_args(s, total, blocks * kBlock);
     RC_HIP(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_view_factors, dim3(blocks), dim3(kBlock), 0, stream, v, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
-                       src_end - src_begin, ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags);
+    hipLaunchKernelGGL(k_view_factors, dim3(blocks), dim3(kBlock), 0, stream, v, p, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
+                       ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
 }

@@ -17,8 +17,6 @@ namespace {
 
 using namespace rc;
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 // ---- kernel 0: one ray per lane, grid-stride --------------------------------------------------------
 template <bool ANY, int LDS_N, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_simple(TraceArgs a) {
@@ -330,203 +328,12 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
     }
 }
 
-// ---- kernel 3: persistent waves, phase-structured ("while-while") scheduling --------------------------
-// Same idea as kernel 2 -- run one block at a time for the lanes that need it -- but with a fixed phase order
-// instead of a per-iteration vote: an inner loop walks interior nodes for as long as at least `int_thr`
-// lanes have one pending (always at least once), then ONE pass each over the BLAS-leaf lanes, the level-switch
-// lanes (instance entry / return to top level) and the finished lanes (write-out + refill).  The inner loop
-// only touches {node, sp} so the compiler keeps the ray registers untouched across it.  Per-lane order of
-// visits, tests, pushes and pops is the reference's; only the interleaving between lanes differs.
+// ---- kernel 3: the phase-structured persistent core (rc_traverse_core.h) on a ray array ------------------------
 template <bool ANY, int LDS_N, int MINW, bool STATS>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
     __shared__ uint32_t lds_stack[LDS_N * kBlock];
-    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    LaneStackT<LDS_N> st(lds_stack + threadIdx.x, a.v.overflow + gtid, a.v.total_threads, a.v.status);
-    const int lane = threadIdx.x & 63;
-    if (a.v.n_tlas_nodes == 0) {
-        RayState miss;
-        miss.closest_inst = -1;
-        for (uint64_t i = gtid; i < a.n_rays; i += a.v.total_threads) write_hit(miss, a.v, a.hits, i);
-        return;
-    }
-    const uint32_t n_instances = (a.v.n_tlas_nodes + 1u) >> 1;
-    const uint32_t tlas_off = a.v.tlas_off;
-    const RcNode* const nodes = a.v.blas_nodes;
-    unsigned long long pool_next = 0, pool_end = 0;
-    bool exhausted = false;
-    uint64_t my_ray = 0;
-    float3_ wo = mk3(0, 0, 0), wd = mk3(0, 0, 0), winv = mk3(0, 0, 0);
-    float3_ o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0), ox = mk3(0, 0, 0);
-    float tmin = 0.f, closest_t = 0.f, cull_t = 0.f, hit_u = 0.f, hit_v = 0.f;
-    uint32_t closest_prim = RC_INVALID_NODE, cur_off = 0, n_level = 0;
-    uint32_t node = RC_INVALID_NODE;  // INVALID + !live = empty lane; INVALID + live = finished, result pending
-    int closest_inst = -1, cur_inst = -1, sp = 0;
-    bool live = false;
-    unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0};
-
-    for (;;) {
-        // ---- interior phase: intersect_internal_node (:1807-1832) + push far / descend near / pop (:1946-1960, 1991-1993)
-        for (;;) {
-            const bool is_int = node < n_level;  // sentinels and INVALID are >= 0xFFFFFFFE, never below a leaf threshold
-            const int n_int = __popcll(__ballot(is_int));
-            if (n_int == 0) break;
-            if (STATS) { st_iter[1] += 1; st_lane[1] += is_int ? 1 : 0; }
-            if (is_int) {
-                const float4* q = reinterpret_cast<const float4*>(nodes + (cur_off + node - 1));
-                const float4 na = q[0], nb = q[1], nc = q[2];
-                const uint2 ch = *reinterpret_cast<const uint2*>(q + 3);
-                // packed node (rc_pack_node): na = child-0 (min.x,min.y,max.x,max.y), nb = child-1 likewise, nc = z of both
-                const v2f ixy = {inv.x, inv.y}, oxy = {ox.x, ox.y}, izz = {inv.z, inv.z}, ozz = {ox.z, ox.z};
-                const v2f n0xy = v2f{na.x, na.y} * ixy + oxy, f0xy = v2f{na.z, na.w} * ixy + oxy;
-                const v2f n1xy = v2f{nb.x, nb.y} * ixy + oxy, f1xy = v2f{nb.z, nb.w} * ixy + oxy;
-                const v2f nf0z = v2f{nc.x, nc.y} * izz + ozz, nf1z = v2f{nc.z, nc.w} * izz + ozz;
-                const float f0x = f0xy.x, f0y = f0xy.y, f0z = nf0z.y, n0x = n0xy.x, n0y = n0xy.y, n0z = nf0z.x;
-                const float f1x = f1xy.x, f1y = f1xy.y, f1z = nf1z.y, n1x = n1xy.x, n1y = n1xy.y, n1z = nf1z.x;
-                const float t0_max = fminf(fminf(fminf(fmaxf(f0x, n0x), fmaxf(f0y, n0y)), fmaxf(f0z, n0z)), cull_t);
-                const float t0_min = fmaxf(fmaxf(fmaxf(fminf(f0x, n0x), fminf(f0y, n0y)), fminf(f0z, n0z)), tmin);
-                const float t1_max = fminf(fminf(fminf(fmaxf(f1x, n1x), fmaxf(f1y, n1y)), fmaxf(f1z, n1z)), cull_t);
-                const float t1_min = fmaxf(fmaxf(fmaxf(fminf(f1x, n1x), fminf(f1y, n1y)), fminf(f1z, n1z)), tmin);
-                const uint32_t trav0 = (t0_min <= t0_max) ? ch.x : RC_INVALID_NODE;
-                const uint32_t trav1 = (t1_min <= t1_max) ? ch.y : RC_INVALID_NODE;
-                const bool first0 = (t0_min < t1_min) && (trav0 != RC_INVALID_NODE);
-                const uint32_t near_c = first0 ? trav0 : trav1, far_c = first0 ? trav1 : trav0;
-                if (far_c != RC_INVALID_NODE) st.push(sp, far_c);
-                node = (near_c != RC_INVALID_NODE) ? near_c : st.pop(sp);
-            }
-            if (n_int < a.sched_thr) break;  // too few interior lanes left: serve the waiting ones first
-        }
-        // ---- leaf phase: fast_intersect_triangle (:1756-1797) on BLAS leaves, then pop
-        {
-            const bool is_leaf = cur_inst >= 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
-            if (STATS && __ballot(is_leaf)) { st_iter[2] += 1; st_lane[2] += is_leaf ? 1 : 0; }
-            if (is_leaf) {
-                const RcNode* np = nodes + (cur_off + node - 1);
-                const float4* q = reinterpret_cast<const float4*>(np);
-                const float4 na = q[0];
-                const float2 nb = *reinterpret_cast<const float2*>(q + 1);
-                const float4 nc = q[2];
-                const float3_ v0 = mk3(na.x, na.y, nc.x), v1 = mk3(na.z, na.w, nc.y), v2 = mk3(nb.x, nb.y, nc.z);  // packed order
-                const float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
-                const float3_ s1 = cross3(d, e2);
-                const float det = dot3(s1, e1);
-                const float invd = 1.0f / det;
-                const float3_ dd = sub3(o, v0);
-                const float u = dot3(dd, s1) * invd;
-                const float3_ s2 = cross3(dd, e1);
-                const float v = dot3(d, s2) * invd;
-                const float t = dot3(e2, s2) * invd;
-                const bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || (u + v) > 1.0f) && !(t < tmin || t > closest_t);
-                closest_prim = hit ? node - n_level + 1u : closest_prim;  // leaf of sorted primitive j sits at n-1+j
-                closest_inst = hit ? cur_inst : closest_inst;
-                closest_t = hit ? t : closest_t;
-                cull_t = hit ? ((t != t) ? -INFINITY : t) : cull_t;
-                hit_u = hit ? u : hit_u;
-                hit_v = hit ? v : hit_v;
-                if (ANY && hit) node = RC_INVALID_NODE;  // :2106-2115
-                else node = st.pop(sp);
-            }
-        }
-        // ---- switch phase: return to the top level (:1996-2006) or enter an instance (:1961-1977)
-        {
-            const bool is_exit = node == RC_TOP_LEVEL_SENTINEL;
-            const bool is_entry = cur_inst < 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
-            if (STATS && __ballot(is_exit || is_entry)) { st_iter[3] += 1; st_lane[3] += (is_exit || is_entry) ? 1 : 0; }
-            if (is_exit) {
-                node = st.pop(sp);
-                cur_inst = -1;
-                cur_off = tlas_off; n_level = n_instances;
-                o = wo; d = wd; inv = winv;
-                ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-            } else if (is_entry) {
-                cur_inst = (int)(nodes + (cur_off + node - 1))->child1;
-                st.push(sp, RC_TOP_LEVEL_SENTINEL);
-                node = 1;
-                const float4* q = reinterpret_cast<const float4*>(a.v.inst + cur_inst);
-                const float4 m0 = q[0], m1 = q[1], m2 = q[2];
-                const uint4 m3 = *reinterpret_cast<const uint4*>(q + 3);
-                cur_off = m3.x;
-                n_level = m3.w;
-                o = mk3(m0.x * wo.x + m0.y * wo.y + m0.z * wo.z + m0.w, m1.x * wo.x + m1.y * wo.y + m1.z * wo.z + m1.w,
-                        m2.x * wo.x + m2.y * wo.y + m2.z * wo.z + m2.w);
-                d = mk3(m0.x * wd.x + m0.y * wd.y + m0.z * wd.z, m1.x * wd.x + m1.y * wd.y + m1.z * wd.z,
-                        m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
-                inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
-                ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-            }
-        }
-        // ---- finished lanes: write out; refill when enough lanes are free
-        {
-            const bool fin = live && node == RC_INVALID_NODE;
-            const int n_free = __popcll(__ballot(fin || !live));
-            const bool can_refill = !(exhausted && pool_next == pool_end);
-            if (n_free == 64 && !can_refill && !__ballot(fin)) break;
-            if (n_free >= a.refill || n_free == 64 || !can_refill) {
-                if (fin) {
-                    uint4 w0, w1;
-                    if (closest_inst >= 0) {  // :2010-2017
-                        const uint4 m3 = *(reinterpret_cast<const uint4*>(a.v.inst + closest_inst) + 3);
-                        w0 = make_uint4(1u, __float_as_uint(closest_t), m3.y + closest_prim - 1u, m3.z);
-                        w1 = make_uint4(__float_as_uint(hit_u), __float_as_uint(hit_v), (uint32_t)closest_inst, 0u);
-                    } else {  // :2018-2023
-                        w0 = make_uint4(0u, 0u, RC_INVALID_NODE, 0u);
-                        w1 = make_uint4(0u, 0u, RC_INVALID_NODE, 0u);
-                    }
-                    uint4* out = reinterpret_cast<uint4*>(a.hits + my_ray);
-                    out[0] = w0;
-                    out[1] = w1;
-                    live = false;
-                }
-                if (STATS) { st_iter[0] += 1; }
-                while (can_refill) {
-                    const unsigned long long free_mask = __ballot(!live);
-                    const int nf = __popcll(free_mask);
-                    if (nf == 0) break;
-                    if (pool_next == pool_end) {
-                        if (exhausted) break;
-                        unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)a.pool);
-                        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-                        unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-                        base = ((unsigned long long)hi << 32) | lo;
-                        if (base >= a.n_rays) { exhausted = true; break; }
-                        pool_next = base;
-                        pool_end = base + a.pool;
-                        if (pool_end >= a.n_rays) { pool_end = a.n_rays; exhausted = true; }
-                    }
-                    const unsigned long long left = pool_end - pool_next;
-                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)free_mask, 0u));
-                    if (!live && rank < left) {
-                        my_ray = pool_next + rank;
-                        const RcRay r = load_ray(a.rays, my_ray);
-                        wo = mk3(r.ox, r.oy, r.oz);  // init (:1904-1927); check_direction (src/ray.jl:39-49)
-                        wd = mk3(r.dx == 0.0f ? 0.0f : r.dx, r.dy == 0.0f ? 0.0f : r.dy, r.dz == 0.0f ? 0.0f : r.dz);
-                        winv = mk3(safe_inv1(wd.x), safe_inv1(wd.y), safe_inv1(wd.z));
-                        o = wo; d = wd; inv = winv;
-                        ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-                        tmin = ANY ? 0.0f : r.tmin;
-                        closest_t = r.tmax;
-                        cull_t = (r.tmax != r.tmax) ? -INFINITY : r.tmax;
-                        hit_u = hit_v = 0.0f;
-                        closest_prim = RC_INVALID_NODE;
-                        closest_inst = -1; cur_inst = -1;
-                        cur_off = tlas_off; n_level = n_instances;
-                        sp = 0;
-                        st.push(sp, RC_INVALID_NODE);
-                        node = 1;
-                        live = true;
-                    }
-                    pool_next += ((unsigned long long)nf < left) ? (unsigned long long)nf : left;
-                }
-            }
-        }
-    }
-    if (STATS) {
-        for (int k = 0; k < 4; ++k) {
-            if (lane == 0) atomicAdd(&a.stats[2 * k], st_iter[k]);
-            atomicAdd(&a.stats[2 * k + 1], st_lane[k]);
-        }
-    }
+    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats};
+    phased_trace<ANY, LDS_N, STATS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits});
 }
 
 }  // namespace
@@ -546,6 +353,19 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     v.overflow = s->overflow_stack.p; v.total_threads = total_threads;
     v.status = s->counters.p + 4;
     return v;
+}
+
+rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads) {
+    rc::PersistArgs p;
+    p.n_items = n_items;
+    p.work_counter = reinterpret_cast<unsigned long long*>(s->counters.p);
+    uint64_t per = n_items / ((uint64_t)(total_threads / 64) * 4);
+    per = (per / 64) * 64;
+    p.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : (per < 64 ? 64 : (per > 128 ? 128 : per)));
+    p.refill = (int)s->opt.refill;
+    p.int_thr = (int)s->opt.sched_thr;
+    p.stats = reinterpret_cast<unsigned long long*>(s->counters.p + 8);
+    return p;
 }
 
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items) {
