@@ -259,9 +259,15 @@ void rc_launch_ray_grid(rc_scene* s, const float viewdir[3], uint32_t grid, RcRa
     RC_HIP(hipGetLastError());
 }
 
+static void check_buffer_range(rc_scene* s) {
+    if ((uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32))
+        throw RcError(1, "driver kernels address nodes with 32-bit buffer offsets: scenes above 64 M nodes are not supported yet");
+}
+
 void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, uint64_t ray_begin, uint64_t ray_end,
                             float* d_counts, hipStream_t stream) {
     if (ray_end <= ray_begin) return;
+    check_buffer_range(s);
     GridParams g = grid_params(s, viewdir, grid);
     uint32_t blocks = rc_persistent_blocks(s, ray_end - ray_begin);
     rc_prepare_launch(s, stream);
@@ -279,6 +285,7 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     if (src_end > s->n_flat_prims) src_end = s->n_flat_prims;
     if (ray_end > rays_per_triangle) ray_end = rays_per_triangle;
     if (src_begin >= src_end || ray_begin >= ray_end) return;
+    check_buffer_range(s);
     uint64_t total = (uint64_t)(src_end - src_begin) * (ray_end - ray_begin);
     uint32_t blocks = rc_persistent_blocks(s, total);
     rc_prepare_launch(s, stream);

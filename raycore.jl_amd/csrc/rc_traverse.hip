@@ -349,7 +349,7 @@ void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     rc::SceneView v;
     v.tlas_nodes = s->tlas_nodes.p; v.blas_nodes = s->flat_nodes.p; v.inst = s->inst_recs.p; v.prims = s->flat_prims.p;
-    v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims; v.tlas_off = s->n_flat_nodes;
+    v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims; v.tlas_off = s->n_flat_nodes; v.n_nodes_total = s->n_flat_nodes + s->n_tlas_nodes; v.n_inst = s->n_static_instances;
     v.overflow = s->overflow_stack.p; v.total_threads = total_threads;
     v.status = s->counters.p + 4;
     return v;
@@ -423,7 +423,8 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.stats = reinterpret_cast<unsigned long long*>(s->counters.p + 8);
     RC_HIP(hipEventRecord(s->ev0, stream));
     const int64_t saved_kernel = s->opt.kernel;
-    if (saved_kernel < 0) s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : 3;  // auto: tiny batches gain nothing from refilling
+    if (saved_kernel < 0) s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : 3;
+    if (s->opt.kernel == 3 && (uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32)) s->opt.kernel = 1;  // buffer offsets are 32-bit  // auto: tiny batches gain nothing from refilling
     if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
     s->opt.kernel = saved_kernel;
     RC_HIP(hipEventRecord(s->ev1, stream));

@@ -20,6 +20,8 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
     uint32_t n_tlas_nodes;
     uint32_t n_prims;
     uint32_t tlas_off;        // a copy of the TLAS nodes sits at blas_nodes[tlas_off ...] (single-base addressing)
+    uint32_t n_nodes_total;   // BLAS + TLAS nodes in blas_nodes (sizes the buffer descriptor)
+    uint32_t n_inst;          // instance records
     uint32_t* overflow;       // [kTotalStack][total_threads] spill area of the lane stacks (entries below the LDS depth unused)
     uint32_t total_threads;
     uint32_t* status;         // [0] = stack overflow flag
@@ -260,6 +262,23 @@ struct HitWriter {
 // lanes (instance entry / return to top level) and the finished lanes (write-out + refill).  The inner loop
 // only touches {node, sp} so the compiler keeps the ray registers untouched across it.  Per-lane order of
 // visits, tests, pushes and pops is the reference's; only the interleaving between lanes differs.
+// Raw buffer loads (buffer_load_dwordx{1,2,4} ... offen): one wave-uniform descriptor per array in SGPRs and a 32-bit
+// per-lane byte offset, so a node address is one shift instead of 64-bit pointer arithmetic, every fetch has exactly the
+// width asked for, and an out-of-range offset reads 0 instead of faulting.  Arrays must stay below 4 GiB (64 M nodes).
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ inline float4 buf_f4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ inline float2 buf_f2(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    u2v v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+
 // `src(i)` produces work item i's ray (a ray array, or a generator: grid rays, view-factor samples); `sink(i, hit, t, u,
 // v, prim, inst)` consumes the result (prim = 1-based leaf primitive index inside the instance's BLAS as the reference
 // keeps it, inst = 0-based instance, -1 on a miss).
@@ -283,7 +302,8 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     }
     const uint32_t n_instances = (av.n_tlas_nodes + 1u) >> 1;
     const uint32_t tlas_off = av.tlas_off;
-    const RcNode* const nodes = av.blas_nodes;
+    const __amdgpu_buffer_rsrc_t nrs = make_rsrc(av.blas_nodes, av.n_nodes_total * 64u);
+    const __amdgpu_buffer_rsrc_t irs = make_rsrc(av.inst, av.n_inst * 64u);
     unsigned long long pool_next = 0, pool_end = 0;
     bool exhausted = false;
     uint64_t my_ray = 0;
@@ -304,9 +324,9 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             if (n_int == 0) break;
             if (STATS) { st_iter[1] += 1; st_lane[1] += is_int ? 1 : 0; }
             if (is_int) {
-                const float4* q = reinterpret_cast<const float4*>(nodes + (cur_off + node - 1));
-                const float4 na = q[0], nb = q[1], nc = q[2];
-                const uint2 ch = *reinterpret_cast<const uint2*>(q + 3);
+                const uint32_t off = (cur_off + node - 1u) << 6;
+                const float4 na = buf_f4(nrs, off), nb = buf_f4(nrs, off + 16), nc = buf_f4(nrs, off + 32);
+                const u2v ch = __builtin_amdgcn_raw_buffer_load_b64(nrs, off + 48, 0, 0);
                 // packed node (rc_pack_node): na = child-0 (min.x,min.y,max.x,max.y), nb = child-1 likewise, nc = z of both
                 const v2f ixy = {inv.x, inv.y}, oxy = {ox.x, ox.y}, izz = {inv.z, inv.z}, ozz = {ox.z, ox.z};
                 const v2f n0xy = v2f{na.x, na.y} * ixy + oxy, f0xy = v2f{na.z, na.w} * ixy + oxy;
@@ -332,11 +352,10 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             const bool is_leaf = cur_inst >= 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
             if (STATS && __ballot(is_leaf)) { st_iter[2] += 1; st_lane[2] += is_leaf ? 1 : 0; }
             if (is_leaf) {
-                const RcNode* np = nodes + (cur_off + node - 1);
-                const float4* q = reinterpret_cast<const float4*>(np);
-                const float4 na = q[0];
-                const float2 nb = *reinterpret_cast<const float2*>(q + 1);
-                const float4 nc = q[2];
+                const uint32_t off = (cur_off + node - 1u) << 6;
+                const float4 na = buf_f4(nrs, off);
+                const float2 nb = buf_f2(nrs, off + 16);
+                const float4 nc = buf_f4(nrs, off + 32);
                 const float3_ v0 = mk3(na.x, na.y, nc.x), v1 = mk3(na.z, na.w, nc.y), v2 = mk3(nb.x, nb.y, nc.z);  // packed order
                 const float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
                 const float3_ s1 = cross3(d, e2);
@@ -370,12 +389,12 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 o = wo; d = wd; inv = winv;
                 ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
             } else if (is_entry) {
-                cur_inst = (int)(nodes + (cur_off + node - 1))->child1;
+                cur_inst = (int)__builtin_amdgcn_raw_buffer_load_b32(nrs, ((cur_off + node - 1u) << 6) + 52u, 0, 0);  // child1
                 st.push(sp, RC_TOP_LEVEL_SENTINEL);
                 node = 1;
-                const float4* q = reinterpret_cast<const float4*>(av.inst + cur_inst);
-                const float4 m0 = q[0], m1 = q[1], m2 = q[2];
-                const uint4 m3 = *reinterpret_cast<const uint4*>(q + 3);
+                const uint32_t ioff = (uint32_t)cur_inst << 6;
+                const float4 m0 = buf_f4(irs, ioff), m1 = buf_f4(irs, ioff + 16), m2 = buf_f4(irs, ioff + 32);
+                const u4v m3 = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff + 48, 0, 0);
                 cur_off = m3.x;
                 n_level = m3.w;
                 o = mk3(m0.x * wo.x + m0.y * wo.y + m0.z * wo.z + m0.w, m1.x * wo.x + m1.y * wo.y + m1.z * wo.z + m1.w,
