@@ -15,8 +15,10 @@
  *    non-zero status into ErrorException (test/test_tlas_stress.jl:585-617 expects that type).
  *  - The caller owns every host buffer it passes.  The library owns all device memory behind the opaque
  *    rc_scene handle and frees it in rc_scene_destroy (replaces free!, src/instanced-bvh.jl:383-399).
- *  - Mutations (rc_add_*, rc_update_*, rc_delete, rc_sync) on one scene must be externally serialised;
- *    trace calls on a synced scene may run concurrently on distinct HIP streams.  No global mutable state.
+ *  - Mutations (rc_add_*, rc_update_*, rc_delete, rc_sync) on one scene must be externally serialised; device-pointer
+ *    trace / driver calls on a synced scene may be in flight on distinct HIP streams (each launch gets its own work
+ *    counter; the only shared scratch is the spill area used by traversal stacks deeper than 24 entries, so scenes with
+ *    such deep trees should keep their launches on one stream).  No global mutable state.
  *  - There is NO CPU fallback: every compute entry point runs hand-written gfx950 HIP kernels and fails
  *    with RC_ERR_NO_DEVICE when no GPU is present.
  *  - Index bases at this boundary are 0-based (C); the host wrappers add 1 where the Julia API is 1-based.

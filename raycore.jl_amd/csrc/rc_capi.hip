@@ -81,7 +81,7 @@ void require_synced(rc_scene* s) {
 
 void check_status(rc_scene* s, hipStream_t stream) {
     uint32_t st = 0;
-    RC_HIP(hipMemcpyAsync(&st, s->counters.p + 4, 4, hipMemcpyDeviceToHost, stream));
+    RC_HIP(hipMemcpyAsync(&st, rc_counter_slot(s) + 4, 4, hipMemcpyDeviceToHost, stream));
     RC_HIP(hipStreamSynchronize(stream));
     if (st) throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels)");
 }
@@ -439,7 +439,7 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
         unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipSetDevice(s->device);
         (void)hipDeviceSynchronize();
-        if (s->counters.p && hipMemcpy(st, s->counters.p + 8, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "stats read failed");
+        if (s->counters.p && hipMemcpy(st, rc_counter_slot(s) + 8, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "stats read failed");
         *value = (int64_t)st[k[4] - '0'];
     }
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);

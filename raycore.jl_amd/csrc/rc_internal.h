@@ -108,7 +108,8 @@ struct rc_scene {
     DevBuf<float> aabb_tmp;
     DevBuf<RcPrim> prim_tmp;
     DevBuf<uint32_t> overflow_stack;  // global spill area of the traversal stacks
-    DevBuf<uint32_t> counters;        // persistent-kernel work counters / status words
+    DevBuf<uint32_t> counters;        // 64 slots x 64 words: per-launch work counter [0..1], status [4], stats [8..]
+    uint64_t launch_seq = 0;
     DevBuf<RcRay> ray_stage;
     DevBuf<RcHit> hit_stage;
     DevBuf<float> f32_stage;
@@ -139,5 +140,6 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
 // rc_traverse.hip helpers shared with rc_drivers.hip
 namespace rc { struct SceneView; }
 void rc_prepare_launch(rc_scene* s, hipStream_t stream);
+inline uint32_t* rc_counter_slot(rc_scene* s) { return s->counters.p + (s->launch_seq % 64) * 64; }  // slot of the most recent launch
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items);
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream);

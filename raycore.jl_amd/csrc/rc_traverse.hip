@@ -342,8 +342,11 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
 // grid: n_cus x 8 blocks) and the counter / status words, zeroed on the launch stream.
 void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
     s->overflow_stack.reserve((size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock);
-    s->counters.reserve(64);
-    RC_HIP(hipMemsetAsync(s->counters.p, 0, 64 * sizeof(uint32_t), stream));
+    // one 256-byte slot of counter / status words per launch, rotated over 64 slots, so launches of one scene that
+    // are in flight on different streams never share a work counter
+    s->counters.reserve(64 * 64);
+    s->launch_seq += 1;
+    RC_HIP(hipMemsetAsync(rc_counter_slot(s), 0, 64 * sizeof(uint32_t), stream));
 }
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
@@ -351,20 +354,20 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     v.tlas_nodes = s->tlas_nodes.p; v.blas_nodes = s->flat_nodes.p; v.inst = s->inst_recs.p; v.prims = s->flat_prims.p;
     v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims; v.tlas_off = s->n_flat_nodes; v.n_nodes_total = s->n_flat_nodes + s->n_tlas_nodes; v.n_inst = s->n_static_instances;
     v.overflow = s->overflow_stack.p; v.total_threads = total_threads;
-    v.status = s->counters.p + 4;
+    v.status = rc_counter_slot(s) + 4;
     return v;
 }
 
 rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads) {
     rc::PersistArgs p;
     p.n_items = n_items;
-    p.work_counter = reinterpret_cast<unsigned long long*>(s->counters.p);
+    p.work_counter = reinterpret_cast<unsigned long long*>(rc_counter_slot(s));
     uint64_t per = n_items / ((uint64_t)(total_threads / 64) * 4);
     per = (per / 64) * 64;
     p.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : (per < 64 ? 64 : (per > 128 ? 128 : per)));
     p.refill = (int)s->opt.refill;
     p.int_thr = (int)s->opt.sched_thr;
-    p.stats = reinterpret_cast<unsigned long long*>(s->counters.p + 8);
+    p.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
     return p;
 }
 
@@ -412,7 +415,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     TraceArgs a;
     a.v = rc_scene_view(s, total_threads);
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
-    a.work_counter = reinterpret_cast<unsigned long long*>(s->counters.p);
+    a.work_counter = reinterpret_cast<unsigned long long*>(rc_counter_slot(s));
     a.refill = (int)s->opt.refill;
     {
         uint64_t per = n / ((uint64_t)(total_threads / 64) * 4);
@@ -420,7 +423,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
         a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : (per < 64 ? 64 : (per > 128 ? 128 : per)));
     }
     a.sched_thr = (int)s->opt.sched_thr;
-    a.stats = reinterpret_cast<unsigned long long*>(s->counters.p + 8);
+    a.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
     RC_HIP(hipEventRecord(s->ev0, stream));
     const int64_t saved_kernel = s->opt.kernel;
     if (saved_kernel < 0) s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : 3;

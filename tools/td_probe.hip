@@ -21,6 +21,23 @@ __global__ __launch_bounds__(256) void k_gather(const float4* table, unsigned ma
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// quad-cooperative pattern: lane k of each quad loads chunk k of the quad's j-th record (j = 0..3), so every
+// instruction reads one contiguous 64-byte record per quad instead of four scattered 16-byte chunks.
+__global__ __launch_bounds__(256) void k_gather_quad(const float4* table, unsigned mask, int iters, float* out) {
+    const int lane = threadIdx.x & 63, k = lane & 3, quad = (blockIdx.x * 256 + threadIdx.x) >> 2;
+    unsigned idx = quad * 2654435761u;
+    float acc = 0.f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            idx = idx * 1664525u + 1013904223u;   // same value in the 4 lanes of a quad
+            float4 v = table[((idx >> 8) & mask) * 4 + k];
+            acc += v.x + v.w;
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(1024) void k_gather_lds(const float4* table, unsigned mask, int active, int iters, float* out) {
     extern __shared__ float4 cache[];
     for (unsigned i = threadIdx.x; i < (mask + 1) * 4; i += 1024) cache[i] = table[i];
@@ -59,6 +76,17 @@ int main() {
             printf("global table %6u KB active %2d: %.3f ms  -> %.1f clk/CU per load instr, %.1f GB/s useful\n", (mask + 1) / 16, active, ms,
                    ms * 1e-3 * 2.1e9 * 256 / insts, waves * iters * active * 64.0 / (ms * 1e-3) / 1e9);
         }
+    }
+    for (unsigned mask : masks) {
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_gather_quad, dim3(256 * 6), dim3(256), 0, 0, table, mask, iters, out);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        }
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double waves = 256.0 * 6 * 4, insts = waves * iters * 4;
+        printf("quad-cooperative table %6u KB: %.3f ms -> %.1f clk/CU per load instr, %.1f GB/s useful\n", (mask + 1) / 16, ms,
+               ms * 1e-3 * 2.1e9 * 256 / insts, waves * iters * 64 * 64.0 / (ms * 1e-3) / 1e9);
     }
     for (int active : {64, 32, 16, 8}) {
         for (int rep = 0; rep < 2; ++rep) {
