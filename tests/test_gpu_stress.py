@@ -1,0 +1,153 @@
+"""Lifecycle stress tests restated from the reference's test/test_tlas_stress.jl against the C ABI (GPU)."""
+import numpy as np
+import pytest
+
+from helpers import assert_hits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rc():
+    import raycore_jl_amd
+    assert raycore_jl_amd.device_count() > 0
+    return raycore_jl_amd
+
+
+def xlat(x, y, z):
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 3] = [x, y, z]
+    return m
+
+
+def test_200_blases_alive_then_delete_every_other(rc):  # test/test_tlas_stress.jl:187-227
+    t = rc.TLAS()
+    n_blas, spacing = 200, 4.0
+    handles = []
+    for i in range(1, n_blas + 1):
+        n = 4 + (i % 6)
+        handles.append(t.push(rc.scenes.fan_sphere(2 * n, n, radius=1.0), xlat(i * spacing, 0, 0)))
+    t.sync()
+    assert t.n_geometries() == n_blas and t.n_instances() == n_blas
+    o = np.array([[i * spacing, 0, 5] for i in range(1, n_blas + 1)], dtype=np.float32)
+    h = t.trace(rc.scenes.make_rays(o, [0, 0, -1]))
+    assert np.all(h["hit"] == 1) and np.all(np.abs(h["t"] - 4.0) < 0.1)
+    for i, hd in enumerate(handles, start=1):
+        if i % 2 == 0:
+            assert t.delete(hd)
+    t.sync()
+    assert t.n_geometries() == n_blas // 2 and t.n_instances() == n_blas // 2
+    h2 = t.trace(rc.scenes.make_rays(o, [0, 0, -1]))
+    assert list(h2["hit"]) == [i % 2 for i in range(1, n_blas + 1)]
+    # compaction: blas_index values are dense 1..n_geometries and instance order follows handle order
+    inst = t.adapt().instances
+    assert sorted(set(inst["blas_index"].tolist())) == list(range(1, n_blas // 2 + 1))
+
+
+def test_5000_instances_refit_keeps_topology(rc, oracle):  # test/test_tlas_stress.jl:233-273
+    sc = rc.scenes
+    g = sc.rng(9)
+    pos = g.uniform(-50, 50, size=(5000, 3))
+    xf = np.tile(sc.IDENTITY3x4, (5000, 1)).astype(np.float32)
+    xf[:, [3, 7, 11]] = pos
+    t = rc.TLAS()
+    h = t.push(sc.fan_sphere(8, 5, radius=0.4), xf)
+    t.sync()
+    assert t.n_instances() == 5000 and len(t.adapt().nodes) == 9999
+    topo = t.adapt().nodes[["child0", "child1", "parent"]].copy()
+    for it in range(3):
+        xf[:, 3] += 0.25
+        t.update_transforms(h, xf)
+        t.sync()
+        assert t.last_sync_action == "refit"
+        assert np.array_equal(t.adapt().nodes[["child0", "child1", "parent"]], topo)
+    o = oracle.Scene()
+    b = o.add_blas(sc.fan_sphere(8, 5, radius=0.4))
+    for x in xf:
+        o.add_instance(b, x, 0)
+    o.build()
+    # a refit tree has the old topology but the new boxes: hits must equal a fresh build's (closest hit is unique here)
+    rays = sc.make_rays(pos[:2000] + [0, 0, 5] + [0.75, 0, 0], [0, 0, -1])
+    got, want = t.trace(rays), o.trace(rays, nthreads=8)
+    assert np.array_equal(got["hit"], want["hit"]) and got["hit"].mean() > 0.9
+    m = got["hit"] == 1
+    assert np.array_equal(got["t"][m].view(np.uint32), want["t"][m].view(np.uint32))
+    assert np.array_equal(got["instance_id"][m], want["instance_id"][m])
+
+
+def test_random_churn_matches_model(rc, oracle):  # test/test_tlas_stress.jl:101-181 (invariants), checked against the oracle
+    sc = rc.scenes
+    g = sc.rng(2024)
+    meshes = [sc.fan_sphere(8, 5, radius=0.5), sc.random_triangles(60, 3, lo=-0.5, hi=0.5, edge=0.3), sc.fan_sphere(12, 7, radius=0.3)]
+    t = rc.TLAS()
+    live = {}  # handle -> (mesh_idx, xforms, ids)
+    deleted = []
+    for op in range(160):
+        r = g.uniform()
+        if r < 0.45 or not live:
+            k = int(g.integers(1, 4))
+            xf = np.tile(sc.IDENTITY3x4, (k, 1)).astype(np.float32)
+            xf[:, [3, 7, 11]] = g.uniform(-4, 4, size=(k, 3))
+            mi = int(g.integers(0, len(meshes)))
+            ids = g.integers(0, 1000, size=k).astype(np.uint32)
+            h = t.push(meshes[mi], xf, instance_ids=ids)
+            live[h] = [mi, xf, ids]
+        elif r < 0.65:
+            h = list(live)[int(g.integers(0, len(live)))]
+            assert t.delete(h) and not t.delete(h)
+            deleted.append(h)
+            del live[h]
+        elif r < 0.85:
+            h = list(live)[int(g.integers(0, len(live)))]
+            xf = live[h][1].copy()
+            xf[:, [3, 7, 11]] += g.uniform(-0.5, 0.5, size=(len(xf), 3)).astype(np.float32)
+            t.update_transforms(h, xf)
+            live[h][1] = xf
+        else:
+            h = list(live)[int(g.integers(0, len(live)))]
+            mi = int(g.integers(0, len(meshes)))
+            t.update(h, meshes[mi])
+            live[h][0] = mi
+        if op % 8 == 7 or op == 159:
+            t.sync()
+            assert t.sync().last_sync_action == "noop"
+            assert t.n_instances() == sum(len(v[1]) for v in live.values()) == t.n_total_instances()
+            assert all(t.is_valid(h) for h in live) and not any(t.is_valid(h) for h in deleted)
+            for h in deleted[-3:]:
+                with pytest.raises(rc.RaycoreError):
+                    t.update_transforms(h, np.eye(4, dtype=np.float32)[None])
+            # model: surviving handles in ascending id order; one BLAS per live handle that still references it
+            o = oracle.Scene()
+            for h in sorted(live, key=lambda x: x.id):
+                mi, xf, ids = live[h]
+                b = o.add_blas(meshes[mi])
+                for x, i in zip(xf, ids):
+                    o.add_instance(b, x, int(i))
+            o.build()
+            if live:
+                st = t.adapt()
+                assert st.instances[["instance_id", "transform", "inv_transform"]].tobytes() == o.instances[["instance_id", "transform", "inv_transform"]].tobytes()
+                wb = o.world_bound
+                rays = sc.make_rays(g.uniform(wb[:3] - 1, wb[3:] + 1, size=(3000, 3)), sc.normalize(g.normal(size=(3000, 3))))
+                got, want = t.trace(rays), o.trace(rays, nthreads=4)
+                for f in ("hit", "instance_id", "instance_custom_index"):
+                    assert np.array_equal(got[f], want[f]), (op, f)
+                m = got["hit"] == 1
+                assert np.array_equal(got["t"][m].view(np.uint32), want["t"][m].view(np.uint32))
+            else:
+                assert t.n_geometries() == 0
+                assert not t.trace(sc.make_rays([[0, 0, 5]], [0, 0, -1]))["hit"][0]
+
+
+def test_grow_and_shrink(rc):  # test/test_tlas_stress.jl:517-548
+    t = rc.TLAS()
+    base = rc.scenes.fan_sphere(6, 4, radius=0.4)
+    hs = []
+    for it in range(60):
+        hs.append(t.push(base, xlat(it, 0, 0)))
+        if it % 3 == 2:
+            t.delete(hs.pop(0))
+        t.sync()
+        assert t.n_instances() == len(hs) == t.n_geometries()
+    o = np.array([[t.get_instance(h)["transform"][3], 0, 5] for h in hs], dtype=np.float32)
+    assert np.all(t.trace(rc.scenes.make_rays(o, [0, 0, -1]))["hit"] == 1)
