@@ -198,6 +198,19 @@ int rc_view_factors(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, 
 int rc_view_factor_rays_device(rc_scene* scene, uint64_t seed, uint32_t src_prim, uint32_t ray_begin, uint32_t n_rays,
                                rc_ray* d_rays, void* stream);
 
+/* Wavefront stages next to the trace (the reference's fastest renderer is a wavefront pipeline around closest_hit /
+ * any_hit, docs/src/wavefront-renderer.jl:260-362).  All buffers are device pointers; slot i belongs to ray i.
+ * rc_hit_points_device: hit_point = ray.o + ray.d * t (:302) and the geometric world-space normal of the hit primitive
+ * (normalize(cross(v1-v0, v2-v0)) through the instance's inverse-transpose, flipped to face the ray origin); zeros on a
+ * miss.  d_points / d_normals: n x 3 f32, d_normals may be NULL.
+ * rc_shadow_rays_device: generate_shadow_rays! for one point light (:288-333): origin = hit_point + normal * bias,
+ * direction = normalize(light - origin), t_max = distance; misses get the reference's dummy ray (d = (0,0,1), t_max = 0).
+ * The output feeds rc_trace_any_device unchanged. */
+int rc_hit_points_device(rc_scene* scene, const rc_ray* d_rays, const rc_hit* d_hits, uint64_t n, float* d_points,
+                         float* d_normals, void* stream);
+int rc_shadow_rays_device(rc_scene* scene, const rc_ray* d_rays, const rc_hit* d_hits, uint64_t n, const float light[3],
+                          float bias, rc_ray* d_shadow_rays, void* stream);
+
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);

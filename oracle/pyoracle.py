@@ -82,6 +82,8 @@ def lib():
         L.rco_get_illumination.argtypes = [vp, vp, u32, vp, C.c_int]
         L.rco_view_factors.argtypes = [vp, u32, u64, u32, u32, u32, u32, vp, C.c_int]
         L.rco_view_factor_ray.argtypes = [vp, u32, u32, u64, vp]
+        L.rco_hit_points.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.rco_shadow_rays.argtypes = [vp, vp, vp, u64, vp, C.c_float, vp]
         _lib = L
     return _lib
 
@@ -196,6 +198,16 @@ class Scene:
         s0, s1 = (0, n) if src is None else src
         r0, r1 = (0, rays_per_triangle) if rays is None else rays
         lib().rco_view_factors(self._h, rays_per_triangle, seed, s0, s1, r0, r1, _p(out), nthreads)
+        return out
+
+    def hit_points(self, rays, hits):
+        pts, nrm = np.zeros((len(rays), 3), np.float32), np.zeros((len(rays), 3), np.float32)
+        lib().rco_hit_points(self._h, _p(np.ascontiguousarray(rays)), _p(np.ascontiguousarray(hits)), len(rays), _p(pts), _p(nrm))
+        return pts, nrm
+
+    def shadow_rays(self, rays, hits, light, bias=0.01):
+        out = np.zeros(len(rays), dtype=RAY_DT)
+        lib().rco_shadow_rays(self._h, _p(np.ascontiguousarray(rays)), _p(np.ascontiguousarray(hits)), len(rays), _p(_f32(light)), bias, _p(out))
         return out
 
     def view_factor_ray(self, src_idx0, ray_idx, seed=0):

@@ -874,3 +874,42 @@ void rco_view_factors(const rco_scene* s, uint32_t rpt, uint64_t seed, uint32_t 
     vf_ctx c = {s, rpt, seed, src_begin, ray_begin, ray_end, out};
     parallel_for(src_end - src_begin, nthreads, vf_range, &c);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Wavefront stages next to the trace (docs/src/wavefront-renderer.jl:296-333): hit point, geometric world normal,
+ * shadow rays toward one point light.  Same expression order as the product's stage kernels.
+ * ---------------------------------------------------------------------------------------------- */
+static void hit_frame(const rco_scene* s, const rco_ray* r, const rco_hit* h, v3* point, v3* normal) {
+    *point = v3_add(V(r->ox, r->oy, r->oz), v3_scale(V(r->dx, r->dy, r->dz), h->t));
+    const rco_tri* tri = &s->blas_prims[h->primitive_id];
+    v3 v0 = v3_from(tri->v[0]), v1 = v3_from(tri->v[1]), v2 = v3_from(tri->v[2]);
+    v3 nl = v3_cross(v3_sub(v1, v0), v3_sub(v2, v0));
+    const float* m = s->inst[h->instance_id].inv_transform;
+    v3 nw = V(m[0] * nl.x + m[4] * nl.y + m[8] * nl.z, m[1] * nl.x + m[5] * nl.y + m[9] * nl.z, m[2] * nl.x + m[6] * nl.y + m[10] * nl.z);
+    nw = v3_normalize(nw);
+    if (v3_dot(nw, V(r->dx, r->dy, r->dz)) > 0.0f) nw = V(-nw.x, -nw.y, -nw.z);
+    *normal = nw;
+}
+void rco_hit_points(const rco_scene* s, const rco_ray* rays, const rco_hit* hits, uint64_t n, float* points, float* normals) {
+    for (uint64_t i = 0; i < n; ++i) {
+        v3 p = V(0, 0, 0), nn = V(0, 0, 0);
+        if (hits[i].hit) hit_frame(s, &rays[i], &hits[i], &p, &nn);
+        v3_store(points + 3 * i, p);
+        if (normals) v3_store(normals + 3 * i, nn);
+    }
+}
+void rco_shadow_rays(const rco_scene* s, const rco_ray* rays, const rco_hit* hits, uint64_t n, const float light[3], float bias, rco_ray* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        rco_ray sr = {0, 0, 0, 0, 0, 0, 1, 0};
+        if (hits[i].hit) {
+            v3 p, nn;
+            hit_frame(s, &rays[i], &hits[i], &p, &nn);
+            v3 o = v3_add(p, v3_scale(nn, bias));
+            v3 lv = v3_sub(v3_from(light), o);
+            float dist = sqrtf(v3_dot(lv, lv));
+            sr.ox = o.x; sr.oy = o.y; sr.oz = o.z; sr.tmin = 0.0f;
+            sr.dx = lv.x / dist; sr.dy = lv.y / dist; sr.dz = lv.z / dist; sr.tmax = dist;
+        }
+        out[i] = sr;
+    }
+}

@@ -140,6 +140,10 @@ void rco_view_factors(const rco_scene*, uint32_t rays_per_triangle, uint64_t see
 /* The ray view_factors shoots for (src prim idx0, ray_idx): exposed so ray generation can be checked. */
 int rco_view_factor_ray(const rco_scene*, uint32_t src_idx0, uint32_t ray_idx, uint64_t seed, rco_ray* out);
 
+/* wavefront stages next to the trace (docs/src/wavefront-renderer.jl:296-333); points/normals: n x 3 floats */
+void rco_hit_points(const rco_scene*, const rco_ray* rays, const rco_hit* hits, uint64_t n, float* points, float* normals);
+void rco_shadow_rays(const rco_scene*, const rco_ray* rays, const rco_hit* hits, uint64_t n, const float light[3], float bias, rco_ray* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ SYMBOLS = [
     ("rc_view_factors_device", _int, [_vp, _u32, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _u64, _u32, _u32, _vp]),
     ("rc_view_factors", _int, [_vp, _u32, _u64, _vp]),
     ("rc_view_factor_rays_device", _int, [_vp, _u64, _u32, _u32, _u32, _vp, _vp]),
+    ("rc_hit_points_device", _int, [_vp, _vp, _vp, _u64, _vp, _vp, _vp]),
+    ("rc_shadow_rays_device", _int, [_vp, _vp, _vp, _u64, _vp, C.c_float, _vp, _vp]),
     ("rc_last_kernel_ms", _int, [_vp, _pf]),
 ]
 

@@ -280,6 +280,16 @@ class TLAS:
         fn = lib().rc_trace_closest_device if mode == "closest" else lib().rc_trace_any_device
         check(fn(self._h, ptr(d_rays), ptr(d_hits), int(n), ptr(stream) if stream else None))
 
+    def hit_points_device(self, d_rays, d_hits, n, d_points, d_normals=None, stream=None):
+        check(lib().rc_hit_points_device(self._h, ptr(d_rays), ptr(d_hits), int(n), ptr(d_points), ptr(d_normals) if d_normals else None,
+                                         ptr(stream) if stream else None))
+
+    def shadow_rays_device(self, d_rays, d_hits, n, light, d_shadow_rays, bias=0.01, stream=None):
+        """generate_shadow_rays! for one point light (docs/src/wavefront-renderer.jl:288-333); output feeds trace_device(mode='any')."""
+        lv = np.ascontiguousarray(light, dtype=np.float32)
+        check(lib().rc_shadow_rays_device(self._h, ptr(d_rays), ptr(d_hits), int(n), ptr(lv), float(bias), ptr(d_shadow_rays),
+                                          ptr(stream) if stream else None))
+
     def last_kernel_ms(self):
         ms = C.c_float()
         check(lib().rc_last_kernel_ms(self._h, C.byref(ms)))

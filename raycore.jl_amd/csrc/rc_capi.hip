@@ -518,6 +518,24 @@ int rc_view_factor_rays_device(rc_scene* s, uint64_t seed, uint32_t src_prim, ui
     });
 }
 
+int rc_hit_points_device(rc_scene* s, const rc_ray* d_rays, const rc_hit* d_hits, uint64_t n, float* d_points, float* d_normals, void* stream) {
+    if (!s || !d_rays || !d_hits || !d_points) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        rc_launch_hit_points(s, reinterpret_cast<const RcRay*>(d_rays), reinterpret_cast<const RcHit*>(d_hits), n, d_points, d_normals, (hipStream_t)stream);
+    });
+}
+
+int rc_shadow_rays_device(rc_scene* s, const rc_ray* d_rays, const rc_hit* d_hits, uint64_t n, const float light[3], float bias, rc_ray* d_shadow_rays, void* stream) {
+    if (!s || !d_rays || !d_hits || !light || !d_shadow_rays) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        rc_launch_shadow_rays(s, reinterpret_cast<const RcRay*>(d_rays), reinterpret_cast<const RcHit*>(d_hits), n, light, bias, reinterpret_cast<RcRay*>(d_shadow_rays), (hipStream_t)stream);
+    });
+}
+
 int rc_last_kernel_ms(rc_scene* s, float* ms) {
     if (!s || !ms) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {

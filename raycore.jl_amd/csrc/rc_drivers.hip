@@ -122,7 +122,7 @@ __device__ inline double acos_f64(double x) {  // 0 <= x < 1
         return pio2_hi - (x - (pio2_lo - x * r));
     }
     double z = (1.0 - x) * 0.5;
-    double s = __dsqrt_rn(z);
+    double s = __builtin_sqrt(z);  // IEEE f64 square root
     double df = __longlong_as_double(__double_as_longlong(s) & 0xFFFFFFFF00000000ll);
     double c = (z - df * df) / (s + df);
     double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
@@ -132,10 +132,12 @@ __device__ inline double acos_f64(double x) {  // 0 <= x < 1
     return 2.0 * (df + w);
 }
 
-// norm(a) = sqrt(dot(a,a)); normalize(a) = a ./ norm(a) (GeometryBasics 0.5 fixed_arrays)
+// norm(a) = sqrt(dot(a,a)); normalize(a) = a ./ norm(a) (GeometryBasics 0.5 fixed_arrays).
+// sqrtf and / are the IEEE correctly-rounded forms here (-fhip-fp32-correctly-rounded-divide-sqrt); HIP's __fsqrt_rn is
+// the NATIVE (approximate) square root unless OCML_BASIC_ROUNDED_OPERATIONS is defined, so it is not used.
 __device__ inline float3_ normalize3(float3_ a) {
-    float n = __fsqrt_rn(dot3(a, a));
-    return mk3(__fdiv_rn(a.x, n), __fdiv_rn(a.y, n), __fdiv_rn(a.z, n));
+    float n = __builtin_sqrtf(dot3(a, a));
+    return mk3((a.x / n), (a.y / n), (a.z / n));
 }
 
 // The ray view_factors! shoots for (source primitive, ray index) (:83-92 + src/math.jl:125-174)
@@ -155,7 +157,7 @@ __device__ inline RcRay view_factor_ray(const RcPrim& tri, uint32_t src, uint32_
     philox4x32_10(ray_idx, src, 0u, 0u, k0, k1, rnd);
     float r1 = u32_to_unit(rnd[0]), r2 = u32_to_unit(rnd[1]), xi1 = u32_to_unit(rnd[2]), xi2 = u32_to_unit(rnd[3]);
     // random_triangle_point (src/math.jl:158-174)
-    float sqrt_r1 = __fsqrt_rn(r1);
+    float sqrt_r1 = __builtin_sqrtf(r1);
     float wu = 1.0f - sqrt_r1, wv = sqrt_r1 * (1.0f - r2), ww = sqrt_r1 * r2;
     float3_ pt = add3(add3(scale3(p1, wu), scale3(p2, wv)), scale3(p3, ww));
     float3_ o = add3(pt, scale3(normal, 0.01f));  // :91
@@ -208,6 +210,52 @@ __global__ __launch_bounds__(kBlock, 6) void k_view_factors(SceneView v, Persist
 __global__ void k_view_factor_rays(SceneView v, uint32_t k0, uint32_t k1, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_ray) out[i] = view_factor_ray(v.prims[src], src, ray_begin + i, k0, k1);
+}
+
+// ---- wavefront stages adjacent to the trace (docs/src/wavefront-renderer.jl:296-333) ---------
+// Geometric world-space normal of a hit: normalize(cross(v1-v0, v2-v0)) of the hit primitive carried through the
+// instance's inverse-transpose, flipped to face the ray origin.
+__device__ inline void hit_frame(const SceneView& v, const RcRay& r, const RcHit& h, float3_& point, float3_& normal) {
+    point = add3(mk3(r.ox, r.oy, r.oz), scale3(mk3(r.dx, r.dy, r.dz), h.t));  // hit_point = ray.o + ray.d * dist (:302)
+    const RcPrim tri = v.prims[h.primitive_id];
+    const float3_ v0 = mk3(tri.v[0], tri.v[1], tri.v[2]), v1 = mk3(tri.v[3], tri.v[4], tri.v[5]), v2 = mk3(tri.v[6], tri.v[7], tri.v[8]);
+    const float3_ nl = cross3(sub3(v1, v0), sub3(v2, v0));
+    const float* m = v.inst[h.instance_id].inv;  // n_w = transpose(inv 3x3) * n_l
+    float3_ nw = mk3(m[0] * nl.x + m[4] * nl.y + m[8] * nl.z, m[1] * nl.x + m[5] * nl.y + m[9] * nl.z, m[2] * nl.x + m[6] * nl.y + m[10] * nl.z);
+    nw = normalize3(nw);
+    if (dot3(nw, mk3(r.dx, r.dy, r.dz)) > 0.0f) nw = mk3(-nw.x, -nw.y, -nw.z);
+    normal = nw;
+}
+
+__global__ void k_hit_points(SceneView v, const RcRay* rays, const RcHit* hits, uint64_t n, float* points, float* normals) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        float3_ p = mk3(0, 0, 0), nn = mk3(0, 0, 0);
+        const RcHit h = hits[i];
+        if (h.hit) hit_frame(v, rays[i], h, p, nn);
+        points[3 * i] = p.x; points[3 * i + 1] = p.y; points[3 * i + 2] = p.z;
+        if (normals) { normals[3 * i] = nn.x; normals[3 * i + 1] = nn.y; normals[3 * i + 2] = nn.z; }
+    }
+}
+
+// generate_shadow_rays! for one point light (:288-333): slot i of the output belongs to ray i; misses get the
+// reference's dummy ray (o = 0, d = (0,0,1), t_max = 0), hits a ray from hit_point + normal*bias toward the light with
+// t_max = distance, ready for rc_trace_any_device.
+__global__ void k_shadow_rays(SceneView v, const RcRay* rays, const RcHit* hits, uint64_t n, float lx, float ly, float lz, float bias, RcRay* out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        RcRay s{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+        const RcHit h = hits[i];
+        if (h.hit) {
+            float3_ p, nn;
+            hit_frame(v, rays[i], h, p, nn);
+            const float3_ o = add3(p, scale3(nn, bias));
+            const float3_ lv = sub3(mk3(lx, ly, lz), o);
+            const float dist = __builtin_sqrtf(dot3(lv, lv));
+            s = RcRay{o.x, o.y, o.z, 0.f, (lv.x / dist), (lv.y / dist), (lv.z / dist), dist};
+        }
+        float4* q = reinterpret_cast<float4*>(out + i);
+        q[0] = make_float4(s.ox, s.oy, s.oz, s.tmin);
+        q[1] = make_float4(s.dx, s.dy, s.dz, s.tmax);
+    }
 }
 
 float3_ h_normalize(float3_ a) {
@@ -302,5 +350,19 @@ void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32
     if (n_ray == 0) return;
     SceneView v = rc_scene_view(s, 0);
     hipLaunchKernelGGL(k_view_factor_rays, dim3((n_ray + 255) / 256), dim3(256), 0, stream, v, (uint32_t)seed, (uint32_t)(seed >> 32), src, ray_begin, n_ray, d_out);
+    RC_HIP(hipGetLastError());
+}
+
+void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float* d_points, float* d_normals, hipStream_t stream) {
+    if (n == 0) return;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cus * 8);
+    hipLaunchKernelGGL(k_hit_points, dim3(blocks), dim3(256), 0, stream, rc_scene_view(s, 0), d_rays, d_hits, n, d_points, d_normals);
+    RC_HIP(hipGetLastError());
+}
+
+void rc_launch_shadow_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, const float light[3], float bias, RcRay* d_out, hipStream_t stream) {
+    if (n == 0) return;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cus * 8);
+    hipLaunchKernelGGL(k_shadow_rays, dim3(blocks), dim3(256), 0, stream, rc_scene_view(s, 0), d_rays, d_hits, n, light[0], light[1], light[2], bias, d_out);
     RC_HIP(hipGetLastError());
 }

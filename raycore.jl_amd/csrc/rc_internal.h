@@ -143,3 +143,5 @@ void rc_prepare_launch(rc_scene* s, hipStream_t stream);
 inline uint32_t* rc_counter_slot(rc_scene* s) { return s->counters.p + (s->launch_seq % 64) * 64; }  // slot of the most recent launch
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items);
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream);
+void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float* d_points, float* d_normals, hipStream_t stream);
+void rc_launch_shadow_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, const float light[3], float bias, RcRay* d_out, hipStream_t stream);

@@ -267,6 +267,25 @@ def test_ray_grid_and_illumination_parity(rc, oracle):
         assert got.sum() == np.count_nonzero(metas <= len(got))  # metadata outside 1..N is dropped (src/kernels.jl:123)
 
 
+def test_view_factor_rays_bit_exact(rc, oracle):
+    """The sampled rays themselves (Philox -> triangle point -> hemisphere direction, src/kernels.jl:83-92,
+    src/math.jl:125-174) are bit-identical on device and oracle, not just the counted matrices."""
+    import torch
+    from raycore_jl_amd._capi import check, lib, ptr
+    sc = rc.scenes
+    verts = np.concatenate([sc.fan_sphere(12, 7, centre=(0.3, -0.2, 0.1), radius=0.5), sc.random_triangles(300, 4, lo=-1, hi=1, edge=0.3)])
+    cfg = {"blas": [(verts, np.arange(1, len(verts) + 1, dtype=np.uint32))], "instances": [(1, sc.IDENTITY3x4[None], np.zeros(1, np.uint32))]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    n_ray = 512
+    buf = torch.empty(n_ray * 32, dtype=torch.uint8, device="cuda")
+    for src in (0, 1, 17, 100, len(verts) - 1):
+        check(lib().rc_view_factor_rays_device(t._h, 99, src, 5, n_ray, ptr(buf.data_ptr()), None))
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy().view(rc.RAY_DT)
+        want = np.array([o.view_factor_ray(src, 5 + i, seed=99) for i in range(n_ray)], dtype=rc.RAY_DT)
+        assert got.tobytes() == want.tobytes(), src
+
+
 def test_view_factors_parity(rc, oracle):
     sc = rc.scenes
     verts = np.concatenate([sc.fan_sphere(12, 7, centre=(0, 0, 0), radius=0.5), sc.box_room((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5), 2)])
@@ -297,6 +316,37 @@ def test_view_factors_parity(rc, oracle):
     il = rd.get_illumination_distributed(t, [0.3, 0.2, 1.0], 128)
     torch.cuda.synchronize()
     assert np.array_equal(il.cpu().numpy(), rc.get_illumination(t, [0.3, 0.2, 1.0], 128))
+
+
+def test_wavefront_stages(rc, oracle):
+    """primary trace -> hit points / normals -> shadow rays -> any_hit, all on device buffers, vs the oracle's stages."""
+    import torch
+    cfg = rc.scenes.config_c3()
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    rays = rc.scenes.c3_primary_rays(cfg, 256, 256)
+    n = len(rays)
+    d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+    d_hits = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+    d_shadow = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+    d_occ = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+    d_pts, d_nrm = torch.empty(n * 3, dtype=torch.float32, device="cuda"), torch.empty(n * 3, dtype=torch.float32, device="cuda")
+    light = cfg["light"].astype(np.float32)
+    t.trace_device(d_rays.data_ptr(), d_hits.data_ptr(), n)
+    t.hit_points_device(d_rays.data_ptr(), d_hits.data_ptr(), n, d_pts.data_ptr(), d_nrm.data_ptr())
+    t.shadow_rays_device(d_rays.data_ptr(), d_hits.data_ptr(), n, light, d_shadow.data_ptr(), bias=0.01)
+    t.trace_device(d_shadow.data_ptr(), d_occ.data_ptr(), n, mode="any")
+    torch.cuda.synchronize()
+    hits = o.trace(rays, nthreads=8)
+    assert_hits_equal(d_hits.cpu().numpy().view(rc.HIT_DT), hits, "stage primary")
+    pts, nrm = o.hit_points(rays, hits)
+    assert d_pts.cpu().numpy().reshape(n, 3).tobytes() == pts.tobytes()
+    assert d_nrm.cpu().numpy().reshape(n, 3).tobytes() == nrm.tobytes()
+    shadow = o.shadow_rays(rays, hits, light, 0.01)
+    assert d_shadow.cpu().numpy().view(rc.RAY_DT).tobytes() == shadow.tobytes()
+    occ = o.trace(shadow, mode="any", nthreads=8)
+    assert_hits_equal(d_occ.cpu().numpy().view(rc.HIT_DT), occ, "stage shadow any_hit")
+    lit = (hits["hit"] == 1) & (occ["hit"] == 0)
+    assert 0 < lit.sum() < (hits["hit"] == 1).sum()
 
 
 # ---- lifecycle (handles, dirty flags, refit identity, errors) -------------------------------------------------
