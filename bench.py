@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--res", type=int, default=2048, help="primary rays = res x res")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for dry runs)")
     args = ap.parse_args()
 
     import torch
@@ -50,12 +51,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        if args.backend == "nccl":
+            raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible")
+        local_rank %= max(n_dev, 1)  # dry run of the multi-rank control flow on fewer GPUs
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("RC_BENCH_FORCE_DIST") == "1"  # the env switch exercises the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import raycore_jl_amd as rc
     sc = rc.scenes
@@ -96,14 +105,22 @@ def main():
     elapsed = time.perf_counter() - t0
     launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     hits = d_hits.cpu().numpy().view(rc.HIT_DT)
     hit_frac = float(hits["hit"].mean())
 
     extras = {}
-    if not args.no_extras and rank == 0:
+
+    def guarded_extra(name, fn):
+        """An extra measurement must never cost the headline line: failures are recorded, not raised."""
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            extras[name + "_error"] = f"{type(e).__name__}: {e}"[:300]
+
+    def extra_traces():
         def timed(rs, mode, reps=3):
             dr = torch.from_numpy(rs.view(np.uint8).reshape(-1)).cuda()
             dh = torch.empty(len(rs) * 32, dtype=torch.uint8, device="cuda")
@@ -126,6 +143,9 @@ def main():
         t2.free()
 
     if not args.no_extras and rank == 0:
+        guarded_extra("traces", extra_traces)
+
+    def extra_builds():
         # LBVH build (row a14): device pipeline time for triangle soup already in HBM; the reference publishes
         # 4.93 / 7.46 / 16.16 ms for 250k / 1M / 4M triangles on an RX 7900 XTX (benchmarks/implicitbvh_comparison.md:12-14).
         builds = {}
@@ -141,7 +161,11 @@ def main():
             del dv
         extras["blas_build_device"] = builds
         torch.cuda.empty_cache()
-    if not args.no_extras:
+
+    if not args.no_extras and rank == 0:
+        guarded_extra("builds", extra_builds)
+
+    def extra_view_factors():
         # view_factors (BASELINE config C5: ~50k-triangle closed scene, rays_per_triangle = 4096 => 204.9 M rays, N x N
         # u32 = 10 GB) through the multi-GPU driver: every rank takes part; both partitions are timed.
         from raycore_jl_amd import distributed as rd
@@ -166,6 +190,9 @@ def main():
         t5.free()
         if rank == 0:
             extras["view_factors_c5"] = vf
+
+    if not args.no_extras and args.backend == "nccl":
+        guarded_extra("view_factors", extra_view_factors)
 
     node_f, inst_f = C3_NODE_FETCHES_PER_RAY, C3_INST_ENTRIES_PER_RAY
     cpu_baseline = None
