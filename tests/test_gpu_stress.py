@@ -151,3 +151,27 @@ def test_grow_and_shrink(rc):  # test/test_tlas_stress.jl:517-548
         assert t.n_instances() == len(hs) == t.n_geometries()
     o = np.array([[t.get_instance(h)["transform"][3], 0, 5] for h in hs], dtype=np.float32)
     assert np.all(t.trace(rc.scenes.make_rays(o, [0, 0, -1]))["hit"] == 1)
+
+
+def test_mesh_swap_keeps_analytic_depth(rc):  # test/test_mesh_update.jl:96-116: sphere t = 4 - z_off after mesh swaps
+    t = rc.TLAS()
+    h = t.push(rc.scenes.fan_sphere(32, 17, centre=(0, 0, 0), radius=1.0))
+    for z_off in (0.0, 0.5, -1.0, 2.0, 0.25):
+        t.update(h, rc.scenes.fan_sphere(32, 17, centre=(0, 0, z_off), radius=1.0))
+        assert t.sync().last_sync_action == "rebuild"
+        hit, _, dist, _, inst = rc.closest_hit(t, rc.Ray((0.0, 0.0, 5.0), (0, 0, -1)))
+        assert hit and inst == 1 and abs(dist - (4.0 - z_off)) < 0.05
+    # refit path (test/test_mesh_update.jl:184-227): move the instance instead of the mesh
+    for dz in (0.5, 1.5):
+        t.update_transform(h, xlat(0, 0, dz))
+        assert t.sync().last_sync_action == "refit"
+        hit, _, dist, _, _ = rc.closest_hit(t, rc.Ray((0.0, 0.0, 5.0), (0, 0, -1)))
+        assert hit and abs(dist - (4.0 - 0.25 - dz)) < 0.05
+
+
+def test_contract_counters(rc):  # test/test_abstract_accel_contract.jl:22-34
+    t, hs = rc.TLAS_from_meshes([rc.scenes.fan_sphere(8, 5), rc.scenes.fan_sphere(8, 5, centre=(3, 0, 0))])
+    assert t.n_instances() == 2 and t.n_geometries() == 2
+    wb = t.world_bound()
+    assert np.all(wb.p_min < wb.p_max) and wb.p_max[0] > 3.0
+    assert t.wait_for_gpu() is t
