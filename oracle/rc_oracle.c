@@ -543,6 +543,8 @@ static inline void intersect_internal_node(const rco_node* node, v3 inv_d, v3 ra
 static uint32_t* g_hist_tlas = NULL;
 static uint32_t* g_hist_blas = NULL;
 void rco_set_histograms(uint32_t* tlas, uint32_t* blas) { g_hist_tlas = tlas; g_hist_blas = blas; }
+static int32_t g_max_sp = 0;  /* dev: deepest stack seen (single-threaded use) */
+int32_t rco_max_stack(int reset) { int32_t v = g_max_sp; if (reset) g_max_sp = 0; return v; }
 
 static void set_miss(rco_hit* h) {
     h->hit = 0; h->t = 0.0f; h->primitive_id = 0xFFFFFFFFu; h->instance_custom_index = 0;
@@ -581,7 +583,7 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
         if (!is_leaf) {
             uint32_t near_c, far_c;
             intersect_internal_node(node, ray_inv_d, ray_o, ray_mint, ray_maxt, &near_c, &far_c);
-            if (far_c != RCO_INVALID_NODE) { if (sp < RCO_STACK) stack[sp++] = far_c; }
+            if (far_c != RCO_INVALID_NODE) { if (sp < RCO_STACK) stack[sp++] = far_c; if (sp > g_max_sp) g_max_sp = sp; }
             if (near_c != RCO_INVALID_NODE) { node_index = near_c; continue; }
         } else if (current_instance < 0) {
             current_instance = (int32_t)node->child1;

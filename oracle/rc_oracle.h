@@ -121,6 +121,7 @@ void rco_safe_invdir(const float d[3], float out[3]);       /* :1742-1748 */
 int rco_is_degenerate(const float v[9]);                    /* src/triangle_mesh.jl:14-17 */
 void rco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void rco_set_histograms(uint32_t* tlas_hist, uint32_t* blas_hist); /* dev: per-node visit counts (single-threaded use) */
+int32_t rco_max_stack(int reset); /* dev: deepest traversal stack seen since the last reset (single-threaded use) */
 void rco_sincos_f64(double x, double* s, double* c); /* sampler trig, see rc_oracle.c */
 double rco_acos_f64(double x);
 

@@ -233,6 +233,45 @@ def test_trace_edge_cases(rc, oracle):
     assert dup.any()
 
 
+def test_deep_trees_use_the_stack_spill_path(rc, oracle):
+    """LBVH chains (one leaf split off per level: Morton codes that are successive powers of two) make 30-level BLAS and
+    deep TLAS trees; rays through the shared corner keep one pending far child per level, so the per-lane stack outgrows
+    its 24 LDS entries and runs through the global spill area (the reference's 32-entry MVector would overflow, :1912)."""
+    def chain(levels, fat=0.3):
+        tris = []
+        for j in range(1, levels + 1):
+            for axis in range(3):
+                size = 2.0 ** (-j + 1)
+                p = np.full(3, fat * size); p[axis] = size
+                q = p.copy(); q[(axis + 1) % 3] += 0.5 * size * fat
+                r = np.full(3, -1e-4 * (1 + 0.5 * j))   # smaller triangles start earlier along +rays: the deep subtree is the near child
+                tris.append(np.concatenate([r, p, q]))
+        return np.array(tris, dtype=np.float32)
+    verts = chain(10)
+    xf = np.tile(rc.scenes.IDENTITY3x4, (4, 1)).astype(np.float32)
+    xf[1, [0, 5, 10]] = 0.5
+    xf[2, [0, 5, 10]] = 0.25
+    xf[3, [3, 7, 11]] = [0.01, 0.0, 0.0]
+    cfg = {"blas": [(verts, None)], "instances": [(1, xf, np.arange(4, dtype=np.uint32))]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    g = rc.scenes.rng(12)
+    n = 20000
+    org = g.uniform(-0.2, 0.0, size=(n, 3))
+    d = rc.scenes.normalize(g.uniform(0.05, 1.0, size=(n, 3)))
+    rays = rc.scenes.make_rays(org, d)
+    want = o.trace(rays, nthreads=8)
+    assert want["hit"].mean() > 0.01
+    t.set_option("kernel", 1); t.set_option("stats", 1)
+    assert_hits_equal(t.trace(rays), want, "deep k1")
+    max_sp = t.get_option("stat2")
+    t.set_option("stats", 0)
+    assert max_sp > 24, f"scene too shallow to reach the spill path (max stack {max_sp})"
+    for k in (0, 2, 3):
+        t.set_option("kernel", k)
+        assert_hits_equal(t.trace(rays), want, f"deep k{k}")
+        assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any", nthreads=8), f"deep any k{k}")
+
+
 def test_full_size_c2_properties(rc, oracle):
     """BASELINE C2 at full size: 100k triangles, 1M coherent rays.  Oracle comparison on every ray (the C
     oracle does 1M rays in seconds on 8 threads) plus size-independent properties."""
