@@ -54,3 +54,13 @@ def test_product_does_not_link_oracle(rc):
                 text = open(os.path.join(dirpath, f)).read()
                 for needle in ("pyoracle", "rc_oracle", "librc_oracle", "from oracle", "import oracle", "rco_"):
                     assert needle not in text, f"{f} references the oracle ({needle})"
+
+
+def test_header_is_plain_c_and_example_links(rc, tmp_path):
+    """The boundary is a C ABI: the header compiles as C11 and a C client links against the library (not run here: no GPU)."""
+    exe = tmp_path / "trace_quad"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "trace_quad.c"),
+                           "-L", os.path.dirname(rc.LIB_PATH), "-lraycore_mi355x", "-Wl,-rpath," + os.path.dirname(rc.LIB_PATH), "-o", str(exe)])
+    if rc.device_count() == 0:
+        r = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert r.returncode == 2 and "no GPU" in r.stderr

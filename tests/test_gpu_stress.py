@@ -175,3 +175,18 @@ def test_contract_counters(rc):  # test/test_abstract_accel_contract.jl:22-34
     wb = t.world_bound()
     assert np.all(wb.p_min < wb.p_max) and wb.p_max[0] > 3.0
     assert t.wait_for_gpu() is t
+
+
+def test_c_client_example_runs(rc, tmp_path):
+    """examples/trace_quad.c through the C ABI on the GPU (the reference's KAT shape: t = 1, 2, miss, 3; instance ids 0/1)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "trace_quad"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "trace_quad.c"),
+                           "-L", os.path.dirname(rc.LIB_PATH), "-lraycore_mi355x", "-Wl,-rpath," + os.path.dirname(rc.LIB_PATH), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    assert out[0].startswith("ray 0: hit=1 t=1 ") and "instance=0 custom=11" in out[0]
+    assert out[1].startswith("ray 1: hit=1 t=2 ") and "instance=1 custom=22" in out[1]
+    assert out[2].startswith("ray 2: hit=0")
+    assert out[3].startswith("ray 3: hit=1 t=3 ") and "instance=0" in out[3]
