@@ -365,29 +365,35 @@ def generate_ray_grid(accel, viewdir, grid_size):
     return buf.cpu().numpy().view(RAY_DT).reshape(n)
 
 
+RAYHIT_DT = np.dtype([("hit", "?"), ("point", "<f4", 3), ("metadata", "<u4")])  # RayHit{UInt32}, src/kernels.jl:1-5
+
+
 def hits_from_grid(accel, viewdir, grid_size=32):
-    """hits_from_grid (src/kernels.jl:58-72): RayHit per grid cell, point = sum(bary .* vertices)."""
+    """hits_from_grid (src/kernels.jl:58-72): a grid_size x grid_size array of RayHit records (RAYHIT_DT, indexed [i, j] like
+    the Julia Matrix); point = sum_mul(bary, prim.vertices) in the primitive's local space, metadata = prim.metadata
+    (a miss carries the zero triangle: point 0, metadata 0)."""
     t = _owner(accel)
     rays = generate_ray_grid(t._static, viewdir, grid_size)
     hits = t.trace(rays)
     prims = t._prims()
-    out = []
-    for h in hits:
-        if h["hit"]:
-            p = prims[h["primitive_id"]]
-            u, v = h["bary_u"], h["bary_v"]
-            w = (np.float32(1) - u) - v
-            point = (w * p["v"][0] + u * p["v"][1]) + v * p["v"][2]  # sum_mul, src/math.jl:52
-            out.append(RayHit(True, point, p["meta"]))
-        else:
-            out.append(RayHit(False, np.zeros(3, np.float32), np.uint32(0)))
-    return out
+    out = np.zeros(len(rays), dtype=RAYHIT_DT)
+    m = hits["hit"] == 1
+    out["hit"] = m
+    if m.any():
+        p = prims[hits["primitive_id"][m]]
+        u, v = hits["bary_u"][m], hits["bary_v"][m]
+        w = (np.float32(1) - u) - v
+        # sum_mul (src/math.jl:52): a[1]*b[1] + a[2]*b[2] + a[3]*b[3], left to right, in Float32
+        out["point"][m] = (w[:, None] * p["v"][:, 0] + u[:, None] * p["v"][:, 1]) + v[:, None] * p["v"][:, 2]
+        out["metadata"][m] = p["meta"]
+    return out.reshape(grid_size, grid_size, order="F")
 
 
 def get_centroid(accel, viewdir, grid_size=32):
-    """get_centroid (src/kernels.jl:106-110)."""
-    pts = [h.point for h in hits_from_grid(accel, viewdir, grid_size) if h.hit]
-    return pts, (np.mean(np.stack(pts), axis=0) if pts else np.full(3, np.nan, np.float32))
+    """get_centroid (src/kernels.jl:106-110): the hit points and their mean."""
+    hits = hits_from_grid(accel, viewdir, grid_size)
+    pts = hits["point"][hits["hit"]]
+    return pts, (pts.mean(axis=0) if len(pts) else np.full(3, np.nan, np.float32))
 
 
 def get_illumination(accel, viewdir, grid_size=1000):

@@ -306,6 +306,29 @@ def test_ray_grid_and_illumination_parity(rc, oracle):
         assert got.sum() == np.count_nonzero(metas <= len(got))  # metadata outside 1..N is dropped (src/kernels.jl:123)
 
 
+def test_hits_from_grid_and_centroid(rc, oracle):  # src/kernels.jl:58-72, 106-110
+    cfg = rc.scenes.config_c1()
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    g = 48
+    hg = rc.hits_from_grid(t, cfg["viewdir"], g)
+    assert hg.shape == (g, g)
+    rays = o.ray_grid(cfg["viewdir"], g)
+    want = o.trace(rays)
+    flat = hg.reshape(-1, order="F")
+    assert np.array_equal(flat["hit"], want["hit"] == 1)
+    m = want["hit"] == 1
+    prims = o.blas_prims[want["primitive_id"][m]]
+    u, v = want["bary_u"][m], want["bary_v"][m]
+    w = (np.float32(1) - u) - v
+    pts = (w[:, None] * prims["v"][:, 0] + u[:, None] * prims["v"][:, 1]) + v[:, None] * prims["v"][:, 2]
+    assert flat["point"][m].tobytes() == pts.astype(np.float32).tobytes()
+    assert np.array_equal(flat["metadata"][m], prims["meta"])
+    # the sphere is centred at (0,0,2) with radius 1: hit points lie on it, their mean is on the axis towards the viewer
+    assert np.allclose(np.linalg.norm(flat["point"][m] - [0, 0, 2], axis=1), 1.0, atol=0.02)
+    pts2, mean = rc.get_centroid(t, cfg["viewdir"], g)
+    assert len(pts2) == m.sum() and abs(mean[0]) < 0.02 and abs(mean[1]) < 0.02 and mean[2] < 2.0
+
+
 def test_view_factor_rays_bit_exact(rc, oracle):
     """The sampled rays themselves (Philox -> triangle point -> hemisphere direction, src/kernels.jl:83-92,
     src/math.jl:125-174) are bit-identical on device and oracle, not just the counted matrices."""
