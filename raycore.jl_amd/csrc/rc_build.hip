@@ -213,21 +213,6 @@ __global__ void k_blas_leaves(RcNode* nodes, const RcPrim* prims, uint32_t n) {
     nd->child1 = j;
 }
 
-// get_node_aabb / get_tlas_node_aabb (src/instanced-bvh.jl:1141-1174)
-__device__ inline void node_aabb(const RcNode& nd, bool interior, bool tlas, float3_& mn, float3_& mx) {
-    if (interior) {
-        mn = min3v(mk3(nd.f[0], nd.f[1], nd.f[2]), mk3(nd.f[6], nd.f[7], nd.f[8]));
-        mx = max3v(mk3(nd.f[3], nd.f[4], nd.f[5]), mk3(nd.f[9], nd.f[10], nd.f[11]));
-    } else if (tlas) {
-        mn = mk3(nd.f[0], nd.f[1], nd.f[2]);
-        mx = mk3(nd.f[3], nd.f[4], nd.f[5]);
-    } else {
-        float3_ v0 = mk3(nd.f[0], nd.f[1], nd.f[2]), v1 = mk3(nd.f[3], nd.f[4], nd.f[5]), v2 = mk3(nd.f[6], nd.f[7], nd.f[8]);
-        mn = min3v(min3v(v0, v1), v2);
-        mx = max3v(max3v(v0, v1), v2);
-    }
-}
-
 // Device-coherent 8/16-byte accesses for data exchanged between workgroups inside one launch: sc0 sc1 loads and
 // stores on both sides go past the (non-coherent) per-CU L1 and per-XCD L2 (CDNA guide, Guideline 16).
 typedef float f4v __attribute__((ext_vector_type(4)));

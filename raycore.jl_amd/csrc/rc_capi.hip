@@ -86,14 +86,6 @@ void check_status(rc_scene* s, hipStream_t stream) {
     if (st) throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels)");
 }
 
-template <typename T>
-void export_array(const std::vector<T>& host, T* out, uint32_t capacity, uint32_t* count) {
-    if (count) *count = (uint32_t)host.size();
-    if (!out) return;
-    if (capacity < host.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
-    if (!host.empty()) memcpy(out, host.data(), sizeof(T) * host.size());
-}
-
 void export_nodes(rc_scene* s, const RcNode* d, uint32_t n, rc_bvh_node* out, uint32_t capacity, uint32_t* count) {
     if (count) *count = n;
     if (!out || n == 0) return;
