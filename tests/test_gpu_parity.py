@@ -293,6 +293,41 @@ def test_full_size_c2_properties(rc, oracle):
         assert np.array_equal(t.trace(rays, mode="any")["hit"], got["hit"])
 
 
+def test_full_size_c3_c4_properties(rc, oracle):
+    """BASELINE C3 (4 M primary rays + shadow rays) and C4 (16 M incoherent bounce rays) at full size on the device:
+    a 1/16 sample against the oracle, and size-independent properties over the whole batch -- every kernel variant
+    agrees bit for bit, permuting the batch permutes the results, any_hit agrees with closest_hit on occlusion."""
+    import torch
+    cfg = rc.scenes.config_c3()
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    rays = rc.scenes.c3_primary_rays(cfg, 2048, 2048)
+    n = len(rays)
+
+    def run(rs, mode, kernel):
+        t.set_option("kernel", kernel)
+        dr = torch.from_numpy(rs.view(np.uint8).reshape(-1)).cuda()
+        dh = torch.empty(len(rs) * 32, dtype=torch.uint8, device="cuda")
+        t.trace_device(dr.data_ptr(), dh.data_ptr(), len(rs), mode=mode)
+        torch.cuda.synchronize()
+        return dh.cpu().numpy().view(rc.HIT_DT)
+
+    prim = run(rays, "closest", -1)
+    assert_hits_equal(prim[::16], o.trace(rays[::16], nthreads=8), "C3 full-size sample")
+    assert_hits_equal(run(rays, "closest", 0), prim, "C3 kernel 0 vs default")
+    shadow = rc.scenes.c3_shadow_rays(cfg, rays, prim)
+    occ = run(shadow, "any", -1)
+    assert_hits_equal(occ[::16], o.trace(shadow[::16], mode="any", nthreads=8), "C3 shadow sample")
+    assert np.array_equal(occ["hit"], run(shadow, "closest", -1)["hit"])   # occluded <=> a closest hit exists within t_max
+    bounce = rc.scenes.c4_bounce_rays(cfg, rays, prim, 4 * n)
+    assert len(bounce) == 16_777_216
+    b3 = run(bounce, "closest", 3)
+    assert_hits_equal(b3[::64], o.trace(bounce[::64], nthreads=8), "C4 sample")
+    assert_hits_equal(run(bounce, "closest", 1), b3, "C4 kernel 1 vs 3")
+    perm = rc.scenes.rng(3).permutation(len(bounce))
+    assert_hits_equal(run(bounce[perm], "closest", 3), b3[perm], "C4 permuted")
+    t.set_option("kernel", -1)
+
+
 # ---- drivers ---------------------------------------------------------------------------------------------------
 def test_ray_grid_and_illumination_parity(rc, oracle):
     for cfg, grid in ((rc.scenes.config_c1(), 64), (rc.scenes.config_c2(20_000, 300), 300)):
