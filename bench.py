@@ -29,8 +29,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # Reference-algorithm fetch counts for this workload (avg per ray), measured by the oracle; refreshed by the
 # cpu_baseline leg whenever it runs.  Used only when the oracle leg is skipped (N > 1).
-C3_NODE_FETCHES_PER_RAY = 32.98
-C3_INST_ENTRIES_PER_RAY = 1.92
+C3_NODE_FETCHES_PER_RAY = 33.006
+C3_INST_ENTRIES_PER_RAY = 1.922
 
 
 def main():
@@ -237,14 +237,19 @@ def main():
                        "triangles": int(n_tris), "rays_per_step_per_gpu": n, "hit_fraction": round(hit_frac, 4),
                        "kernel": {-1: "auto (phased persistent)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": "k_trace_*<closest>", "avg_launch_ms": round(launch_ms, 4),
+                         "traffic": traffic, "kernel": "k_trace_phased<false, 24, 6, false>" if t.get_option("kernel") in (-1, 3) else f"kernel option {t.get_option('kernel')}", "avg_launch_ms": round(launch_ms, 4),
                          "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3)},
             "cpu_baseline": cpu_baseline,
             "extras": extras,
         }
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":
