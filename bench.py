@@ -208,15 +208,17 @@ def main():
         o.build()
         cores = os.cpu_count() or 1
         o.trace(rays[:65536], nthreads=cores)  # warm
-        c0 = time.perf_counter()
-        ohits, cnt = o.trace(rays, nthreads=cores, counters=True)
-        cdt = time.perf_counter() - c0
+        cdt = 1e30
+        for _ in range(5):  # 5 passes over the whole batch, best one reported (a single 0.3 s pass on 256 threads is noisy)
+            c0 = time.perf_counter()
+            ohits, cnt = o.trace(rays, nthreads=cores, counters=True)
+            cdt = min(cdt, time.perf_counter() - c0)
         node_f, inst_f = float(cnt[:, 0].mean()), float(cnt[:, 1].mean())
         same = bool(np.array_equal(ohits["primitive_id"], hits["primitive_id"]) and np.array_equal(ohits["instance_id"], hits["instance_id"])
                     and np.array_equal(ohits["t"].view(np.uint32), hits["t"].view(np.uint32)))
         cpu_baseline = {"value": round(n / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                         "sample": f"all {n} primary rays of the workload, closest_hit, C restatement of the reference algorithm "
-                                  f"(oracle/, gcc -O2, {cores} pthreads), {cdt:.1f} s", "gpu_matches_bit_exact": same}
+                                  f"(oracle/, gcc -O2, {cores} pthreads), best of 5 passes, {cdt:.2f} s per pass", "gpu_matches_bit_exact": same}
 
     if rank == 0:
         bytes_per_ray = 32 + 32 + 60.0 * node_f + 140.0 * inst_f
