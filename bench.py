@@ -176,15 +176,23 @@ def main():
         t5.sync()
         n5, rpt = t5.n_primitives(), cfg5["rays_per_triangle"]
         vf = {"n_prims": n5, "rays_per_triangle": rpt, "n_rays": n5 * rpt, "matrix_bytes": 4 * n5 * n5}
-        for mode in ("rows", "rays"):
+        t5._prims()  # metadata read-back outside the timed region
+        for mode in ("rows_sharded", "rows", "rays"):
             rd.view_factors_distributed(t5, 4, 7, mode=mode)  # warm-up: allocator, RCCL channels
             fence()
             v0 = time.perf_counter()
             m = rd.view_factors_distributed(t5, rpt, 7, mode=mode)
             fence()
             vdt = time.perf_counter() - v0
+            if mode == "rows_sharded":  # result stays row-sharded: count = sum over ranks
+                cnt = m[0].sum(dtype=torch.int64)
+                if use_dist and args.backend == "nccl":
+                    dist.all_reduce(cnt)
+                counted = int(cnt.item())
+            else:
+                counted = int(m.sum(dtype=torch.int64).item()) if rank == 0 else 0
             if rank == 0:
-                vf[mode] = {"seconds": round(vdt, 4), "Mrays_s": round(n5 * rpt / vdt / 1e6, 1), "counted": int(m.sum(dtype=torch.int64).item())}
+                vf[mode] = {"seconds": round(vdt, 4), "Mrays_s": round(n5 * rpt / vdt / 1e6, 1), "counted": counted}
             del m
             torch.cuda.empty_cache()
         t5.free()

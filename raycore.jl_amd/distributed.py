@@ -9,6 +9,9 @@ Only the parts of the path that shard get a collective:
   bit-identical to the single-GPU matrix:
     - mode="rays"  (the north-star wording): every rank shoots rays [r0, r1) of ALL source primitives into a
       full N x N accumulator, then ONE reduce(SUM) of the accumulators over RCCL.  Message = 4 N^2 bytes.
+    - mode="rows_sharded": like "rows" below but the result STAYS sharded (each rank returns its own row block and the
+      metadata of its rows): no collective at all -- the layout a row-parallel consumer (e.g. a radiosity solve) wants,
+      and the only one whose cost does not grow with N^2 bytes over xGMI.
     - mode="rows": rank g owns source primitives [s0, s1) and shoots all their rays into its own
       (s1 - s0) x N row block; rows are disjoint (result[src, :] is written only by src, :85-97), so the
       exchange is a gather of row blocks -- each byte crosses xGMI once, the 7 peers use the root's 7
@@ -48,7 +51,8 @@ def view_factors_distributed(tlas, rays_per_triangle=10000, seed=0, mode="rows",
                              compute=None, device=None, prim_meta=None):
     """view_factors sharded over the ranks of `group`.  Returns, on rank `dst`, an int32 torch tensor whose
     uint32 view is the N x N matrix M[src_meta-1, hit_meta-1] (row-major; Julia's Matrix is its transpose in
-    memory); other ranks return None.  `compute(local, (s0,s1), (r0,r1), row_stride, col_stride, row_offset,
+    memory); other ranks return None.  mode="rows_sharded" returns (block, row_index) on EVERY rank instead: block[r]
+    is matrix row row_index[r].  `compute(local, (s0,s1), (r0,r1), row_stride, col_stride, row_offset,
     by_prim)` must ACCUMULATE into `local`; the default launches the HIP kernel through the C ABI.
     prim_meta: metadata of the flat (Morton-sorted) primitive array (default: read back from the scene)."""
     import torch
@@ -67,6 +71,14 @@ def view_factors_distributed(tlas, rays_per_triangle=10000, seed=0, mode="rows",
         if world > 1:
             dist.reduce(local, dst=dst, op=dist.ReduceOp.SUM, group=group)
         return local.view(n, n) if rank == dst else None
+    if mode == "rows_sharded":
+        s0, s1 = shard_range(n, rank, world)
+        local = torch.zeros((s1 - s0) * n, dtype=torch.int32, device=device)
+        compute(local, (s0, s1), (0, int(rays_per_triangle)), n, 1, s0, True)
+        if prim_meta is None:
+            prim_meta = tlas._prims()["meta"]
+        # row r of the block belongs to matrix row prim_meta[s0 + r] - 1
+        return local.view(s1 - s0, n), np.asarray(prim_meta)[s0:s1].astype(np.int64) - 1
     if mode == "rows":
         s0, s1 = shard_range(n, rank, world)
         rows_max = max(shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world))
@@ -90,7 +102,7 @@ def view_factors_distributed(tlas, rays_per_triangle=10000, seed=0, mode="rows",
             return out
         dist.gather(local, gather_list=None, dst=dst, group=group)
         return None
-    raise ValueError("mode must be 'rays' or 'rows'")
+    raise ValueError("mode must be 'rays', 'rows' or 'rows_sharded'")
 
 
 def get_illumination_distributed(tlas, viewdir, grid_size=1000, group=None, dst=0, n_prims=None, compute=None, device=None):

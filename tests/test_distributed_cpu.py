@@ -46,6 +46,9 @@ def _worker(rank, world, port, mode, q):
         if mode in ("rays", "rows"):
             out = rd.view_factors_distributed(None, rpt, seed, mode=mode, n_prims=n, compute=compute, device=torch.device("cpu"), prim_meta=meta)
             res = None if out is None else out.numpy().view(np.uint32).copy()
+        elif mode == "rows_sharded":
+            block, rows = rd.view_factors_distributed(None, rpt, seed, mode=mode, n_prims=n, compute=compute, device=torch.device("cpu"), prim_meta=meta)
+            res = (block.numpy().view(np.uint32).copy(), rows)
         else:
             grid = 40
             rays = o.ray_grid([0.2, 0.3, 1.0], grid)
@@ -62,13 +65,13 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["rays", "rows", "illum"])
+@pytest.mark.parametrize("mode", ["rays", "rows", "rows_sharded", "illum"])
 def test_sharded_drivers_world2(oracle, mode):
     import torch.multiprocessing as mp
     import raycore_jl_amd as rc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + {"rays": 0, "rows": 1, "illum": 2}[mode]
+    port = 29500 + (os.getpid() % 500) + {"rays": 0, "rows": 1, "illum": 2, "rows_sharded": 3}[mode]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -77,6 +80,14 @@ def test_sharded_drivers_world2(oracle, mode):
         p.join(timeout=60)
         assert p.exitcode == 0
     o, n = _scene(oracle, rc)
+    if mode == "rows_sharded":  # every rank keeps its own rows; together they are the whole matrix
+        want = o.view_factors(64, seed=99)
+        full = np.zeros_like(want)
+        for r in (0, 1):
+            block, rows = results[r]
+            full[rows] += block
+        assert np.array_equal(full, want) and len(results[0][1]) + len(results[1][1]) == n
+        return
     assert results[1] is None
     if mode == "illum":
         assert np.array_equal(results[0], o.get_illumination([0.2, 0.3, 1.0], 40))

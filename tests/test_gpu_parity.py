@@ -410,6 +410,11 @@ def test_view_factors_parity(rc, oracle):
         out = rd.view_factors_distributed(t, 256, 1234, mode=mode)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint32), got), mode
+    block, rows = rd.view_factors_distributed(t, 256, 1234, mode="rows_sharded")
+    torch.cuda.synchronize()
+    full = np.zeros_like(got)
+    full[rows] = block.cpu().numpy().view(np.uint32)
+    assert np.array_equal(full, got)
     il = rd.get_illumination_distributed(t, [0.3, 0.2, 1.0], 128)
     torch.cuda.synchronize()
     assert np.array_equal(il.cpu().numpy(), rc.get_illumination(t, [0.3, 0.2, 1.0], 128))
