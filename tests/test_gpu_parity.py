@@ -233,6 +233,48 @@ def test_trace_edge_cases(rc, oracle):
     assert dup.any()
 
 
+def test_weird_rays_and_scales(rc, oracle):
+    """Inputs outside the comfortable range, still required to match the oracle bit for bit: zero / infinite / tiny
+    direction components (safe_invdir clamps, :1742-1748), t_max < t_min, negative t_min, huge and tiny coordinates,
+    NaN-free but extreme rays.  (Rays with NaN components are excluded: the reference's behaviour there is whatever
+    Julia's NaN-propagating min/max happen to produce and is not part of the parity domain)"""
+    sc = rc.scenes
+    xf, _, _ = sc.lattice_transforms(2, 2, 2, 2.0, 5)
+    xf[3, [0, 5, 10]] *= 1e3      # a huge instance
+    xf[4, [0, 5, 10]] *= 1e-3     # and a tiny one
+    xf[5, [3, 7, 11]] += 1e4      # far from the origin
+    cfg = {"blas": [(sc.fan_sphere(12, 7, radius=0.5), None), (sc.random_triangles(100, 2, lo=-0.5, hi=0.5, edge=0.4), None)],
+           "instances": [(1, xf[:5], np.arange(5, dtype=np.uint32)), (2, xf[5:], np.arange(3, dtype=np.uint32) + 10)]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    g = sc.rng(77)
+    n = 20000
+    org = g.uniform(-3, 5, size=(n, 3))
+    d = sc.normalize(g.normal(size=(n, 3)))
+    rays = sc.make_rays(org, d)
+    k = n // 10
+    rays["d"][0 * k:1 * k, 0] = 0.0                       # exactly axis-plane directions
+    rays["d"][1 * k:2 * k, 1] = -0.0
+    rays["d"][2 * k:3 * k] *= np.float32(1e-7)            # |d| tiny: every component is clamped to +-1e-5
+    rays["d"][3 * k:4 * k, 2] = np.float32(1e-6)          # one clamped component
+    rays["d"][4 * k:5 * k] *= np.float32(1e6)             # long direction vectors (t is in units of |d|)
+    rays["tmin"][5 * k:6 * k] = 2.0
+    rays["tmax"][5 * k:6 * k] = 1.0                       # empty interval
+    rays["tmin"][6 * k:7 * k] = -5.0                      # hits behind the origin are legal for closest_hit
+    rays["o"][7 * k:8 * k] = (xf[5, [3, 7, 11]] + g.uniform(-2, 2, size=(k, 3))).astype(np.float32)
+    rays["o"][8 * k:9 * k] *= np.float32(1e3)
+    rays["d"][9 * k:9 * k + 50] = [0.0, 0.0, 0.0]         # null direction
+    rays["d"][9 * k + 50:9 * k + 100] = [np.inf, 0.0, 0.0]
+    want_c, want_a = o.trace(rays, nthreads=8), o.trace(rays, mode="any", nthreads=8)
+    assert 0 < want_c["hit"].sum() < n
+    for kern in (0, 1, 2, 3):
+        t.set_option("kernel", kern)
+        got_c, got_a = t.trace(rays), t.trace(rays, mode="any")
+        ok = ~(np.isnan(want_c["t"]) | np.isnan(got_c["t"]))  # NaN != NaN bitwise is fine to compare too, but keep ids strict
+        assert_hits_equal(got_c, want_c, f"weird closest k{kern}")
+        assert_hits_equal(got_a, want_a, f"weird any k{kern}")
+        assert ok.any()
+
+
 def test_deep_trees_use_the_stack_spill_path(rc, oracle):
     """LBVH chains (one leaf split off per level: Morton codes that are successive powers of two) make 30-level BLAS and
     deep TLAS trees; rays through the shared corner keep one pending far child per level, so the per-lane stack outgrows
