@@ -11,6 +11,8 @@
 // fetch), the per-lane traversal stack in LDS ([entry][lane] layout => conflict-free ds_read/ds_write_b32)
 // with a global spill area for the rare deep path, and a persistent-wave kernel that refills finished lanes
 // from a global ray counter using ballot + mbcnt prefix sums instead of waiting for the slowest ray.
+#include <algorithm>
+
 #include "rc_traverse_core.h"
 
 namespace {
@@ -104,6 +106,31 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
         atomicAdd(&a.stats[1], st_lanes);
         atomicMax(&a.stats[2], st_maxsp);
     }
+}
+
+// ---- kernel 4: kernel 3 with the whole top level staged in LDS ----------------------------------------------------
+// One 1024-thread workgroup per CU (16 waves): 96 KiB of lane stacks + the packed TLAS nodes as seven float2 planes
+// (28 KiB) + the instance records (16 KiB) = 140 KiB of the CU's 160 KiB LDS.  Used when the scene has <= 256 instances.
+constexpr int kBigBlock = 1024;
+constexpr size_t kBigStackBytes = (size_t)kLdsStack * kBigBlock * 4;
+constexpr size_t kTlasPlaneBytes = (size_t)7 * kTlasLdsNodes * sizeof(float2);
+constexpr size_t kBigLdsBytes = kBigStackBytes + kTlasPlaneBytes + (size_t)kTlasLdsInst * 64;
+
+template <bool ANY>
+__global__ __launch_bounds__(kBigBlock) void k_trace_phased_lds(TraceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem);
+    float2* tl = reinterpret_cast<float2*>(smem + kBigStackBytes);
+    float4* il = reinterpret_cast<float4*>(smem + kBigStackBytes + kTlasPlaneBytes);
+    const RcNode* tnodes = a.v.blas_nodes + a.v.tlas_off;
+    for (uint32_t i = threadIdx.x; i < a.v.n_tlas_nodes * 7u; i += kBigBlock) {
+        const uint32_t nd = i / 7u, p = i % 7u;
+        tl[p * kTlasLdsNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
+    }
+    for (uint32_t i = threadIdx.x; i < a.v.n_inst * 4u; i += kBigBlock) il[i] = reinterpret_cast<const float4*>(a.v.inst)[i];
+    __syncthreads();
+    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats};
+    phased_trace<ANY, kLdsStack, false, ArraySource, HitWriter, kBigBlock, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, tl, il);
 }
 
 // ---- kernel 2: persistent waves + per-wave path scheduling --------------------------------------------
@@ -383,7 +410,14 @@ static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hip
     const bool stats = s->opt.stats != 0;
 #define RC_LAUNCH_P(L, W) hipLaunchKernelGGL((k_trace_persistent<ANY, L, W, false>), dim3(blocks), dim3(kBlock), 0, stream, a)
 #define RC_LAUNCH_S(L, W) hipLaunchKernelGGL((k_trace_simple<ANY, L, W>), dim3(blocks), dim3(kBlock), 0, stream, a)
-    if (s->opt.kernel == 3) {
+    if (s->opt.kernel == 4) {
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[ANY ? 1 : 0]) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes));
+            attr_set[ANY ? 1 : 0] = true;
+        }
+        hipLaunchKernelGGL((k_trace_phased_lds<ANY>), dim3(blocks), dim3(kBigBlock), kBigLdsBytes, stream, a);
+    } else if (s->opt.kernel == 3) {
         if (stats) hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
     } else if (s->opt.kernel == 2) {
@@ -411,6 +445,14 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     uint64_t want = (n + kBlock - 1) / kBlock, cap = (uint64_t)s->n_cus * rc_blocks_per_cu(s);
     uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     uint32_t total_threads = blocks * kBlock;
+    const int64_t saved_kernel = s->opt.kernel;
+    if (saved_kernel < 0) s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : 3;  // auto: tiny batches gain nothing from refilling
+    if (s->opt.kernel == 4 && (s->n_tlas_nodes > (uint32_t)kTlasLdsNodes || s->n_static_instances > (uint32_t)kTlasLdsInst)) s->opt.kernel = 3;
+    if (s->opt.kernel >= 3 && (uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32)) s->opt.kernel = 1;  // buffer offsets are 32-bit
+    if (s->opt.kernel == 4) {  // one 1024-thread workgroup per CU
+        blocks = (uint32_t)std::min<uint64_t>((n + kBigBlock - 1) / kBigBlock, (uint64_t)s->n_cus);
+        total_threads = blocks * kBigBlock;
+    }
     rc_prepare_launch(s, stream);
     TraceArgs a;
     a.v = rc_scene_view(s, total_threads);
@@ -425,9 +467,6 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.sched_thr = (int)s->opt.sched_thr;
     a.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
     RC_HIP(hipEventRecord(s->ev0, stream));
-    const int64_t saved_kernel = s->opt.kernel;
-    if (saved_kernel < 0) s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : 3;
-    if (s->opt.kernel == 3 && (uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32)) s->opt.kernel = 1;  // buffer offsets are 32-bit  // auto: tiny batches gain nothing from refilling
     if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
     s->opt.kernel = saved_kernel;
     RC_HIP(hipEventRecord(s->ev1, stream));

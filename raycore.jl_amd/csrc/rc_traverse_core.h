@@ -45,7 +45,7 @@ struct TraceArgs {
 typedef uint32_t __attribute__((address_space(3))) lds_u32;
 typedef uint32_t __attribute__((address_space(1))) glb_u32;
 
-template <int LDS_N>
+template <int LDS_N, int BLOCK = kBlock>
 struct LaneStackT {
     lds_u32* lds;        // &lds_stack[threadIdx.x]
     glb_u32* ovf;        // &overflow[global thread id]
@@ -54,14 +54,14 @@ struct LaneStackT {
     __device__ inline LaneStackT(uint32_t* lds_base, uint32_t* ovf_base, uint32_t stride, uint32_t* st)
         : lds((lds_u32*)lds_base), ovf((glb_u32*)ovf_base), ovf_stride(stride), status(st) {}
     __device__ inline void push(int& sp, uint32_t v) {
-        if (__builtin_expect(sp < LDS_N, 1)) lds[sp * kBlock] = v;
+        if (__builtin_expect(sp < LDS_N, 1)) lds[sp * BLOCK] = v;
         else if (sp < kTotalStack) ovf[(size_t)(sp - LDS_N) * ovf_stride] = v;
         else { *status = 1u; return; }
         ++sp;
     }
     __device__ inline uint32_t pop(int& sp) {
         --sp;
-        if (__builtin_expect(sp < LDS_N, 1)) return lds[sp * kBlock];
+        if (__builtin_expect(sp < LDS_N, 1)) return lds[sp * BLOCK];
         return ovf[(size_t)(sp - LDS_N) * ovf_stride];
     }
 };
@@ -291,10 +291,18 @@ struct PersistArgs {
     unsigned long long* stats;
 };
 
-template <bool ANY, int LDS_N, bool STATS, class Source, class Sink>
-__device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink) {
-    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    LaneStackT<LDS_N> st(lds_stack + threadIdx.x, av.overflow + gtid, av.total_threads, av.status);
+// TLAS_LDS: the block has staged the whole top level in LDS before the call (see k_trace_phased_lds): `tl` holds the packed
+// TLAS nodes as seven float2 planes of kTlasLdsNodes entries (dword pairs 0-1, 2-3, ... 12-13 of each node; a plane read is
+// one ds_read_b64 with lane addresses 8 bytes apart per node), `il` the instance records (4 x float4 each).  TLAS-level
+// visits and instance entries then never touch the vector-memory path, which is what bounds the kernel.
+constexpr int kTlasLdsNodes = 512;
+constexpr int kTlasLdsInst = 256;
+
+template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false>
+__device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
+                                    const float2* tl = nullptr, const float4* il = nullptr) {
+    const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
+    LaneStackT<LDS_N, BLOCK> st(lds_stack + threadIdx.x, av.overflow + gtid, av.total_threads, av.status);
     const int lane = threadIdx.x & 63;
     if (av.n_tlas_nodes == 0) {  // empty TLAS: every ray misses (test/test_tlas_stress.jl:808-831)
         for (uint64_t i = gtid; i < a.n_items; i += av.total_threads) sink(i, false, 0.0f, 0.0f, 0.0f, RC_INVALID_NODE, -1);
@@ -324,9 +332,19 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             if (n_int == 0) break;
             if (STATS) { st_iter[1] += 1; st_lane[1] += is_int ? 1 : 0; }
             if (is_int) {
-                const uint32_t off = (cur_off + node - 1u) << 6;
-                const float4 na = buf_f4(nrs, off), nb = buf_f4(nrs, off + 16), nc = buf_f4(nrs, off + 32);
-                const u2v ch = __builtin_amdgcn_raw_buffer_load_b64(nrs, off + 48, 0, 0);
+                float4 na, nb, nc;
+                u2v ch;
+                if (TLAS_LDS && cur_inst < 0) {
+                    const float2* q = tl + (node - 1u);
+                    const float2 p0 = q[0], p1 = q[kTlasLdsNodes], p2 = q[2 * kTlasLdsNodes], p3 = q[3 * kTlasLdsNodes],
+                                 p4 = q[4 * kTlasLdsNodes], p5 = q[5 * kTlasLdsNodes], p6 = q[6 * kTlasLdsNodes];
+                    na = make_float4(p0.x, p0.y, p1.x, p1.y); nb = make_float4(p2.x, p2.y, p3.x, p3.y); nc = make_float4(p4.x, p4.y, p5.x, p5.y);
+                    ch = u2v{__float_as_uint(p6.x), __float_as_uint(p6.y)};
+                } else {
+                    const uint32_t off = (cur_off + node - 1u) << 6;
+                    na = buf_f4(nrs, off); nb = buf_f4(nrs, off + 16); nc = buf_f4(nrs, off + 32);
+                    ch = __builtin_amdgcn_raw_buffer_load_b64(nrs, off + 48, 0, 0);
+                }
                 // packed node (rc_pack_node): na = child-0 (min.x,min.y,max.x,max.y), nb = child-1 likewise, nc = z of both
                 const v2f ixy = {inv.x, inv.y}, oxy = {ox.x, ox.y}, izz = {inv.z, inv.z}, ozz = {ox.z, ox.z};
                 const v2f n0xy = v2f{na.x, na.y} * ixy + oxy, f0xy = v2f{na.z, na.w} * ixy + oxy;
@@ -389,12 +407,22 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 o = wo; d = wd; inv = winv;
                 ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
             } else if (is_entry) {
-                cur_inst = (int)__builtin_amdgcn_raw_buffer_load_b32(nrs, ((cur_off + node - 1u) << 6) + 52u, 0, 0);  // child1
+                float4 m0, m1, m2;
+                u4v m3;
+                if (TLAS_LDS) {
+                    cur_inst = (int)__float_as_uint(tl[6 * kTlasLdsNodes + (node - 1u)].y);  // child1
+                    const float4* q = il + 4 * cur_inst;
+                    m0 = q[0]; m1 = q[1]; m2 = q[2];
+                    const float4 w = q[3];
+                    m3 = u4v{__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
+                } else {
+                    cur_inst = (int)__builtin_amdgcn_raw_buffer_load_b32(nrs, ((cur_off + node - 1u) << 6) + 52u, 0, 0);  // child1
+                    const uint32_t ioff = (uint32_t)cur_inst << 6;
+                    m0 = buf_f4(irs, ioff); m1 = buf_f4(irs, ioff + 16); m2 = buf_f4(irs, ioff + 32);
+                    m3 = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff + 48, 0, 0);
+                }
                 st.push(sp, RC_TOP_LEVEL_SENTINEL);
                 node = 1;
-                const uint32_t ioff = (uint32_t)cur_inst << 6;
-                const float4 m0 = buf_f4(irs, ioff), m1 = buf_f4(irs, ioff + 16), m2 = buf_f4(irs, ioff + 32);
-                const u4v m3 = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff + 48, 0, 0);
                 cur_off = m3.x;
                 n_level = m3.w;
                 o = mk3(m0.x * wo.x + m0.y * wo.y + m0.z * wo.z + m0.w, m1.x * wo.x + m1.y * wo.y + m1.z * wo.z + m1.w,

@@ -161,7 +161,7 @@ def test_build_parity_100k(rc, oracle):
 
 
 # ---- traversal parity -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
 def test_trace_parity_c1(rc, oracle, kernel):
     cfg = rc.scenes.config_c1()
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
@@ -173,7 +173,7 @@ def test_trace_parity_c1(rc, oracle, kernel):
     assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any"), "C1 any")
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
 def test_trace_parity_random_scene(rc, oracle, kernel):
     sc = rc.scenes
     xf, _, _ = sc.lattice_transforms(3, 3, 2, 1.2, 77)
@@ -191,7 +191,7 @@ def test_trace_parity_random_scene(rc, oracle, kernel):
     assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any", nthreads=8), "random any")
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
 def test_trace_parity_c3_and_shadow(rc, oracle, kernel):
     cfg = rc.scenes.config_c3()
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
@@ -224,7 +224,7 @@ def test_trace_edge_cases(rc, oracle):
             os_.append([x, 0.5, 0.0]); ds.append([1.0, 0.0, 0.0])      # in the plane of the quad
     rays = rc.scenes.make_rays(os_, ds)
     want = o.trace(rays)
-    for k in (0, 1, 2, 3):
+    for k in (0, 1, 2, 3, 4):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(rays), want, f"edge closest k{k}")
         assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any"), f"edge any k{k}")
@@ -266,7 +266,7 @@ def test_weird_rays_and_scales(rc, oracle):
     rays["d"][9 * k + 50:9 * k + 100] = [np.inf, 0.0, 0.0]
     want_c, want_a = o.trace(rays, nthreads=8), o.trace(rays, mode="any", nthreads=8)
     assert 0 < want_c["hit"].sum() < n
-    for kern in (0, 1, 2, 3):
+    for kern in (0, 1, 2, 3, 4):
         t.set_option("kernel", kern)
         got_c, got_a = t.trace(rays), t.trace(rays, mode="any")
         ok = ~(np.isnan(want_c["t"]) | np.isnan(got_c["t"]))  # NaN != NaN bitwise is fine to compare too, but keep ids strict
@@ -308,7 +308,7 @@ def test_deep_trees_use_the_stack_spill_path(rc, oracle):
     max_sp = t.get_option("stat2")
     t.set_option("stats", 0)
     assert max_sp > 24, f"scene too shallow to reach the spill path (max stack {max_sp})"
-    for k in (0, 2, 3):
+    for k in (0, 2, 3, 4):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(rays), want, f"deep k{k}")
         assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any", nthreads=8), f"deep any k{k}")
@@ -329,7 +329,7 @@ def test_full_size_c2_properties(rc, oracle):
     perm = rc.scenes.rng(5).permutation(len(rays))
     assert_hits_equal(t.trace(rays[perm]), got[perm], "C2 permuted")
     # every kernel variant agrees
-    for k in (0, 1, 2, 3):
+    for k in (0, 1, 2, 3, 4):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(rays), got, f"C2 kernel {k}")
         assert np.array_equal(t.trace(rays, mode="any")["hit"], got["hit"])
