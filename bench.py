@@ -224,7 +224,15 @@ def main():
         node_f, inst_f = float(cnt[:, 0].mean()), float(cnt[:, 1].mean())
         same = bool(np.array_equal(ohits["primitive_id"], hits["primitive_id"]) and np.array_equal(ohits["instance_id"], hits["instance_id"])
                     and np.array_equal(ohits["t"].view(np.uint32), hits["t"].view(np.uint32)))
-        cpu_baseline = {"value": round(n / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        cpu_model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        cpu_baseline = {"value": round(n / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
                         "sample": f"all {n} primary rays of the workload, closest_hit, C restatement of the reference algorithm "
                                   f"(oracle/, gcc -O2, {cores} pthreads), best of 5 passes, {cdt:.2f} s per pass", "gpu_matches_bit_exact": same}
 
