@@ -160,6 +160,28 @@ def test_build_parity_100k(rc, oracle):
     assert nodes_equal(t.adapt().all_blas_nodes, o.blas_nodes)
 
 
+def test_build_parity_1m_repeated(rc, oracle):
+    """1 M triangles: the refit's cross-workgroup hand-off (agent-coherent stores, relaxed counter, coherent loads of the
+    sibling box) runs under real contention across all 8 XCDs; every rebuild must still be byte-identical to the oracle."""
+    import torch
+    verts = rc.scenes.random_triangles(1_000_000, 4242, edge=0.01)
+    o = oracle.Scene()
+    o.add_instance(o.add_blas(verts))
+    o.build()
+    want = o.blas_nodes.tobytes()
+    t = rc.TLAS()
+    dv = torch.from_numpy(verts).cuda()
+    for rep in range(3):
+        b = t.add_geometry_device(dv.data_ptr(), len(verts))
+        h = t.push_instances(b)
+        st = t.adapt()
+        got = st.all_blas_nodes
+        # only the newest BLAS matters: it is the last n_nodes of the flat array
+        assert got[-(2 * len(verts) - 1):].tobytes() == want, rep
+        t.delete(h)   # the next sync compacts the old geometry away
+    t.free()
+
+
 # ---- traversal parity -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
 def test_trace_parity_c1(rc, oracle, kernel):
