@@ -7,10 +7,12 @@
 // Per-ray semantics are the reference's, statement for statement: same BVH2 nodes, same near/far rule,
 // same push/pop order, same Moeller-Trumbore expression order, no FMA contraction -- so hit ids and t are
 // bit-identical to the reference algorithm regardless of how rays are scheduled onto lanes.  What is
-// MI355X-specific is everything around that: 64-byte aligned node / instance records (4 x dwordx4 per
-// fetch), the per-lane traversal stack in LDS ([entry][lane] layout => conflict-free ds_read/ds_write_b32)
-// with a global spill area for the rare deep path, and a persistent-wave kernel that refills finished lanes
-// from a global ray counter using ballot + mbcnt prefix sums instead of waiting for the slowest ray.
+// MI355X-specific is everything around that: 64-byte aligned, pair-packed node / instance records fetched with
+// raw buffer loads, the per-lane traversal stack in LDS ([entry][lane] layout => conflict-free ds_read/ds_write_b32)
+// with a global spill area for the rare deep path, persistent waves that refill finished lanes from a global ray
+// counter (ballot + mbcnt prefix sums), and phase-structured execution so a wave only issues the block its lanes
+// actually need.  Kernel variants (rc_set_option "kernel"): 0 simple, 1 persistent, 2 voted scheduling, 3 phased
+// (default; core in rc_traverse_core.h), 4 phased with the TLAS staged in LDS.  All return identical results.
 #include <algorithm>
 
 #include "rc_traverse_core.h"
