@@ -211,6 +211,30 @@ int rc_hit_points_device(rc_scene* scene, const rc_ray* d_rays, const rc_hit* d_
 int rc_shadow_rays_device(rc_scene* scene, const rc_ray* d_rays, const rc_hit* d_hits, uint64_t n, const float light[3],
                           float bias, rc_ray* d_shadow_rays, void* stream);
 
+/* ---- BVH4 (src/bvh4.jl; exported by the reference as BVHNode4 / BLAS4 / build_blas4 / closest_hit4 / any_hit4).
+ * BLAS-level only, as in the reference: rays are traced in the geometry's own space, no instances.
+ * rc_bvh4_node = BVHNode4, 120 bytes (src/bvh4.jl:40-69): interior nodes hold 1-based BVH4 child indices, a leaf
+ * (child_count == 0) holds the 1-based index of its triangle in the BLAS's Morton-sorted primitive array in child[0]. */
+typedef struct rc_bvh4_node {
+    uint32_t child[4];
+    float aabb[4][2][3]; /* aabbK_min, aabbK_max */
+    uint32_t parent;
+    uint8_t child_count, primitive_count, _pad1, _pad2;
+} rc_bvh4_node;
+/* build_blas4 (src/bvh4.jl:511-522) for geometry blas_id (from rc_add_blas*): collapses its binary LBVH into BVHNode4s on
+ * the device (collapse_bvh2_to_bvh4 :314-497, same node numbering).  *n_nodes (optional) receives the node count. */
+int rc_blas4_build(rc_scene* scene, uint32_t blas_id, uint32_t* n_nodes);
+/* Copies the BLAS4's nodes out in the reference layout (count query when out == NULL). */
+int rc_export_blas4_nodes(rc_scene* scene, uint32_t blas_id, rc_bvh4_node* out, uint32_t capacity, uint32_t* count);
+/* closest_hit4 (src/bvh4.jl:606-689) / any_hit4 (:696-766) over a host ray batch.  Both ignore rc_ray.tmin (the
+ * reference starts from t_min = 0, :610/:700).  rc_hit: primitive_id = 0-based index into the BLAS's sorted primitives,
+ * instance_id = RC_INVALID_ID, instance_custom_index = 0; miss as rc_trace_closest. */
+int rc_trace_closest4(rc_scene* scene, uint32_t blas_id, const rc_ray* rays, rc_hit* hits, uint64_t n);
+int rc_trace_any4(rc_scene* scene, uint32_t blas_id, const rc_ray* rays, rc_hit* hits, uint64_t n);
+/* Same on device buffers, enqueued on `stream` (NULL = default stream), no host synchronisation. */
+int rc_trace_closest4_device(rc_scene* scene, uint32_t blas_id, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream);
+int rc_trace_any4_device(rc_scene* scene, uint32_t blas_id, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream);
+
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);

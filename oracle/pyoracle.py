@@ -23,6 +23,9 @@ TRI_DT = np.dtype([("v", "<f4", (3, 3)), ("meta", "<u4")])
 RAY_DT = np.dtype([("o", "<f4", 3), ("tmin", "<f4"), ("d", "<f4", 3), ("tmax", "<f4")])
 HIT_DT = np.dtype([("hit", "<u4"), ("t", "<f4"), ("primitive_id", "<u4"), ("instance_custom_index", "<u4"),
                    ("bary_u", "<f4"), ("bary_v", "<f4"), ("instance_id", "<u4"), ("_pad", "<u4")])
+NODE4_DT = np.dtype([("child", "<u4", 4), ("aabb", "<f4", (4, 2, 3)), ("parent", "<u4"), ("child_count", "u1"),
+                     ("primitive_count", "u1"), ("_pad1", "u1"), ("_pad2", "u1")])  # BVHNode4, src/bvh4.jl:40-69
+assert NODE4_DT.itemsize == 120
 assert NODE_DT.itemsize == 60 and INSTANCE_DT.itemsize == 108 and DESC_DT.itemsize == 32
 assert TRI_DT.itemsize == 40 and RAY_DT.itemsize == 32 and HIT_DT.itemsize == 32
 
@@ -84,6 +87,9 @@ def lib():
         L.rco_view_factor_ray.argtypes = [vp, u32, u32, u64, vp]
         L.rco_hit_points.argtypes = [vp, vp, vp, u64, vp, vp]
         L.rco_shadow_rays.argtypes = [vp, vp, vp, u64, vp, C.c_float, vp]
+        L.rco_blas4_nodes.restype = u32
+        L.rco_blas4_nodes.argtypes = [vp, u32, vp]
+        L.rco_trace4_batch.argtypes = [vp, u32, vp, vp, u64, C.c_int, C.c_int, vp]
         _lib = L
     return _lib
 
@@ -179,6 +185,20 @@ class Scene:
         for i in range(len(rays)):
             lib().rco_brute_closest(self._h, _p(rays[i:i + 1]), _p(hits[i:i + 1]))
         return hits
+
+    # ---- BVH4 (src/bvh4.jl) ----
+    def blas4_nodes(self, blas_index):
+        n = lib().rco_blas4_nodes(self._h, blas_index, None)
+        out = np.zeros(n, dtype=NODE4_DT)
+        lib().rco_blas4_nodes(self._h, blas_index, _p(out))
+        return out
+
+    def trace4(self, blas_index, rays, mode="closest", nthreads=1, counters=False):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DT)
+        hits = np.zeros(len(rays), dtype=HIT_DT)
+        cnt = np.zeros((len(rays), 2), dtype=np.uint32) if counters else None
+        lib().rco_trace4_batch(self._h, blas_index, _p(rays), _p(hits), len(rays), 0 if mode == "closest" else 1, nthreads, _p(cnt))
+        return (hits, cnt) if counters else hits
 
     # ---- drivers ----
     def ray_grid(self, viewdir, grid):

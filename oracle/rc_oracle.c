@@ -249,6 +249,7 @@ typedef struct {
     rco_tri* prims; uint32_t n_prims; /* Morton-sorted */
     uint32_t* morton;                 /* sorted codes */
     float root_min[3], root_max[3];
+    rco_node4* nodes4; uint32_t n_nodes4; /* BLAS4 (src/bvh4.jl), built on demand */
 } blas_t;
 
 struct rco_scene {
@@ -271,7 +272,7 @@ static void free_static(rco_scene* s) {
 }
 void rco_scene_free(rco_scene* s) {
     if (!s) return;
-    for (uint32_t i = 0; i < s->n_blas; ++i) { free(s->blas[i].nodes); free(s->blas[i].prims); free(s->blas[i].morton); }
+    for (uint32_t i = 0; i < s->n_blas; ++i) { free(s->blas[i].nodes); free(s->blas[i].prims); free(s->blas[i].morton); free(s->blas[i].nodes4); }
     free(s->blas); free(s->inst); free_static(s); free(s);
 }
 
@@ -914,4 +915,210 @@ void rco_shadow_rays(const rco_scene* s, const rco_ray* rays, const rco_hit* hit
         }
         out[i] = sr;
     }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * BVH4 (src/bvh4.jl)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float mn[3], mx[3]; } b3;
+
+static void bvh4_child_box(const rco_node* node, int interior, b3* out) { /* :265-274 / :288-295 */
+    v3 mn, mx;
+    node_aabb(node, interior, 0, &mn, &mx);
+    v3_store(out->mn, mn); v3_store(out->mx, mx);
+}
+
+/* gather_children_bvh2 (:201-300).  Returns child_count. */
+static int gather_children_bvh2(uint32_t root_idx, const rco_node* nodes2, uint32_t children[4], b3 aabbs[4], int child_is_leaf[4]) {
+    uint32_t queue[8];
+    int queue_size = 0, child_count = 0;
+    for (int i = 0; i < 4; ++i) {
+        children[i] = RCO_INVALID_NODE; child_is_leaf[i] = 0;
+        for (int k = 0; k < 3; ++k) { aabbs[i].mn[k] = INFINITY; aabbs[i].mx[k] = -INFINITY; } /* Bounds3() */
+    }
+    const rco_node* root = &nodes2[root_idx - 1];
+    if (root->child0 == RCO_INVALID_NODE) { /* :220-226 */
+        children[0] = root_idx; bvh4_child_box(root, 0, &aabbs[0]); child_is_leaf[0] = 1;
+        return 1;
+    }
+    queue[0] = root->child0; queue[1] = root->child1; queue_size = 2;
+    while (child_count < 4 && queue_size > 0) { /* :234-277 */
+        int best = 0;
+        for (int i = 0; i < queue_size; ++i) {
+            const rco_node* node = &nodes2[queue[i] - 1];
+            if (node->child0 != RCO_INVALID_NODE && child_count + queue_size - 1 + 2 <= 4) { best = i; break; }
+        }
+        uint32_t node_idx = queue[best];
+        queue[best] = queue[queue_size - 1];
+        queue_size -= 1;
+        const rco_node* node = &nodes2[node_idx - 1];
+        int interior = node->child0 != RCO_INVALID_NODE;
+        if (interior && child_count + queue_size + 2 <= 4) {
+            queue[queue_size++] = node->child0;
+            queue[queue_size++] = node->child1;
+        } else {
+            children[child_count] = node_idx;
+            bvh4_child_box(node, interior, &aabbs[child_count]);
+            child_is_leaf[child_count] = !interior;
+            child_count += 1;
+        }
+    }
+    while (queue_size > 0 && child_count < 4) { /* :280-297 */
+        uint32_t node_idx = queue[queue_size - 1];
+        queue_size -= 1;
+        const rco_node* node = &nodes2[node_idx - 1];
+        int interior = node->child0 != RCO_INVALID_NODE;
+        children[child_count] = node_idx;
+        bvh4_child_box(node, interior, &aabbs[child_count]);
+        child_is_leaf[child_count] = !interior;
+        child_count += 1;
+    }
+    return child_count;
+}
+
+static void bvh4_leaf(rco_node4* out, const rco_node* node2, uint32_t parent) { /* :368-387, :455-474 */
+    b3 box;
+    memset(out, 0, sizeof(*out));
+    bvh4_child_box(node2, 0, &box);
+    out->child[0] = node2->child1; out->child[1] = out->child[2] = out->child[3] = RCO_INVALID_NODE;
+    memcpy(out->aabb[0][0], box.mn, 12); memcpy(out->aabb[0][1], box.mx, 12);
+    out->parent = parent; out->child_count = 0; out->primitive_count = 1;
+}
+
+/* collapse_bvh2_to_bvh4 (:314-497): FIFO over interior subtrees; each task allocates its own node, then one leaf
+ * node per leaf child in slot order; interior children are queued with (slot, parent) and patch the parent's
+ * child pointer when they are dequeued. */
+static uint32_t collapse_bvh2_to_bvh4(const rco_node* nodes2, uint32_t n_nodes2, rco_node4** out_nodes) {
+    uint32_t max_nodes4 = n_nodes2 + 1;
+    rco_node4* nodes4 = (rco_node4*)calloc(max_nodes4, sizeof(rco_node4));
+    uint32_t node4_count = 0;
+    typedef struct { uint32_t bvh2_idx; int slot; uint32_t parent4; } task;
+    task* queue = (task*)malloc(sizeof(task) * (size_t)max_nodes4);
+    size_t q_head = 0, q_tail = 0;
+    const rco_node* root = &nodes2[0];
+    if (root->child0 == RCO_INVALID_NODE) { /* :334-351 */
+        node4_count += 1;
+        bvh4_leaf(&nodes4[0], root, RCO_INVALID_NODE);
+    } else {
+        queue[q_tail++] = (task){1u, 0, RCO_INVALID_NODE}; /* the root task: same body as :404-490 minus the parent patch */
+        while (q_head < q_tail) {
+            task tk = queue[q_head++];
+            uint32_t ch[4]; b3 boxes[4]; int is_leaf[4];
+            int count = gather_children_bvh2(tk.bvh2_idx, nodes2, ch, boxes, is_leaf);
+            node4_count += 1;
+            uint32_t current4 = node4_count;
+            if (tk.parent4 != RCO_INVALID_NODE) nodes4[tk.parent4 - 1].child[tk.slot] = current4; /* :415-444 */
+            uint32_t child_indices[4] = {RCO_INVALID_NODE, RCO_INVALID_NODE, RCO_INVALID_NODE, RCO_INVALID_NODE};
+            for (int i = 0; i < count; ++i) {
+                if (is_leaf[i]) {
+                    node4_count += 1;
+                    child_indices[i] = node4_count;
+                    bvh4_leaf(&nodes4[node4_count - 1], &nodes2[ch[i] - 1], current4);
+                } else {
+                    queue[q_tail++] = (task){ch[i], i, current4};
+                }
+            }
+            rco_node4* nd = &nodes4[current4 - 1];
+            memset(nd, 0, sizeof(*nd));
+            for (int i = 0; i < 4; ++i) {
+                nd->child[i] = child_indices[i];
+                memcpy(nd->aabb[i][0], boxes[i].mn, 12); memcpy(nd->aabb[i][1], boxes[i].mx, 12);
+            }
+            nd->parent = tk.parent4; nd->child_count = (uint8_t)count; nd->primitive_count = 0;
+        }
+    }
+    free(queue);
+    *out_nodes = (rco_node4*)realloc(nodes4, sizeof(rco_node4) * node4_count); /* resize! :494 */
+    return node4_count;
+}
+
+static blas_t* blas4_of(rco_scene* s, uint32_t bi) {
+    if (bi == 0 || bi > s->n_blas) return NULL;
+    blas_t* b = &s->blas[bi - 1];
+    if (!b->nodes4) b->n_nodes4 = collapse_bvh2_to_bvh4(b->nodes, b->n_nodes, &b->nodes4);
+    return b;
+}
+
+uint32_t rco_blas4_nodes(rco_scene* s, uint32_t bi, rco_node4* out) {
+    blas_t* b = blas4_of(s, bi);
+    if (!b) return 0;
+    if (out) memcpy(out, b->nodes4, sizeof(rco_node4) * b->n_nodes4);
+    return b->n_nodes4;
+}
+
+/* closest_hit4 (:606-689) and any_hit4 (:696-766) share the loop. */
+static void traverse4(const blas_t* b, const rco_ray* r, rco_hit* out, uint32_t* counters, int any) {
+    set_miss(out);
+    v3 ray_o = V(r->ox, r->oy, r->oz);
+    v3 ray_d = V(r->dx == 0.0f ? 0.0f : r->dx, r->dy == 0.0f ? 0.0f : r->dy, r->dz == 0.0f ? 0.0f : r->dz); /* check_direction */
+    float ray_mint = 0.0f; /* :610 -- NOT ray.t_min */
+    float ray_maxt = r->tmax;
+    v3 ray_inv_d = safe_invdir(ray_d);
+    uint32_t stack[RCO_STACK];
+    int32_t sp = 0;
+    uint32_t closest_prim = RCO_INVALID_NODE;
+    float hit_u = 0.0f, hit_v = 0.0f;
+    uint32_t node_idx = 1, n_node = 0, n_tri = 0;
+    for (;;) {
+        const rco_node4* node = &b->nodes4[node_idx - 1];
+        ++n_node;
+        if (node->child_count > 0) {
+            /* intersect_all_children4 (:562-599) */
+            uint32_t h_idx[4] = {RCO_INVALID_NODE, RCO_INVALID_NODE, RCO_INVALID_NODE, RCO_INVALID_NODE};
+            float h_t[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+            int hit_count = 0;
+            for (int i = 0; i < (int)node->child_count; ++i) {
+                uint32_t child_idx = node->child[i];
+                if (child_idx != RCO_INVALID_NODE) {
+                    float min_t, max_t;
+                    fast_intersect_bbox(ray_o, ray_inv_d, node->aabb[i][0], node->aabb[i][1], ray_mint, ray_maxt, &min_t, &max_t); /* :533-554 */
+                    if (min_t <= max_t) { h_idx[hit_count] = child_idx; h_t[hit_count] = min_t; hit_count += 1; }
+                }
+            }
+            for (int i = 1; i < hit_count; ++i) { /* insertion sort :590-596 */
+                int j = i;
+                while (j > 0 && h_t[j] < h_t[j - 1]) {
+                    uint32_t ti = h_idx[j]; h_idx[j] = h_idx[j - 1]; h_idx[j - 1] = ti;
+                    float tt = h_t[j]; h_t[j] = h_t[j - 1]; h_t[j - 1] = tt;
+                    j -= 1;
+                }
+            }
+            for (int i = hit_count - 1; i >= 1; --i) /* :637-642 */
+                if (h_idx[i] != RCO_INVALID_NODE && sp < RCO_STACK) stack[sp++] = h_idx[i];
+            if (hit_count > 0 && h_idx[0] != RCO_INVALID_NODE) { node_idx = h_idx[0]; continue; }
+        } else {
+            uint32_t prim_idx = node->child[0];
+            if (prim_idx != RCO_INVALID_NODE && prim_idx <= b->n_prims) { /* :652 */
+                const rco_tri* tri = &b->prims[prim_idx - 1];
+                ++n_tri;
+                float t, u, v;
+                if (fast_intersect_triangle(ray_o, ray_d, v3_from(tri->v[0]), v3_from(tri->v[1]), v3_from(tri->v[2]), ray_mint, ray_maxt, &t, &u, &v)) {
+                    if (any) { /* :744-749 */
+                        out->hit = 1; out->t = t; out->bary_u = u; out->bary_v = v; out->primitive_id = prim_idx - 1;
+                        if (counters) { counters[0] += n_node; counters[1] += n_tri; }
+                        return;
+                    }
+                    ray_maxt = t; closest_prim = prim_idx; hit_u = u; hit_v = v;
+                }
+            }
+        }
+        if (sp > 0) node_idx = stack[--sp]; else break;
+    }
+    if (counters) { counters[0] += n_node; counters[1] += n_tri; }
+    if (!any && closest_prim != RCO_INVALID_NODE) { /* :679-683 */
+        out->hit = 1; out->t = ray_maxt; out->bary_u = hit_u; out->bary_v = hit_v; out->primitive_id = closest_prim - 1;
+    }
+}
+
+typedef struct { const blas_t* b; const rco_ray* rays; rco_hit* hits; int mode; uint32_t* counters; } trace4_ctx;
+static void trace4_range(void* p, uint64_t b, uint64_t e) {
+    trace4_ctx* c = (trace4_ctx*)p;
+    for (uint64_t i = b; i < e; ++i) traverse4(c->b, &c->rays[i], &c->hits[i], c->counters ? c->counters + 2 * i : NULL, c->mode);
+}
+void rco_trace4_batch(rco_scene* s, uint32_t bi, const rco_ray* rays, rco_hit* hits, uint64_t n, int mode, int nthreads, uint32_t* counters) {
+    blas_t* b = blas4_of(s, bi);
+    if (!b) { for (uint64_t i = 0; i < n; ++i) set_miss(&hits[i]); return; }
+    if (counters) memset(counters, 0, sizeof(uint32_t) * 2 * n);
+    trace4_ctx c = {b, rays, hits, mode, counters};
+    parallel_for(n, nthreads, trace4_range, &c);
 }

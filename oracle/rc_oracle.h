@@ -145,6 +145,27 @@ int rco_view_factor_ray(const rco_scene*, uint32_t src_idx0, uint32_t ray_idx, u
 void rco_hit_points(const rco_scene*, const rco_ray* rays, const rco_hit* hits, uint64_t n, float* points, float* normals);
 void rco_shadow_rays(const rco_scene*, const rco_ray* rays, const rco_hit* hits, uint64_t n, const float light[3], float bias, rco_ray* out);
 
+/* ---- BVH4 (src/bvh4.jl): BLAS-level 4-wide tree collapsed from the BVH2; no TLAS/instance support in the
+ * reference.  PARITY UNPINNED: the reference has no test for this file. ------- */
+/* BVHNode4, 120 bytes (src/bvh4.jl:40-69) */
+typedef struct {
+    uint32_t child[4];     /* child0..child3; interior: 1-based BVH4 node index; leaf: child0 = 1-based sorted prim index */
+    float aabb[4][2][3];   /* aabbK_min, aabbK_max for K = 0..3 */
+    uint32_t parent;
+    uint8_t child_count;   /* 0 = leaf */
+    uint8_t primitive_count;
+    uint8_t _pad1, _pad2;
+} rco_node4;
+/* build_blas4 (:511-522) = build_blas + collapse_bvh2_to_bvh4 (:314-497) for BLAS `blas_index` (1-based).
+ * Returns the node count; copies the nodes when out != NULL. */
+uint32_t rco_blas4_nodes(rco_scene*, uint32_t blas_index, rco_node4* out);
+/* closest_hit4 (:606-689) / any_hit4 (:696-766) on that BLAS4, in the BLAS's own space (no instance transform).
+ * Both force t_min = 0 (:610,:700).  Hit record: primitive_id = 0-based index into the BLAS's Morton-sorted
+ * primitives, instance_id = 0xFFFFFFFF, instance_custom_index = 0.  counters (NULL or n x 2 u32):
+ * [0] BVHNode4 fetches, [1] triangle fetches. */
+void rco_trace4_batch(rco_scene*, uint32_t blas_index, const rco_ray* rays, rco_hit* hits, uint64_t n, int mode,
+                      int nthreads, uint32_t* counters);
+
 #ifdef __cplusplus
 }
 #endif

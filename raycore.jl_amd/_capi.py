@@ -22,6 +22,9 @@ INSTANCE_DT = np.dtype([("blas_index", "<u4"), ("instance_id", "<u4"), ("transfo
 DESC_DT = np.dtype([("nodes_offset", "<u4"), ("primitives_offset", "<u4"), ("root_min", "<f4", 3),
                     ("root_max", "<f4", 3)])
 PRIM_DT = np.dtype([("v", "<f4", (3, 3)), ("meta", "<u4")])
+NODE4_DT = np.dtype([("child", "<u4", 4), ("aabb", "<f4", (4, 2, 3)), ("parent", "<u4"), ("child_count", "u1"),
+                     ("primitive_count", "u1"), ("_pad1", "u1"), ("_pad2", "u1")])  # BVHNode4, src/bvh4.jl:40-69
+assert NODE4_DT.itemsize == 120
 assert RAY_DT.itemsize == 32 and HIT_DT.itemsize == 32 and NODE_DT.itemsize == 60
 assert INSTANCE_DT.itemsize == 108 and DESC_DT.itemsize == 32 and PRIM_DT.itemsize == 40
 
@@ -69,6 +72,12 @@ SYMBOLS = [
     ("rc_view_factor_rays_device", _int, [_vp, _u64, _u32, _u32, _u32, _vp, _vp]),
     ("rc_hit_points_device", _int, [_vp, _vp, _vp, _u64, _vp, _vp, _vp]),
     ("rc_shadow_rays_device", _int, [_vp, _vp, _vp, _u64, _vp, C.c_float, _vp, _vp]),
+    ("rc_blas4_build", _int, [_vp, _u32, _pu32]),
+    ("rc_export_blas4_nodes", _int, [_vp, _u32, _vp, _u32, _pu32]),
+    ("rc_trace_closest4", _int, [_vp, _u32, _vp, _vp, _u64]),
+    ("rc_trace_any4", _int, [_vp, _u32, _vp, _vp, _u64]),
+    ("rc_trace_closest4_device", _int, [_vp, _u32, _vp, _vp, _u64, _vp]),
+    ("rc_trace_any4_device", _int, [_vp, _u32, _vp, _vp, _u64, _vp]),
     ("rc_last_kernel_ms", _int, [_vp, _pf]),
 ]
 

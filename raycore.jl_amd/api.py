@@ -353,6 +353,77 @@ def trace_rays(accel, rays):
     return [_tuple_from_hit(t, h, EMPTY_TRIANGLE) for h in t.trace(_as_rays(rays))]
 
 
+class BLAS4:
+    """BLAS4 (src/bvh4.jl:154-162): a 4-wide BVH over ONE geometry, traced in the geometry's own space (the reference has no
+    instanced BVH4 path).  Built by build_blas4; owns a private scene holding the geometry's BVH2 and its collapse."""
+
+    def __init__(self, scene, blas_id, n_nodes):
+        self._scene, self._blas_id, self.num_interior = scene, blas_id, n_nodes  # num_interior = length(nodes4), :521
+        self._prims_cache = None
+
+    @property
+    def nodes(self):
+        out = np.zeros(self.num_interior, dtype=_capi.NODE4_DT)
+        cnt = C.c_uint32(0)
+        check(lib().rc_export_blas4_nodes(self._scene._h, self._blas_id, ptr(out), len(out), C.byref(cnt)))
+        return out
+
+    @property
+    def primitives(self):
+        if self._prims_cache is None:
+            self._prims_cache = self._scene.adapt().all_blas_prims  # one geometry => its Morton-sorted primitives
+        return self._prims_cache
+
+    @property
+    def root_aabb(self):
+        d = self._scene.adapt().blas_descriptors[0]
+        return Bounds3(d["root_min"].copy(), d["root_max"].copy())
+
+    def trace(self, rays, mode="closest"):
+        rays = _as_rays(rays)
+        hits = np.zeros(len(rays), dtype=HIT_DT)
+        fn = lib().rc_trace_closest4 if mode == "closest" else lib().rc_trace_any4
+        check(fn(self._scene._h, self._blas_id, ptr(rays), ptr(hits), len(rays)))
+        return hits
+
+    def trace_device(self, d_rays, d_hits, n, mode="closest", stream=None):
+        fn = lib().rc_trace_closest4_device if mode == "closest" else lib().rc_trace_any4_device
+        check(fn(self._scene._h, self._blas_id, ptr(d_rays), ptr(d_hits), int(n), ptr(stream)))
+
+    def last_kernel_ms(self):
+        return self._scene.last_kernel_ms()
+
+
+def build_blas4(verts, meta=None, device=0):
+    """build_blas4(primitives) (src/bvh4.jl:511-522): LBVH (BVH2) build + collapse to BVH4, both on the device."""
+    scene = TLAS(device)
+    blas_index = scene.add_geometry(verts, meta)
+    scene.push_instances(blas_index)  # identity instance: lets the private scene sync so primitives / root_aabb can be exported
+    n = C.c_uint32(0)
+    check(lib().rc_blas4_build(scene._h, blas_index - 1, C.byref(n)))
+    return BLAS4(scene, blas_index - 1, n.value)
+
+
+def _tuple4(blas, h, miss_prim):
+    if not h["hit"]:
+        return (False, miss_prim, np.float32(0), np.zeros(3, np.float32))
+    p = blas.primitives[h["primitive_id"]]
+    u, v = h["bary_u"], h["bary_v"]
+    w = np.float32(1.0) - u - v  # :681
+    return (True, Triangle(p["v"].copy(), p["meta"]), h["t"], np.array([w, u, v], np.float32))
+
+
+def closest_hit4(blas, ray):
+    """closest_hit4(blas::BLAS4, ray) -> (hit, primitive, distance, barycentric) (src/bvh4.jl:606-689)."""
+    return _tuple4(blas, blas.trace(_as_rays(ray))[0], EMPTY_TRIANGLE)
+
+
+def any_hit4(blas, ray):
+    """any_hit4(blas::BLAS4, ray) (src/bvh4.jl:696-766); the miss dummy is primitives[1] (:763)."""
+    p = blas.primitives[0]
+    return _tuple4(blas, blas.trace(_as_rays(ray), mode="any")[0], Triangle(p["v"].copy(), p["meta"]))
+
+
 def generate_ray_grid(accel, viewdir, grid_size):
     """generate_ray_grid as used by hits_from_grid (src/kernels.jl:10-72), computed on the device; returns RAY_DT rays."""
     import torch

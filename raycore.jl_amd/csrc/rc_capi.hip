@@ -406,6 +406,73 @@ static int trace_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint6
 int rc_trace_closest_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace_device(s, d_rays, d_hits, n, stream, 0); }
 int rc_trace_any_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace_device(s, d_rays, d_hits, n, stream, 1); }
 
+// ---- BVH4 (src/bvh4.jl) ------------------------------------------------------------------------------------------
+static_assert(sizeof(rc_bvh4_node) == 120, "BVHNode4 is 120 bytes");
+
+static Blas& blas4_of(rc_scene* s, uint32_t blas_id) {
+    if (blas_id >= s->blas.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "blas_id out of range");
+    Blas& b = s->blas[blas_id];
+    if (b.n_nodes4 == 0) throw RcError(RC_ERR_NOT_SYNCED, "no BLAS4 for this geometry: call rc_blas4_build first");
+    return b;
+}
+
+int rc_blas4_build(rc_scene* s, uint32_t blas_id, uint32_t* n_nodes) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        if (blas_id >= s->blas.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "blas_id out of range");
+        Blas& b = s->blas[blas_id];
+        RC_HIP(hipEventRecord(s->ev0, s->stream));
+        rc_build_blas4(s, b);
+        RC_HIP(hipEventRecord(s->ev1, s->stream));
+        RC_HIP(hipStreamSynchronize(s->stream));
+        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
+        if (n_nodes) *n_nodes = b.n_nodes4;
+    });
+}
+
+int rc_export_blas4_nodes(rc_scene* s, uint32_t blas_id, rc_bvh4_node* out, uint32_t capacity, uint32_t* count) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        Blas& b = blas4_of(s, blas_id);
+        if (count) *count = b.n_nodes4;
+        if (!out) return;
+        if (capacity < b.n_nodes4) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
+        rc_export_blas4(s, b, out);
+    });
+}
+
+static int trace4_host(rc_scene* s, uint32_t blas_id, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        Blas& b = blas4_of(s, blas_id);
+        if (n == 0) return;
+        if (!rays || !hits) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
+        s->ray_stage.reserve(n);
+        s->hit_stage.reserve(n);
+        RC_HIP(hipMemcpyAsync(s->ray_stage.p, rays, sizeof(RcRay) * n, hipMemcpyHostToDevice, s->stream));
+        rc_launch_trace4(s, b, s->ray_stage.p, s->hit_stage.p, n, any, s->stream);
+        RC_HIP(hipMemcpyAsync(hits, s->hit_stage.p, sizeof(RcHit) * n, hipMemcpyDeviceToHost, s->stream));
+        check_status(s, s->stream);
+        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
+    });
+}
+int rc_trace_closest4(rc_scene* s, uint32_t blas_id, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace4_host(s, blas_id, rays, hits, n, 0); }
+int rc_trace_any4(rc_scene* s, uint32_t blas_id, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace4_host(s, blas_id, rays, hits, n, 1); }
+
+static int trace4_device(rc_scene* s, uint32_t blas_id, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream, int any) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        Blas& b = blas4_of(s, blas_id);
+        rc_launch_trace4(s, b, reinterpret_cast<const RcRay*>(d_rays), reinterpret_cast<RcHit*>(d_hits), n, any, (hipStream_t)stream);
+    });
+}
+int rc_trace_closest4_device(rc_scene* s, uint32_t blas_id, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace4_device(s, blas_id, d_rays, d_hits, n, stream, 0); }
+int rc_trace_any4_device(rc_scene* s, uint32_t blas_id, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace4_device(s, blas_id, d_rays, d_hits, n, stream, 1); }
+
 int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     if (!s || !name) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     std::string k(name);

@@ -37,6 +37,12 @@ __host__ __device__ inline RcNode rc_pack_node(const RcNode& n) {
     return p;
 }
 
+// Traversal record of a BVHNode4 (src/bvh4.jl:40-69), 128 bytes; word layout documented in rc_bvh4.hip.
+struct __attribute__((aligned(128))) RcNode4 {
+    uint32_t w[32];
+};
+static_assert(sizeof(RcNode4) == 128, "RcNode4 must be 128 bytes");
+
 // What the traversal needs of an InstanceDescriptor (src/instanced-bvh.jl:90-96) + its BLASDescriptor
 // (:132-136), folded into one 64-byte record: one aligned fetch per TLAS-leaf entry instead of the
 // reference's 108-byte + 32-byte pair.

@@ -55,6 +55,10 @@ struct Blas {  // one geometry: build_blas output (src/instanced-bvh.jl:111-118)
     uint32_t n_prims = 0;
     uint32_t n_nodes = 0;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    // BLAS4 (src/bvh4.jl:154-162), built on request by rc_blas4_build
+    DevBuf<RcNode4> nodes4;
+    uint32_t n_nodes4 = 0;
+    uint32_t root_word4 = 1;  // root index, leaf bit set when the tree is a single leaf
 };
 
 struct HandleRange {
@@ -115,6 +119,8 @@ struct rc_scene {
     DevBuf<float> f32_stage;
     DevBuf<float> vert_stage;
     DevBuf<uint32_t> meta_stage;
+    DevBuf<uint32_t> c4_tasks_a, c4_tasks_b, c4_gather, c4_totals;  // BVH4 collapse scratch (rc_bvh4.hip)
+    DevBuf<unsigned long long> c4_counts, c4_offsets;
 
     TraceOptions opt;
 };
@@ -128,6 +134,11 @@ void rc_mat3x4_inverse(const float m[12], float out[12]);
 
 // rc_traverse.hip
 void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream);
+
+// rc_bvh4.hip
+void rc_build_blas4(rc_scene* s, Blas& b);                            // build_blas4: collapse of b's BVH2 (src/bvh4.jl:511-522)
+void rc_export_blas4(rc_scene* s, const Blas& b, void* host_out);     // reference-layout BVHNode4 array (120 B each)
+void rc_launch_trace4(rc_scene* s, const Blas& b, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream);
 
 // rc_drivers.hip
 void rc_launch_ray_grid(rc_scene* s, const float viewdir[3], uint32_t grid, RcRay* d_rays, hipStream_t stream);

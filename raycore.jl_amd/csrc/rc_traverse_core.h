@@ -59,6 +59,11 @@ struct LaneStackT {
         else { *status = 1u; return; }
         ++sp;
     }
+    __device__ inline void store(int pos, uint32_t v) {  // write entry `pos` without moving sp (multi-push callers)
+        if (__builtin_expect(pos < LDS_N, 1)) lds[pos * BLOCK] = v;
+        else if (pos < kTotalStack) ovf[(size_t)(pos - LDS_N) * ovf_stride] = v;
+        else *status = 1u;
+    }
     __device__ inline uint32_t pop(int& sp) {
         --sp;
         if (__builtin_expect(sp < LDS_N, 1)) return lds[sp * BLOCK];
