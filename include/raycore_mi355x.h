@@ -235,6 +235,22 @@ int rc_trace_any4(rc_scene* scene, uint32_t blas_id, const rc_ray* rays, rc_hit*
 int rc_trace_closest4_device(rc_scene* scene, uint32_t blas_id, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream);
 int rc_trace_any4_device(rc_scene* scene, uint32_t blas_id, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream);
 
+/* ---- collision broad phase (src/collision.jl) ------------------------------------------------------------------------
+ * rc_contact_pair = ContactPair (:25-28): 1-based instance indices, instance_a < instance_b. */
+typedef struct rc_contact_pair {
+    uint32_t instance_a, instance_b;
+} rc_contact_pair;
+/* collide_instances(tlas) (:189-233) on a synced scene: all pairs of instances whose world AABBs overlap, found by one
+ * TLAS walk per instance on the device (count pass, prefix sum, write pass).  *count receives the number of pairs; they
+ * are written (in the reference algorithm's order) when out != NULL and capacity >= *count, else only counted.
+ * rc_collide_instances copies to a host buffer, _device writes a device buffer on `stream` (the total is read back on
+ * the host either way, as in the reference, :218). */
+int rc_collide_instances(rc_scene* scene, rc_contact_pair* out, uint64_t capacity, uint64_t* count);
+int rc_collide_instances_device(rc_scene* scene, rc_contact_pair* d_out, uint64_t capacity, uint64_t* count, void* stream);
+/* collide_instances_any(tlas, handle_a, handle_b) (:241-261): do any two instances of the two handles overlap (AABB)?
+ * Restated as written: the reference reads instance i's box from TLAS leaf position n-1+i (Morton-sorted order). */
+int rc_collide_instances_any(rc_scene* scene, uint32_t handle_a, uint32_t handle_b, int* overlap);
+
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);

@@ -90,6 +90,9 @@ def lib():
         L.rco_blas4_nodes.restype = u32
         L.rco_blas4_nodes.argtypes = [vp, u32, vp]
         L.rco_trace4_batch.argtypes = [vp, u32, vp, vp, u64, C.c_int, C.c_int, vp]
+        L.rco_collide_instances.restype = u64
+        L.rco_collide_instances.argtypes = [vp, vp, vp]
+        L.rco_collide_instances_any.argtypes = [vp, u32, u32, u32, u32]
         _lib = L
     return _lib
 
@@ -199,6 +202,20 @@ class Scene:
         cnt = np.zeros((len(rays), 2), dtype=np.uint32) if counters else None
         lib().rco_trace4_batch(self._h, blas_index, _p(rays), _p(hits), len(rays), 0 if mode == "closest" else 1, nthreads, _p(cnt))
         return (hits, cnt) if counters else hits
+
+    # ---- collision broad phase (src/collision.jl) ----
+    def collide_instances(self):
+        """-> (contacts (m, 2) uint32 [instance_a, instance_b] 1-based, inclusive prefix counts (n,))"""
+        n = len(self.instances)
+        counts = np.zeros(n, dtype=np.uint32)
+        m = lib().rco_collide_instances(self._h, None, _p(counts))
+        out = np.zeros((m, 2), dtype=np.uint32)
+        if m:
+            lib().rco_collide_instances(self._h, _p(out), None)
+        return out, counts
+
+    def collide_instances_any(self, range_a, range_b):
+        return bool(lib().rco_collide_instances_any(self._h, range_a[0], range_a[1], range_b[0], range_b[1]))
 
     # ---- drivers ----
     def ray_grid(self, viewdir, grid):

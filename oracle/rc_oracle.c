@@ -1122,3 +1122,73 @@ void rco_trace4_batch(rco_scene* s, uint32_t bi, const rco_ray* rays, rco_hit* h
     trace4_ctx c = {b, rays, hits, mode, counters};
     parallel_for(n, nthreads, trace4_range, &c);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Collision broad phase (src/collision.jl)
+ * ---------------------------------------------------------------------------------------------- */
+static inline int aabb_overlaps(v3 a_min, v3 a_max, v3 b_min, v3 b_max) { /* :51-53 */
+    return (a_max.x >= b_min.x && a_max.y >= b_min.y && a_max.z >= b_min.z) &&
+           (a_min.x <= b_max.x && a_min.y <= b_max.y && a_min.z <= b_max.z);
+}
+
+/* collide_instances_kernel! (:81-156) for sorted leaf i (1-based).  contacts == NULL: counting pass. */
+static uint32_t collide_one(const rco_node* nodes, int32_t n_instances, int32_t i, const uint32_t* contact_counts, rco_contact* contacts) {
+    const rco_node* leaf_node = &nodes[(n_instances - 1 + i) - 1];
+    v3 a_min, a_max;
+    node_aabb(leaf_node, leaf_node->child0 != RCO_INVALID_NODE, 1, &a_min, &a_max); /* tlas_node_aabb :56-66 */
+    uint32_t instance_a = leaf_node->child1;
+    uint32_t stack[RCO_STACK];
+    int32_t sp = 0;
+    uint32_t node_index = 1, count = 0;
+    for (;;) {
+        const rco_node* node = &nodes[node_index - 1];
+        if (node->child0 != RCO_INVALID_NODE) {
+            int overlap0 = aabb_overlaps(a_min, a_max, v3_from(node->aabb0_min), v3_from(node->aabb0_max));
+            int overlap1 = aabb_overlaps(a_min, a_max, v3_from(node->aabb1_min), v3_from(node->aabb1_max));
+            if (overlap0 && overlap1) { if (sp < RCO_STACK) stack[sp++] = node->child1; node_index = node->child0; continue; }
+            else if (overlap0) { node_index = node->child0; continue; }
+            else if (overlap1) { node_index = node->child1; continue; }
+        } else {
+            uint32_t instance_b = node->child1;
+            if (instance_b > instance_a) {
+                if (aabb_overlaps(a_min, a_max, v3_from(node->aabb0_min), v3_from(node->aabb0_max))) {
+                    count += 1;
+                    if (contacts) {
+                        uint32_t write_idx = contact_counts[i - 1] - count + 1; /* :135 */
+                        contacts[write_idx - 1].instance_a = instance_a + 1;
+                        contacts[write_idx - 1].instance_b = instance_b + 1;
+                    }
+                }
+            }
+        }
+        if (sp > 0) node_index = stack[--sp]; else break;
+    }
+    return count;
+}
+
+uint64_t rco_collide_instances(const rco_scene* s, rco_contact* out, uint32_t* counts_out) {
+    int32_t n = (int32_t)s->n_inst;
+    if (n == 0) return 0; /* :192-195 */
+    uint32_t* counts = (uint32_t*)calloc((size_t)n, sizeof(uint32_t));
+    for (int32_t i = 1; i <= n; ++i) counts[i - 1] = collide_one(s->nodes, n, i, NULL, NULL);
+    for (int32_t i = 1; i < n; ++i) counts[i] += counts[i - 1]; /* AK.accumulate!(+) :215 */
+    uint64_t total = counts[n - 1];
+    if (out && total) for (int32_t i = 1; i <= n; ++i) collide_one(s->nodes, n, i, counts, out);
+    if (counts_out) memcpy(counts_out, counts, sizeof(uint32_t) * (size_t)n);
+    free(counts);
+    return total;
+}
+
+int rco_collide_instances_any(const rco_scene* s, uint32_t a_first, uint32_t a_count, uint32_t b_first, uint32_t b_count) {
+    uint32_t n = s->n_inst;
+    for (uint32_t ia = a_first + 1; ia <= a_first + a_count; ++ia)
+        for (uint32_t ib = b_first + 1; ib <= b_first + b_count; ++ib) {
+            const rco_node* la = &s->nodes[(n - 1 + ia) - 1]; /* :252-253 */
+            const rco_node* lb = &s->nodes[(n - 1 + ib) - 1];
+            v3 amn, amx, bmn, bmx;
+            node_aabb(la, la->child0 != RCO_INVALID_NODE, 1, &amn, &amx);
+            node_aabb(lb, lb->child0 != RCO_INVALID_NODE, 1, &bmn, &bmx);
+            if (aabb_overlaps(amn, amx, bmn, bmx)) return 1;
+        }
+    return 0;
+}

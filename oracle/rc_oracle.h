@@ -166,6 +166,16 @@ uint32_t rco_blas4_nodes(rco_scene*, uint32_t blas_index, rco_node4* out);
 void rco_trace4_batch(rco_scene*, uint32_t blas_index, const rco_ray* rays, rco_hit* hits, uint64_t n, int mode,
                       int nthreads, uint32_t* counters);
 
+/* ---- collision broad phase (src/collision.jl).  PARITY UNPINNED: no reference test. ------------------ */
+typedef struct { uint32_t instance_a, instance_b; } rco_contact; /* ContactPair (:25-28), 1-based instance indices */
+/* collide_instances (:189-233): pass 1 counts per sorted TLAS leaf, inclusive prefix sum, pass 2 writes each leaf's
+ * pairs back-to-front inside its range (:135).  Returns the number of contacts; writes them when out != NULL and the
+ * inclusive prefix sums (the `cache` buffer, n u32) when counts != NULL. */
+uint64_t rco_collide_instances(const rco_scene*, rco_contact* out, uint32_t* counts);
+/* collide_instances_any (:241-261) for two 0-based instance ranges.  As written in the reference, instance index i is
+ * looked up at TLAS leaf position n-1+i, i.e. in Morton-sorted order, not at the leaf that holds instance i. */
+int rco_collide_instances_any(const rco_scene*, uint32_t a_first, uint32_t a_count, uint32_t b_first, uint32_t b_count);
+
 #ifdef __cplusplus
 }
 #endif

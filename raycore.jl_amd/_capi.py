@@ -78,6 +78,9 @@ SYMBOLS = [
     ("rc_trace_any4", _int, [_vp, _u32, _vp, _vp, _u64]),
     ("rc_trace_closest4_device", _int, [_vp, _u32, _vp, _vp, _u64, _vp]),
     ("rc_trace_any4_device", _int, [_vp, _u32, _vp, _vp, _u64, _vp]),
+    ("rc_collide_instances", _int, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    ("rc_collide_instances_device", _int, [_vp, _vp, _u64, C.POINTER(_u64), _vp]),
+    ("rc_collide_instances_any", _int, [_vp, _u32, _u32, _pint]),
     ("rc_last_kernel_ms", _int, [_vp, _pf]),
 ]
 

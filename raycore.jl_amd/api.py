@@ -353,6 +353,31 @@ def trace_rays(accel, rays):
     return [_tuple_from_hit(t, h, EMPTY_TRIANGLE) for h in t.trace(_as_rays(rays))]
 
 
+ContactPair = namedtuple("ContactPair", ["instance_a", "instance_b"])  # src/collision.jl:25-28 (1-based instance indices)
+CollisionResult = namedtuple("CollisionResult", ["contacts", "num_contacts", "cache"])  # :40-44
+CONTACT_DT = np.dtype([("instance_a", "<u4"), ("instance_b", "<u4")])
+
+
+def collide_instances(tlas, cache=None):
+    """collide_instances(tlas; cache) (src/collision.jl:189-233): all instance pairs with overlapping world AABBs, as a
+    CONTACT_DT array (ContactPair bytes).  `cache` is accepted for signature parity; the library keeps its own buffer."""
+    tlas.sync()
+    n = C.c_uint64(0)
+    check(lib().rc_collide_instances(tlas._h, None, 0, C.byref(n)))
+    out = np.zeros(n.value, dtype=CONTACT_DT)
+    if n.value:
+        check(lib().rc_collide_instances(tlas._h, ptr(out), n.value, C.byref(n)))
+    return CollisionResult(out, int(n.value), cache)
+
+
+def collide_instances_any(tlas, handle_a, handle_b):
+    """collide_instances_any(tlas, handle_a, handle_b) -> Bool (src/collision.jl:241-261)."""
+    tlas.sync()
+    ov = C.c_int(0)
+    check(lib().rc_collide_instances_any(tlas._h, handle_a.id, handle_b.id, C.byref(ov)))
+    return bool(ov.value)
+
+
 class BLAS4:
     """BLAS4 (src/bvh4.jl:154-162): a 4-wide BVH over ONE geometry, traced in the geometry's own space (the reference has no
     instanced BVH4 path).  Built by build_blas4; owns a private scene holding the geometry's BVH2 and its collapse."""

@@ -225,6 +225,8 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
     int sp = 0;
     bool live = false;
     const float tmin = 0.0f;  // closest_hit4 / any_hit4 both start from ray_mint = 0 (:610, :700)
+    float stmin = 0.0f;       // slab-test lower bound: +inf for a ray whose box tests all fail under NaN propagation (box_tests_dead)
+    bool dead = false;
 
     for (;;) {
         for (;;) {
@@ -238,10 +240,10 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                              b4 = buf_f4(nrs, off + 80), b5 = buf_f4(nrs, off + 96);
                 // intersect_all_children4 (:562-599): slots in order, unused slots (child == INVALID) never hit
                 float t0, t1, t2, t3;
-                const bool h0 = slab4(inv, ox, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tmin, cull_t, t0) && ch.x != RC_INVALID_NODE;
-                const bool h1 = slab4(inv, ox, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, tmin, cull_t, t1) && ch.y != RC_INVALID_NODE;
-                const bool h2 = slab4(inv, ox, b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, tmin, cull_t, t2) && ch.z != RC_INVALID_NODE;
-                const bool h3 = slab4(inv, ox, b4.z, b4.w, b5.x, b5.y, b5.z, b5.w, tmin, cull_t, t3) && ch.w != RC_INVALID_NODE;
+                const bool h0 = slab4(inv, ox, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, stmin, cull_t, t0) && ch.x != RC_INVALID_NODE;
+                const bool h1 = slab4(inv, ox, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, stmin, cull_t, t1) && ch.y != RC_INVALID_NODE;
+                const bool h2 = slab4(inv, ox, b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, stmin, cull_t, t2) && ch.z != RC_INVALID_NODE;
+                const bool h3 = slab4(inv, ox, b4.z, b4.w, b5.x, b5.y, b5.z, b5.w, stmin, cull_t, t3) && ch.w != RC_INVALID_NODE;
                 // position of each hit child after the reference's stable insertion sort by entry distance (:590-596):
                 // hits from earlier slots with t <= mine and from later slots with t < mine come first
                 const int r0 = (int)(h1 && t1 < t0) + (int)(h2 && t2 < t0) + (int)(h3 && t3 < t0);
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                                  !(u < 0.0f || u > 1.0f) && !(v < 0.0f || (u + v) > 1.0f) && !(t < tmin || t > closest_t);
                 closest_prim = hit ? prim_idx : closest_prim;
                 closest_t = hit ? t : closest_t;
-                cull_t = hit ? ((t != t) ? -INFINITY : t) : cull_t;
+                cull_t = hit ? slab_cull(dead, t) : cull_t;
                 hit_u = hit ? u : hit_u;
                 hit_v = hit ? v : hit_v;
                 if (ANY && hit) node = RC_INVALID_NODE;  // :744-749
@@ -339,7 +341,9 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                         inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
                         ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
                         closest_t = r.tmax;
-                        cull_t = (r.tmax != r.tmax) ? -INFINITY : r.tmax;
+                        dead = box_tests_dead(ox, tmin);
+                        cull_t = slab_cull(dead, closest_t);
+                        stmin = slab_tmin(dead, tmin);
                         hit_u = hit_v = 0.0f;
                         closest_prim = RC_INVALID_NODE;
                         sp = 0;

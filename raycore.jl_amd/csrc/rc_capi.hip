@@ -473,6 +473,56 @@ static int trace4_device(rc_scene* s, uint32_t blas_id, const rc_ray* d_rays, rc
 int rc_trace_closest4_device(rc_scene* s, uint32_t blas_id, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace4_device(s, blas_id, d_rays, d_hits, n, stream, 0); }
 int rc_trace_any4_device(rc_scene* s, uint32_t blas_id, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace4_device(s, blas_id, d_rays, d_hits, n, stream, 1); }
 
+// ---- collision broad phase (src/collision.jl) --------------------------------------------------------------------
+static_assert(sizeof(rc_contact_pair) == sizeof(uint2), "ContactPair is two u32");
+
+int rc_collide_instances_device(rc_scene* s, rc_contact_pair* d_out, uint64_t capacity, uint64_t* count, void* stream) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        const uint64_t total = rc_collide_instances_launch(s, reinterpret_cast<uint2*>(d_out), capacity, (hipStream_t)stream);
+        if (count) *count = total;
+    });
+}
+
+int rc_collide_instances(rc_scene* s, rc_contact_pair* out, uint64_t capacity, uint64_t* count) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        uint64_t total = rc_collide_instances_launch(s, nullptr, 0, s->stream);
+        if (count) *count = total;
+        if (!out || total == 0) return;
+        if (capacity < total) throw RcError(RC_ERR_INVALID_ARGUMENT, "contact buffer too small");
+        s->contact_stage.reserve(total);
+        total = rc_collide_instances_launch(s, s->contact_stage.p, total, s->stream);
+        RC_HIP(hipMemcpyAsync(out, s->contact_stage.p, sizeof(uint2) * total, hipMemcpyDeviceToHost, s->stream));
+        check_status(s, s->stream);
+        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
+    });
+}
+
+int rc_collide_instances_any(rc_scene* s, uint32_t handle_a, uint32_t handle_b, int* overlap) {
+    if (!s || !overlap) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        const HandleRange ra = live_range(s, handle_a), rb = live_range(s, handle_b);
+        const uint32_t n = s->n_static_instances;
+        *overlap = 0;
+        if (n == 0) return;
+        // "Small download for TLAS nodes" (:247): the leaves only
+        std::vector<RcNode> leaves(n);
+        RC_HIP(hipMemcpy(leaves.data(), s->tlas_nodes.p + (n - 1), sizeof(RcNode) * n, hipMemcpyDeviceToHost));
+        for (uint32_t ia = ra.first; ia < ra.first + ra.count; ++ia)
+            for (uint32_t ib = rb.first; ib < rb.first + rb.count; ++ib) {
+                const float* a = leaves[ia].f; const float* b = leaves[ib].f;  // leaf position n-1+i (1-based) = leaves[i-1]
+                if ((a[3] >= b[0] && a[4] >= b[1] && a[5] >= b[2]) && (a[0] <= b[3] && a[1] <= b[4] && a[2] <= b[5])) { *overlap = 1; return; }
+            }
+    });
+}
+
 int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     if (!s || !name) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     std::string k(name);

@@ -121,6 +121,8 @@ struct rc_scene {
     DevBuf<uint32_t> meta_stage;
     DevBuf<uint32_t> c4_tasks_a, c4_tasks_b, c4_gather, c4_totals;  // BVH4 collapse scratch (rc_bvh4.hip)
     DevBuf<unsigned long long> c4_counts, c4_offsets;
+    DevBuf<uint32_t> collide_counts;  // collide_instances' per-leaf counts / prefix sums (the reference's `cache`)
+    DevBuf<uint2> contact_stage;
 
     TraceOptions opt;
 };
@@ -139,6 +141,9 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
 void rc_build_blas4(rc_scene* s, Blas& b);                            // build_blas4: collapse of b's BVH2 (src/bvh4.jl:511-522)
 void rc_export_blas4(rc_scene* s, const Blas& b, void* host_out);     // reference-layout BVHNode4 array (120 B each)
 void rc_launch_trace4(rc_scene* s, const Blas& b, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream);
+
+// rc_collision.hip
+uint64_t rc_collide_instances_launch(rc_scene* s, uint2* d_out, uint64_t capacity, hipStream_t stream);
 
 // rc_drivers.hip
 void rc_launch_ray_grid(rc_scene* s, const float viewdir[3], uint32_t grid, RcRay* d_rays, hipStream_t stream);

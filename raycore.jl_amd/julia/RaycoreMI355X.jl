@@ -209,4 +209,30 @@ function Raycore.view_factors(a::MI355XStaticTLAS; rays_per_triangle = 10000, se
     return out
 end
 
+# ---- BVH4 (src/bvh4.jl): BLAS-level 4-wide tree, collapsed on the device ------------------------------------
+struct MI355XBLAS4
+    scene::MI355XTLAS            # private scene holding the geometry
+    blas_id::UInt32
+    num_interior::Int32          # length(nodes), as build_blas4 stores it (:521)
+end
+function build_blas4_mi355x(backend::MI355XBackend, mesh::GeometryBasics.Mesh)                   # build_blas4, :511-522
+    t = MI355XTLAS(backend)
+    verts, meta = triangle_soup(mesh)
+    id = Ref{UInt32}(0); n = Ref{UInt32}(0)
+    check(ccall((:rc_add_blas, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{UInt32}, UInt32, Ref{UInt32}), t.ptr, verts, meta, length(meta), id))
+    check(ccall((:rc_blas4_build, LIB), Cint, (Ptr{Cvoid}, UInt32, Ref{UInt32}), t.ptr, id[], n))
+    return MI355XBLAS4(t, id[], Int32(n[]))
+end
+function nodes(b::MI355XBLAS4)                                                                  # Vector{BVHNode4}, 120 B each (:40-69)
+    out = Vector{Raycore.BVHNode4}(undef, b.num_interior)
+    check(ccall((:rc_export_blas4_nodes, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{Cvoid}, UInt32, Ptr{UInt32}), b.scene.ptr, b.blas_id, out, length(out), C_NULL))
+    return out
+end
+function trace4(b::MI355XBLAS4, rays::Vector{RTRay}; any::Bool = false)                         # closest_hit4 :606-689 / any_hit4 :696-766 over a batch
+    hits = Vector{RTHitResult}(undef, length(rays))
+    f = any ? :rc_trace_any4 : :rc_trace_closest4
+    check(ccall((f, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{RTRay}, Ptr{RTHitResult}, UInt64), b.scene.ptr, b.blas_id, rays, hits, length(rays)))
+    return hits     # (hit, primitives[primitive_id + 1], t, (1 - u - v, u, v)) per ray; no instance index at this level
+end
+
 end # module

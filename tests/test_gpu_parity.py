@@ -258,8 +258,7 @@ def test_trace_edge_cases(rc, oracle):
 def test_weird_rays_and_scales(rc, oracle):
     """Inputs outside the comfortable range, still required to match the oracle bit for bit: zero / infinite / tiny
     direction components (safe_invdir clamps, :1742-1748), t_max < t_min, negative t_min, huge and tiny coordinates,
-    NaN-free but extreme rays.  (Rays with NaN components are excluded: the reference's behaviour there is whatever
-    Julia's NaN-propagating min/max happen to produce and is not part of the parity domain)"""
+    NaN-free but extreme rays (NaN / Inf rays: test_nan_and_inf_rays)."""
     sc = rc.scenes
     xf, _, _ = sc.lattice_transforms(2, 2, 2, 2.0, 5)
     xf[3, [0, 5, 10]] *= 1e3      # a huge instance
@@ -295,6 +294,41 @@ def test_weird_rays_and_scales(rc, oracle):
         assert_hits_equal(got_c, want_c, f"weird closest k{kern}")
         assert_hits_equal(got_a, want_a, f"weird any k{kern}")
         assert ok.any()
+
+
+def test_nan_and_inf_rays(rc, oracle):
+    """Rays with NaN / Inf components.  Under Julia's NaN-propagating min/max a NaN slab component fails every box test of
+    that level, while a triangle reached without a box test (single-leaf TLAS / BLAS) is 'hit' with NaN t (all comparisons
+    false).  The kernels reproduce both (box_tests_dead, rc_traverse_core.h)."""
+    sc = rc.scenes
+    xf, _, _ = sc.lattice_transforms(2, 2, 1, 2.0, 9)
+    multi = {"blas": [(sc.fan_sphere(10, 6, radius=0.6), None)], "instances": [(1, xf, np.arange(4, dtype=np.uint32))]}
+    single = {"blas": [(UNIT_TRI, [7])], "instances": [(1, sc.IDENTITY3x4[None], np.array([3], np.uint32))]}  # TLAS root and BLAS root are leaves
+    rot = sc.IDENTITY3x4.copy()
+    rot[[0, 1, 4, 5]] = [0.0, -1.0, 1.0, 0.0]  # 90 degrees about z: zeros in the matrix meet Inf components => NaN after the transform
+    two = {"blas": [(UNIT_TRI, [1])], "instances": [(1, np.stack([sc.IDENTITY3x4, rot]), np.array([0, 1], np.uint32))]}
+    g = sc.rng(5)
+    n = 6000
+    rays = sc.make_rays(g.uniform(-1, 3, size=(n, 3)), sc.normalize(g.normal(size=(n, 3))))
+    rays["o"][:n // 2] = [0.25, 0.25, 1.0]
+    rays["d"][:n // 2] = [0.0, 0.0, -1.0]
+    bad = [np.nan, np.inf, -np.inf]
+    for i in range(0, n, 3):
+        f = ("o", "d")[(i // 3) % 2]
+        rays[f][i, (i // 6) % 3] = bad[(i // 18) % 3]
+    rays["tmin"][1::12] = np.nan
+    rays["tmax"][2::12] = np.nan
+    rays["tmax"][5::12] = np.inf
+    rays["tmin"][8::12] = -np.inf
+    for name, cfg in (("multi", multi), ("single", single), ("two", two)):
+        t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+        want_c, want_a = o.trace(rays, nthreads=4), o.trace(rays, mode="any", nthreads=4)
+        for kern in (0, 1, 2, 3, 4):
+            t.set_option("kernel", kern)
+            assert_hits_equal(t.trace(rays), want_c, f"nan {name} closest k{kern}")
+            assert_hits_equal(t.trace(rays, mode="any"), want_a, f"nan {name} any k{kern}")
+        if name == "single":
+            assert np.isnan(want_c["t"][want_c["hit"] == 1]).any()  # NaN-t hits exist and are reproduced bit for bit
 
 
 def test_deep_trees_use_the_stack_spill_path(rc, oracle):
