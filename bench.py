@@ -253,9 +253,9 @@ def main():
             "config": {"workload": "C3: TLAS of 256 rotated/scaled instances of one 4096-triangle BLAS (1 048 576 triangles), "
                                    f"{n} pinhole primary rays per GPU per step, closest_hit",
                        "triangles": int(n_tris), "rays_per_step_per_gpu": n, "hit_fraction": round(hit_frac, 4),
-                       "kernel": {-1: "auto (phased persistent)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
+                       "kernel": {-1: "auto (phased persistent, TLAS in LDS)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased", 4: "phased + TLAS/instances in LDS", 5: "phased + TLAS in LDS"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": "k_trace_phased<false, 24, 6, false>" if t.get_option("kernel") in (-1, 3) else f"kernel option {t.get_option('kernel')}", "avg_launch_ms": round(launch_ms, 4),
+                         "traffic": traffic, "kernel": {-1: "k_trace_phased_lds<false, 768, 16, false, 6>", 5: "k_trace_phased_lds<false, 768, 16, false, 6>", 3: "k_trace_phased<false, 24, 6, false>"}.get(t.get_option("kernel"), f"kernel option {t.get_option('kernel')}"), "avg_launch_ms": round(launch_ms, 4),
                          "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3)},
             "cpu_baseline": cpu_baseline,
             "extras": extras,

@@ -66,7 +66,7 @@ struct HandleRange {
 };
 
 struct TraceOptions {
-    int64_t kernel = -1;       // -1 = auto, 0 = one-ray-per-lane, 1 = persistent wave-refill, 2 = persistent + voted path scheduling, 3 = persistent + phased (while-while), 4 = 3 with the TLAS staged in LDS (<= 256 instances)
+    int64_t kernel = -1;       // -1 = auto, 0 = one-ray-per-lane, 1 = persistent wave-refill, 2 = persistent + voted path scheduling, 3 = persistent + phased (while-while), 4 = 3 with the TLAS + instance records staged in LDS (1024-thread blocks, <= 256 instances), 5 = 3 with the TLAS staged in LDS at 24 waves/CU (2 x 768 threads)
     int64_t blocks_per_cu = 0; // 0 = derive from the LDS stack depth
     int64_t lds_stack = 24;    // per-lane stack entries kept in LDS: 12, 16, 24 or 32
     int64_t pool = 0;          // persistent kernels: ray indices per atomic claim (0 = auto 64..512)

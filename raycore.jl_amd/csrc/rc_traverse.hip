@@ -12,7 +12,7 @@
 // with a global spill area for the rare deep path, persistent waves that refill finished lanes from a global ray
 // counter (ballot + mbcnt prefix sums), and phase-structured execution so a wave only issues the block its lanes
 // actually need.  Kernel variants (rc_set_option "kernel"): 0 simple, 1 persistent, 2 voted scheduling, 3 phased
-// (default; core in rc_traverse_core.h), 4 phased with the TLAS staged in LDS.  All return identical results.
+// (core in rc_traverse_core.h), 4 / 5 phased with the TLAS staged in LDS (5 = default when the TLAS fits).  All return identical results.
 #include <algorithm>
 
 #include "rc_traverse_core.h"
@@ -118,22 +118,29 @@ constexpr size_t kBigStackBytes = (size_t)kLdsStack * kBigBlock * 4;
 constexpr size_t kTlasPlaneBytes = (size_t)7 * kTlasLdsNodes * sizeof(float2);
 constexpr size_t kBigLdsBytes = kBigStackBytes + kTlasPlaneBytes + (size_t)kTlasLdsInst * 64;
 
-template <bool ANY>
-__global__ __launch_bounds__(kBigBlock) void k_trace_phased_lds(TraceArgs a) {
+// BLOCK threads per workgroup, LDS_N stack entries per lane in LDS, INST_LDS: instance records staged too.
+// kernel 4 = <1024, 24, true> (one workgroup per CU); kernel 5 = <768, 16, false>: two workgroups per CU keep the 24 waves
+// per CU of kernel 3 (the shallower LDS stack costs < 2 %, measured) while the TLAS still comes from LDS.
+template <bool ANY, int BLOCK, int LDS_N, bool INST_LDS, int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr size_t stack_bytes = (size_t)LDS_N * BLOCK * 4;
     uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem);
-    float2* tl = reinterpret_cast<float2*>(smem + kBigStackBytes);
-    float4* il = reinterpret_cast<float4*>(smem + kBigStackBytes + kTlasPlaneBytes);
+    float2* tl = reinterpret_cast<float2*>(smem + stack_bytes);
+    float4* il = reinterpret_cast<float4*>(smem + stack_bytes + kTlasPlaneBytes);
     const RcNode* tnodes = a.v.blas_nodes + a.v.tlas_off;
-    for (uint32_t i = threadIdx.x; i < a.v.n_tlas_nodes * 7u; i += kBigBlock) {
+    for (uint32_t i = threadIdx.x; i < a.v.n_tlas_nodes * 7u; i += BLOCK) {
         const uint32_t nd = i / 7u, p = i % 7u;
         tl[p * kTlasLdsNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
     }
-    for (uint32_t i = threadIdx.x; i < a.v.n_inst * 4u; i += kBigBlock) il[i] = reinterpret_cast<const float4*>(a.v.inst)[i];
+    if (INST_LDS)
+        for (uint32_t i = threadIdx.x; i < a.v.n_inst * 4u; i += BLOCK) il[i] = reinterpret_cast<const float4*>(a.v.inst)[i];
     __syncthreads();
     PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats};
-    phased_trace<ANY, kLdsStack, false, ArraySource, HitWriter, kBigBlock, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, tl, il);
+    phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, INST_LDS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, tl, il);
 }
+constexpr int kMidBlock = 768, kMidStack = 16;
+constexpr size_t kMidLdsBytes = (size_t)kMidStack * kMidBlock * 4 + kTlasPlaneBytes;
 
 // ---- kernel 2: persistent waves + per-wave path scheduling --------------------------------------------
 // Kernel 1 runs the reference's three-way loop body as written, so a wave executes the interior-node,
@@ -424,12 +431,23 @@ static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hip
     if (s->opt.kernel == 4) {
         static bool attr_set[2] = {false, false};
         if (!attr_set[ANY ? 1 : 0]) {
-            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes));
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kBigBlock, kLdsStack, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes));
             attr_set[ANY ? 1 : 0] = true;
         }
-        hipLaunchKernelGGL((k_trace_phased_lds<ANY>), dim3(blocks), dim3(kBigBlock), kBigLdsBytes, stream, a);
+        hipLaunchKernelGGL((k_trace_phased_lds<ANY, kBigBlock, kLdsStack, true, 4>), dim3(blocks), dim3(kBigBlock), kBigLdsBytes, stream, a);
+    } else if (s->opt.kernel == 5) {
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[ANY ? 1 : 0]) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, false, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
+            attr_set[ANY ? 1 : 0] = true;
+        }
+        hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, false, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
     } else if (s->opt.kernel == 3) {
         if (stats) hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        else if (lds == 16) hipLaunchKernelGGL((k_trace_phased<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        else if (lds == 20) hipLaunchKernelGGL((k_trace_phased<ANY, 20, 7, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        else if (lds == 17) hipLaunchKernelGGL((k_trace_phased<ANY, 16, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        else if (lds == 13) hipLaunchKernelGGL((k_trace_phased<ANY, 12, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
     } else if (s->opt.kernel == 2) {
         if (stats) hipLaunchKernelGGL((k_trace_sched<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
@@ -448,7 +466,7 @@ static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hip
 
 uint32_t rc_blocks_per_cu(rc_scene* s) {
     if (s->opt.blocks_per_cu > 0) return (uint32_t)s->opt.blocks_per_cu;
-    switch (s->opt.lds_stack) { case 12: case 16: return 8; case 32: return 4; default: return 6; }
+    switch (s->opt.lds_stack) { case 12: case 16: return 8; case 20: return 7; case 32: return 4; default: return 6; }
 }
 
 void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream) {
@@ -457,12 +475,18 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     uint32_t total_threads = blocks * kBlock;
     const int64_t saved_kernel = s->opt.kernel;
-    if (saved_kernel < 0) s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : 3;  // auto: tiny batches gain nothing from refilling
+    if (saved_kernel < 0)  // auto: tiny batches gain nothing from refilling; a TLAS that fits the LDS planes (<= 256 instances) is read from there
+        s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 3);
     if (s->opt.kernel == 4 && (s->n_tlas_nodes > (uint32_t)kTlasLdsNodes || s->n_static_instances > (uint32_t)kTlasLdsInst)) s->opt.kernel = 3;
+    if (s->opt.kernel == 5 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes) s->opt.kernel = 3;
     if (s->opt.kernel >= 3 && (uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32)) s->opt.kernel = 1;  // buffer offsets are 32-bit
     if (s->opt.kernel == 4) {  // one 1024-thread workgroup per CU
         blocks = (uint32_t)std::min<uint64_t>((n + kBigBlock - 1) / kBigBlock, (uint64_t)s->n_cus);
         total_threads = blocks * kBigBlock;
+    }
+    if (s->opt.kernel == 5) {  // two 768-thread workgroups per CU
+        blocks = (uint32_t)std::min<uint64_t>((n + kMidBlock - 1) / kMidBlock, (uint64_t)s->n_cus * 2);
+        total_threads = blocks * kMidBlock;
     }
     rc_prepare_launch(s, stream);
     TraceArgs a;

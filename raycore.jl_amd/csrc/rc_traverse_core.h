@@ -293,12 +293,14 @@ typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
-__device__ inline float4 buf_f4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+// `soff` goes into the instruction's scalar-offset operand: the 16/32/48-byte pieces of one record share a single per-lane
+// byte offset register instead of costing a v_add each.
+__device__ inline float4 buf_f4(__amdgpu_buffer_rsrc_t r, uint32_t off, int soff = 0) {
+    u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-__device__ inline float2 buf_f2(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    u2v v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+__device__ inline float2 buf_f2(__amdgpu_buffer_rsrc_t r, uint32_t off, int soff = 0) {
+    u2v v = __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0);
     return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
 }
 
@@ -321,7 +323,7 @@ struct PersistArgs {
 constexpr int kTlasLdsNodes = 512;
 constexpr int kTlasLdsInst = 256;
 
-template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false>
+template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS>
 __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
                                     const float2* tl = nullptr, const float4* il = nullptr) {
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
@@ -333,7 +335,8 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     }
     const uint32_t n_instances = (av.n_tlas_nodes + 1u) >> 1;
     const uint32_t tlas_off = av.tlas_off;
-    const __amdgpu_buffer_rsrc_t nrs = make_rsrc(av.blas_nodes, av.n_nodes_total * 64u);
+    // the node array addressed by 1-based node index: the base sits one record before element 0 (never dereferenced: index 0 is not a node)
+    const __amdgpu_buffer_rsrc_t nrs1 = make_rsrc(reinterpret_cast<const char*>(av.blas_nodes) - 64, (av.n_nodes_total + 1u) * 64u);
     const __amdgpu_buffer_rsrc_t irs = make_rsrc(av.inst, av.n_inst * 64u);
     unsigned long long pool_next = 0, pool_end = 0;
     bool exhausted = false;
@@ -365,9 +368,9 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                     na = make_float4(p0.x, p0.y, p1.x, p1.y); nb = make_float4(p2.x, p2.y, p3.x, p3.y); nc = make_float4(p4.x, p4.y, p5.x, p5.y);
                     ch = u2v{__float_as_uint(p6.x), __float_as_uint(p6.y)};
                 } else {
-                    const uint32_t off = (cur_off + node - 1u) << 6;
-                    na = buf_f4(nrs, off); nb = buf_f4(nrs, off + 16); nc = buf_f4(nrs, off + 32);
-                    ch = __builtin_amdgcn_raw_buffer_load_b64(nrs, off + 48, 0, 0);
+                    const uint32_t off = (cur_off + node) << 6;  // the record of 1-based node index `node`: rsrc base is one record early
+                    na = buf_f4(nrs1, off); nb = buf_f4(nrs1, off, 16); nc = buf_f4(nrs1, off, 32);
+                    ch = __builtin_amdgcn_raw_buffer_load_b64(nrs1, off, 48, 0);
                 }
                 // packed node (rc_pack_node): na = child-0 (min.x,min.y,max.x,max.y), nb = child-1 likewise, nc = z of both
                 const v2f ixy = {inv.x, inv.y}, oxy = {ox.x, ox.y}, izz = {inv.z, inv.z}, ozz = {ox.z, ox.z};
@@ -380,12 +383,14 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 const float t0_min = fmaxf(fmaxf(fmaxf(fminf(f0x, n0x), fminf(f0y, n0y)), fminf(f0z, n0z)), stmin);
                 const float t1_max = fminf(fminf(fminf(fmaxf(f1x, n1x), fmaxf(f1y, n1y)), fmaxf(f1z, n1z)), cull_t);
                 const float t1_min = fmaxf(fmaxf(fmaxf(fminf(f1x, n1x), fminf(f1y, n1y)), fminf(f1z, n1z)), stmin);
-                const uint32_t trav0 = (t0_min <= t0_max) ? ch.x : RC_INVALID_NODE;
-                const uint32_t trav1 = (t1_min <= t1_max) ? ch.y : RC_INVALID_NODE;
-                const bool first0 = (t0_min < t1_min) && (trav0 != RC_INVALID_NODE);
-                const uint32_t near_c = first0 ? trav0 : trav1, far_c = first0 ? trav1 : trav0;
-                if (far_c != RC_INVALID_NODE) st.push(sp, far_c);
-                node = (near_c != RC_INVALID_NODE) ? near_c : st.pop(sp);
+                // intersect_internal_node's INVALID-or-child values, kept as predicates (an interior node has two valid children):
+                // traverse0 = h0 ? child0 : INVALID, traverse1 likewise; near first iff t0_min < t1_min && traverse0 valid
+                const bool h0 = t0_min <= t0_max, h1 = t1_min <= t1_max;
+                const bool first0 = (t0_min < t1_min) & h0;
+                const uint32_t near_c = first0 ? ch.x : ch.y, far_c = first0 ? ch.y : ch.x;
+                const bool near_ok = first0 | h1, far_ok = h0 & (h1 | !first0);  // = first0 ? h1 : h0 (first0 implies h0), as lane-mask logic
+                if (far_ok) st.push(sp, far_c);
+                node = near_ok ? near_c : st.pop(sp);
             }
             if (n_int < a.int_thr) break;  // too few interior lanes left: serve the waiting ones first
         }
@@ -394,10 +399,10 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             const bool is_leaf = cur_inst >= 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
             if (STATS && __ballot(is_leaf)) { st_iter[2] += 1; st_lane[2] += is_leaf ? 1 : 0; }
             if (is_leaf) {
-                const uint32_t off = (cur_off + node - 1u) << 6;
-                const float4 na = buf_f4(nrs, off);
-                const float2 nb = buf_f2(nrs, off + 16);
-                const float4 nc = buf_f4(nrs, off + 32);
+                const uint32_t off = (cur_off + node) << 6;
+                const float4 na = buf_f4(nrs1, off);
+                const float2 nb = buf_f2(nrs1, off, 16);
+                const float4 nc = buf_f4(nrs1, off, 32);
                 const float3_ v0 = mk3(na.x, na.y, nc.x), v1 = mk3(na.z, na.w, nc.y), v2 = mk3(nb.x, nb.y, nc.z);  // packed order
                 const float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
                 const float3_ s1 = cross3(d, e2);
@@ -436,17 +441,17 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             } else if (is_entry) {
                 float4 m0, m1, m2;
                 u4v m3;
-                if (TLAS_LDS) {
-                    cur_inst = (int)__float_as_uint(tl[6 * kTlasLdsNodes + (node - 1u)].y);  // child1
+                if (TLAS_LDS) cur_inst = (int)__float_as_uint(tl[6 * kTlasLdsNodes + (node - 1u)].y);  // child1
+                else cur_inst = (int)__builtin_amdgcn_raw_buffer_load_b32(nrs1, (cur_off + node) << 6, 52, 0);
+                if (INST_LDS) {
                     const float4* q = il + 4 * cur_inst;
                     m0 = q[0]; m1 = q[1]; m2 = q[2];
                     const float4 w = q[3];
                     m3 = u4v{__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
                 } else {
-                    cur_inst = (int)__builtin_amdgcn_raw_buffer_load_b32(nrs, ((cur_off + node - 1u) << 6) + 52u, 0, 0);  // child1
                     const uint32_t ioff = (uint32_t)cur_inst << 6;
-                    m0 = buf_f4(irs, ioff); m1 = buf_f4(irs, ioff + 16); m2 = buf_f4(irs, ioff + 32);
-                    m3 = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff + 48, 0, 0);
+                    m0 = buf_f4(irs, ioff); m1 = buf_f4(irs, ioff, 16); m2 = buf_f4(irs, ioff, 32);
+                    m3 = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff, 48, 0);
                 }
                 st.push(sp, RC_TOP_LEVEL_SENTINEL);
                 node = 1;

@@ -246,7 +246,7 @@ def test_trace_edge_cases(rc, oracle):
             os_.append([x, 0.5, 0.0]); ds.append([1.0, 0.0, 0.0])      # in the plane of the quad
     rays = rc.scenes.make_rays(os_, ds)
     want = o.trace(rays)
-    for k in (0, 1, 2, 3, 4):
+    for k in (0, 1, 2, 3, 4, 5):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(rays), want, f"edge closest k{k}")
         assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any"), f"edge any k{k}")
@@ -287,7 +287,7 @@ def test_weird_rays_and_scales(rc, oracle):
     rays["d"][9 * k + 50:9 * k + 100] = [np.inf, 0.0, 0.0]
     want_c, want_a = o.trace(rays, nthreads=8), o.trace(rays, mode="any", nthreads=8)
     assert 0 < want_c["hit"].sum() < n
-    for kern in (0, 1, 2, 3, 4):
+    for kern in (0, 1, 2, 3, 4, 5):
         t.set_option("kernel", kern)
         got_c, got_a = t.trace(rays), t.trace(rays, mode="any")
         ok = ~(np.isnan(want_c["t"]) | np.isnan(got_c["t"]))  # NaN != NaN bitwise is fine to compare too, but keep ids strict
@@ -323,7 +323,7 @@ def test_nan_and_inf_rays(rc, oracle):
     for name, cfg in (("multi", multi), ("single", single), ("two", two)):
         t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
         want_c, want_a = o.trace(rays, nthreads=4), o.trace(rays, mode="any", nthreads=4)
-        for kern in (0, 1, 2, 3, 4):
+        for kern in (0, 1, 2, 3, 4, 5):
             t.set_option("kernel", kern)
             assert_hits_equal(t.trace(rays), want_c, f"nan {name} closest k{kern}")
             assert_hits_equal(t.trace(rays, mode="any"), want_a, f"nan {name} any k{kern}")
@@ -385,7 +385,7 @@ def test_full_size_c2_properties(rc, oracle):
     perm = rc.scenes.rng(5).permutation(len(rays))
     assert_hits_equal(t.trace(rays[perm]), got[perm], "C2 permuted")
     # every kernel variant agrees
-    for k in (0, 1, 2, 3, 4):
+    for k in (0, 1, 2, 3, 4, 5):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(rays), got, f"C2 kernel {k}")
         assert np.array_equal(t.trace(rays, mode="any")["hit"], got["hit"])

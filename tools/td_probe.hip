@@ -56,6 +56,40 @@ __global__ __launch_bounds__(1024) void k_gather_lds(const float4* table, unsign
     out[blockIdx.x * 1024 + threadIdx.x] = acc;
 }
 
+// LDS with the records split into planes: plane k holds chunk k of every record, so lanes reading chunk k of different
+// records hit addresses 16 (or 8) bytes apart per record index instead of 64: 16 (32) distinct bank groups instead of 4.
+template <int CHUNK_FLOATS>
+__global__ __launch_bounds__(1024) void k_gather_lds_planes(const float4* table, unsigned mask, int active, int iters, float* out) {
+    extern __shared__ float4 cache[];
+    const unsigned n = mask + 1;
+    float* cf = reinterpret_cast<float*>(cache);
+    const float* tf = reinterpret_cast<const float*>(table);
+    constexpr int PLANES = 16 / CHUNK_FLOATS;
+    for (unsigned i = threadIdx.x; i < n * 16; i += 1024) {
+        const unsigned rec = i / 16, w = i % 16, plane = w / CHUNK_FLOATS, e = w % CHUNK_FLOATS;
+        cf[(plane * n + rec) * CHUNK_FLOATS + e] = tf[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned idx = (blockIdx.x * 1024 + threadIdx.x) * 2654435761u;
+    float acc = 0.f;
+    if (lane < active) {
+        for (int i = 0; i < iters; ++i) {
+            idx = idx * 1664525u + 1013904223u;
+            const unsigned rec = (idx >> 8) & mask;
+            if (CHUNK_FLOATS == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { float4 v = cache[k * n + rec]; acc += v.x + v.w; }
+            } else {
+                const float2* c2 = reinterpret_cast<const float2*>(cache);
+#pragma unroll
+                for (int k = 0; k < PLANES; ++k) { float2 v = c2[k * n + rec]; acc += v.x + v.y; }
+            }
+        }
+    }
+    out[blockIdx.x * 1024 + threadIdx.x] = acc;
+}
+
 int main() {
     const int iters = 2000;
     float4* table; float* out;
@@ -98,6 +132,28 @@ int main() {
         double waves = 256.0 * 16, insts = waves * iters * 4;
         printf("LDS 64 KB active %2d: %.3f ms -> %.1f clk/CU per ds_read_b128, %.1f GB/s useful\n", active, ms, ms * 1e-3 * 2.1e9 * 256 / insts,
                waves * iters * active * 64.0 / (ms * 1e-3) / 1e9);
+    }
+    for (int active : {64, 48, 40, 32, 16, 8}) {
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_gather_lds_planes<4>, dim3(256), dim3(1024), 64 * 1024, 0, table, 1023u, active, iters, out);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        }
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double waves = 256.0 * 16, insts = waves * iters * 4;
+        printf("LDS float4 planes active %2d: %.3f ms -> %.1f clk/CU per ds_read_b128 (%.1f per 64-B record)\n", active, ms, ms * 1e-3 * 2.1e9 * 256 / insts,
+               ms * 1e-3 * 2.1e9 * 256 / insts * 4);
+    }
+    for (int active : {64, 40, 16}) {
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_gather_lds_planes<2>, dim3(256), dim3(1024), 64 * 1024, 0, table, 1023u, active, iters, out);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        }
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double waves = 256.0 * 16, insts = waves * iters * 8;
+        printf("LDS float2 planes active %2d: %.3f ms -> %.1f clk/CU per ds_read_b64 (%.1f per 64-B record)\n", active, ms, ms * 1e-3 * 2.1e9 * 256 / insts,
+               ms * 1e-3 * 2.1e9 * 256 / insts * 8);
     }
     return 0;
 }
