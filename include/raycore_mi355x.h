@@ -251,6 +251,28 @@ int rc_collide_instances_device(rc_scene* scene, rc_contact_pair* d_out, uint64_
  * Restated as written: the reference reads instance i's box from TLAS leaf position n-1+i (Morton-sorted order). */
 int rc_collide_instances_any(rc_scene* scene, uint32_t handle_a, uint32_t handle_b, int* overlap);
 
+/* ---- mesh ingestion and the full Triangle record -----------------------------------------------------------------------
+ * rc_triangle = Triangle{UInt32}, 136 bytes (src/triangle_mesh.jl:1-7): what closest_hit returns by value. */
+typedef struct rc_triangle {
+    float vertices[3][3], normals[3][3], tangents[3][3], uv[3][2];
+    uint32_t metadata;
+} rc_triangle;
+/* build_and_append_blas! after the GeometryBasics decomposition (src/instanced-bvh.jl:581-608): the caller passes what
+ * expand_faceviews / decompose / decompose_normals / decompose_uv produced -- nv vertices (verts, normals: nv x 3 f32; uvs:
+ * nv x 2 f32 or NULL), nf faces as 0-based index triples, and optionally the per-vertex face_meta array (the reference
+ * reads face_meta[first vertex of the face], :595; NULL => face index 1..nf, assigned before the degenerate filter).
+ * Expansion, is_degenerate_face filtering (:573-577), build_triangle (:555-566) and the LBVH build run on the device. */
+int rc_add_mesh(rc_scene* scene, const float* verts, const float* normals, const float* uvs, uint32_t nv,
+                const uint32_t* indices, uint32_t nf, const uint32_t* face_meta, uint32_t* blas_id);
+/* all_blas_prims as full Triangles (synced scene; count query when out == NULL).  Geometry that came in as plain soup
+ * (rc_add_blas*) has no mesh attributes: normals = geometric normal normalize((v1-v0) x (v2-v0)), uv = the reference's
+ * default (0,0),(1,0),(1,1) (:561-565); tangents are NaN as in build_triangle. */
+int rc_export_triangles(rc_scene* scene, rc_triangle* out, uint32_t capacity, uint32_t* count);
+/* Shading epilogue next to the trace (docs/src/wavefront-renderer.jl:382-387), device buffers: per hit the interpolated
+ * normal normalize(n0*b1 + n1*b2 + n2*b3) (d_normals, n x 3 f32) and uv0*b1 + uv1*b2 + uv2*b3 (d_uvs, n x 2 f32) with
+ * (b1, b2, b3) = ((1-u)-v, u, v); zeros on a miss.  Either output may be NULL.  Saves returning 136-byte Triangles. */
+int rc_shading_attributes_device(rc_scene* scene, const rc_hit* d_hits, uint64_t n, float* d_normals, float* d_uvs, void* stream);
+
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);

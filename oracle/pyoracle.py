@@ -25,7 +25,9 @@ HIT_DT = np.dtype([("hit", "<u4"), ("t", "<f4"), ("primitive_id", "<u4"), ("inst
                    ("bary_u", "<f4"), ("bary_v", "<f4"), ("instance_id", "<u4"), ("_pad", "<u4")])
 NODE4_DT = np.dtype([("child", "<u4", 4), ("aabb", "<f4", (4, 2, 3)), ("parent", "<u4"), ("child_count", "u1"),
                      ("primitive_count", "u1"), ("_pad1", "u1"), ("_pad2", "u1")])  # BVHNode4, src/bvh4.jl:40-69
-assert NODE4_DT.itemsize == 120
+TRIANGLE_DT = np.dtype([("vertices", "<f4", (3, 3)), ("normals", "<f4", (3, 3)), ("tangents", "<f4", (3, 3)), ("uv", "<f4", (3, 2)),
+                        ("metadata", "<u4")])  # Triangle{UInt32}, src/triangle_mesh.jl:1-7
+assert NODE4_DT.itemsize == 120 and TRIANGLE_DT.itemsize == 136
 assert NODE_DT.itemsize == 60 and INSTANCE_DT.itemsize == 108 and DESC_DT.itemsize == 32
 assert TRI_DT.itemsize == 40 and RAY_DT.itemsize == 32 and HIT_DT.itemsize == 32
 
@@ -93,6 +95,11 @@ def lib():
         L.rco_collide_instances.restype = u64
         L.rco_collide_instances.argtypes = [vp, vp, vp]
         L.rco_collide_instances_any.argtypes = [vp, u32, u32, u32, u32]
+        L.rco_scene_add_mesh.restype = u32
+        L.rco_scene_add_mesh.argtypes = [vp, vp, vp, vp, u32, vp, u32, vp]
+        L.rco_scene_triangles.restype = u32
+        L.rco_scene_triangles.argtypes = [vp, vp]
+        L.rco_shading_attributes.argtypes = [vp, vp, u64, vp, vp]
         _lib = L
     return _lib
 
@@ -124,6 +131,30 @@ class Scene:
         if idx == 0:
             raise ValueError("Geometry has no valid triangles")
         return idx
+
+    def add_mesh(self, verts, faces, normals, uvs=None, face_meta=None):
+        v, nrm = _f32(verts).reshape(-1, 3), _f32(normals).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        uv = None if uvs is None else _f32(uvs).reshape(-1, 2)
+        fm = None if face_meta is None else np.ascontiguousarray(face_meta, dtype=np.uint32)
+        idx = lib().rco_scene_add_mesh(self._h, _p(v), _p(nrm), _p(uv), len(v), _p(f), len(f), _p(fm))
+        if idx == 0:
+            raise ValueError("Geometry has no valid triangles")
+        return idx
+
+    @property
+    def triangles(self):
+        n = lib().rco_scene_triangles(self._h, None)
+        out = np.zeros(n, dtype=TRIANGLE_DT)
+        if n:
+            lib().rco_scene_triangles(self._h, _p(out))
+        return out
+
+    def shading_attributes(self, hits):
+        hits = np.ascontiguousarray(hits)
+        nrm, uv = np.zeros((len(hits), 3), np.float32), np.zeros((len(hits), 2), np.float32)
+        lib().rco_shading_attributes(self._h, _p(hits), len(hits), _p(nrm), _p(uv))
+        return nrm, uv
 
     def add_instance(self, blas_index, xform=None, instance_id=0, inv=None):
         x = IDENTITY if xform is None else _f32(xform).reshape(12)

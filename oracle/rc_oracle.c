@@ -250,6 +250,8 @@ typedef struct {
     uint32_t* morton;                 /* sorted codes */
     float root_min[3], root_max[3];
     rco_node4* nodes4; uint32_t n_nodes4; /* BLAS4 (src/bvh4.jl), built on demand */
+    /* mesh attributes (rco_scene_add_mesh): per-vertex arrays + the source face of every sorted primitive */
+    float* m_normals; float* m_uvs; uint32_t* m_indices; uint32_t* src_face; int has_attrs;
 } blas_t;
 
 struct rco_scene {
@@ -272,7 +274,7 @@ static void free_static(rco_scene* s) {
 }
 void rco_scene_free(rco_scene* s) {
     if (!s) return;
-    for (uint32_t i = 0; i < s->n_blas; ++i) { free(s->blas[i].nodes); free(s->blas[i].prims); free(s->blas[i].morton); free(s->blas[i].nodes4); }
+    for (uint32_t i = 0; i < s->n_blas; ++i) { free(s->blas[i].nodes); free(s->blas[i].prims); free(s->blas[i].morton); free(s->blas[i].nodes4); free(s->blas[i].m_normals); free(s->blas[i].m_uvs); free(s->blas[i].m_indices); free(s->blas[i].src_face); }
     free(s->blas); free(s->inst); free_static(s); free(s);
 }
 
@@ -285,7 +287,7 @@ int rco_is_degenerate(const float p[9]) {
 }
 
 /* build_blas (src/instanced-bvh.jl:1376-1443) */
-static int build_blas(const rco_tri* in, uint32_t n, blas_t* out) {
+static int build_blas(const rco_tri* in, uint32_t n, blas_t* out, const uint32_t* face_of_in) {
     if (n == 0) return -1;
     /* scene AABB: mapreduce(world_bound, U, prims, init=Bounds3()) (:1386) */
     v3 smin = V(INFINITY, INFINITY, INFINITY), smax = V(-INFINITY, -INFINITY, -INFINITY);
@@ -311,6 +313,10 @@ static int build_blas(const rco_tri* in, uint32_t n, blas_t* out) {
     out->prims = (rco_tri*)malloc(sizeof(rco_tri) * n);
     out->morton = (uint32_t*)malloc(sizeof(uint32_t) * n);
     for (uint32_t i = 0; i < n; ++i) { out->prims[i] = in[ci[i].idx]; out->morton[i] = ci[i].code; }
+    if (face_of_in) {
+        out->src_face = (uint32_t*)malloc(sizeof(uint32_t) * n);
+        for (uint32_t i = 0; i < n; ++i) out->src_face[i] = face_of_in[ci[i].idx];
+    }
     free(ci);
     out->n_nodes = 2 * n - 1;
     out->nodes = (rco_node*)malloc(sizeof(rco_node) * out->n_nodes);
@@ -349,8 +355,39 @@ uint32_t rco_scene_add_blas(rco_scene* s, const float* verts, const uint32_t* me
     }
     blas_t* b = &s->blas[s->n_blas];
     memset(b, 0, sizeof(*b));
-    build_blas(tris, m, b);
+    build_blas(tris, m, b, NULL);
     free(tris);
+    free_static(s);
+    return ++s->n_blas;
+}
+
+uint32_t rco_scene_add_mesh(rco_scene* s, const float* verts, const float* normals, const float* uvs, uint32_t nv,
+                            const uint32_t* indices, uint32_t nf, const uint32_t* face_meta) {
+    rco_tri* tris = (rco_tri*)malloc(sizeof(rco_tri) * (nf ? nf : 1));
+    uint32_t* face_of = (uint32_t*)malloc(sizeof(uint32_t) * (nf ? nf : 1));
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < nf; ++i) { /* :591-600 */
+        float p[9];
+        for (int k = 0; k < 3; ++k) memcpy(p + 3 * k, verts + 3 * (size_t)indices[3 * (size_t)i + k], 12);
+        if (rco_is_degenerate(p)) continue; /* is_degenerate_face :573-577 */
+        memcpy(tris[m].v, p, 36);
+        tris[m].meta = face_meta ? face_meta[indices[3 * (size_t)i]] : (i + 1); /* :595 */
+        face_of[m] = i;
+        ++m;
+    }
+    if (m == 0) { free(tris); free(face_of); return 0; }
+    if (s->n_blas == s->cap_blas) {
+        s->cap_blas = s->cap_blas ? 2 * s->cap_blas : 8;
+        s->blas = (blas_t*)realloc(s->blas, sizeof(blas_t) * s->cap_blas);
+    }
+    blas_t* b = &s->blas[s->n_blas];
+    memset(b, 0, sizeof(*b));
+    build_blas(tris, m, b, face_of);
+    free(tris); free(face_of);
+    b->has_attrs = 1;
+    b->m_normals = (float*)malloc(sizeof(float) * 3 * (size_t)nv); memcpy(b->m_normals, normals, sizeof(float) * 3 * (size_t)nv);
+    if (uvs) { b->m_uvs = (float*)malloc(sizeof(float) * 2 * (size_t)nv); memcpy(b->m_uvs, uvs, sizeof(float) * 2 * (size_t)nv); }
+    b->m_indices = (uint32_t*)malloc(sizeof(uint32_t) * 3 * (size_t)nf); memcpy(b->m_indices, indices, sizeof(uint32_t) * 3 * (size_t)nf);
     free_static(s);
     return ++s->n_blas;
 }
@@ -1191,4 +1228,58 @@ int rco_collide_instances_any(const rco_scene* s, uint32_t a_first, uint32_t a_c
             if (aabb_overlaps(amn, amx, bmn, bmx)) return 1;
         }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Full Triangle records and the shading epilogue
+ * ---------------------------------------------------------------------------------------------- */
+static void full_triangle(const blas_t* b, uint32_t j, rco_triangle* t) { /* build_triangle :555-566 for sorted primitive j (0-based) */
+    const rco_tri* p = &b->prims[j];
+    memcpy(t->vertices, p->v, 36);
+    for (int k = 0; k < 3; ++k) t->tangents[k][0] = t->tangents[k][1] = t->tangents[k][2] = NAN;
+    static const float default_uv[3][2] = {{0, 0}, {1, 0}, {1, 1}}; /* :561-565 */
+    memcpy(t->uv, default_uv, sizeof(default_uv));
+    if (b->has_attrs) {
+        const uint32_t* idx = b->m_indices + 3 * (size_t)b->src_face[j];
+        for (int k = 0; k < 3; ++k) {
+            memcpy(t->normals[k], b->m_normals + 3 * (size_t)idx[k], 12);
+            if (b->m_uvs) memcpy(t->uv[k], b->m_uvs + 2 * (size_t)idx[k], 8);
+        }
+    } else {
+        v3 v0 = v3_from(p->v[0]), v1 = v3_from(p->v[1]), v2 = v3_from(p->v[2]);
+        v3 n = v3_normalize(v3_cross(v3_sub(v1, v0), v3_sub(v2, v0)));
+        for (int k = 0; k < 3; ++k) v3_store(t->normals[k], n);
+    }
+    t->metadata = p->meta;
+}
+
+uint32_t rco_scene_triangles(const rco_scene* s, rco_triangle* out) {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < s->n_blas; ++i) {
+        if (out) for (uint32_t j = 0; j < s->blas[i].n_prims; ++j) full_triangle(&s->blas[i], j, &out[n + j]);
+        n += s->blas[i].n_prims;
+    }
+    return n;
+}
+
+void rco_shading_attributes(const rco_scene* s, const rco_hit* hits, uint64_t n, float* normals, float* uvs) {
+    for (uint64_t i = 0; i < n; ++i) {
+        float nn[3] = {0, 0, 0}, uv[2] = {0, 0};
+        if (hits[i].hit) {
+            /* locate the BLAS that owns flat primitive primitive_id */
+            uint32_t pid = hits[i].primitive_id, bi = 0;
+            while (bi + 1 < s->n_blas && s->descs[bi + 1].primitives_offset <= pid) ++bi;
+            rco_triangle t;
+            full_triangle(&s->blas[bi], pid - s->descs[bi].primitives_offset, &t);
+            float u = hits[i].bary_u, v = hits[i].bary_v;
+            float b1 = (1.0f - u) - v, b2 = u, b3 = v; /* :2015 */
+            v3 sum = v3_add(v3_add(v3_scale(v3_from(t.normals[0]), b1), v3_scale(v3_from(t.normals[1]), b2)), v3_scale(v3_from(t.normals[2]), b3));
+            v3 nrm = v3_normalize(sum);
+            nn[0] = nrm.x; nn[1] = nrm.y; nn[2] = nrm.z;
+            uv[0] = (t.uv[0][0] * b1 + t.uv[1][0] * b2) + t.uv[2][0] * b3;
+            uv[1] = (t.uv[0][1] * b1 + t.uv[1][1] * b2) + t.uv[2][1] * b3;
+        }
+        if (normals) memcpy(normals + 3 * i, nn, 12);
+        if (uvs) memcpy(uvs + 2 * i, uv, 8);
+    }
 }

@@ -176,6 +176,26 @@ uint64_t rco_collide_instances(const rco_scene*, rco_contact* out, uint32_t* cou
  * looked up at TLAS leaf position n-1+i, i.e. in Morton-sorted order, not at the leaf that holds instance i. */
 int rco_collide_instances_any(const rco_scene*, uint32_t a_first, uint32_t a_count, uint32_t b_first, uint32_t b_count);
 
+/* ---- mesh ingestion and the full Triangle record (src/instanced-bvh.jl:555-608, src/triangle_mesh.jl:1-7) ---------------- */
+/* Triangle{UInt32}, 136 bytes: what closest_hit returns by value. */
+typedef struct {
+    float vertices[3][3], normals[3][3], tangents[3][3], uv[3][2];
+    uint32_t metadata;
+} rco_triangle;
+/* build_and_append_blas! after the GeometryBasics decomposition (:581-600): per-vertex positions / normals / optional uvs,
+ * 0-based triangle indices (3 per face), optional per-vertex face_meta (the reference reads face_meta[first vertex of the
+ * face], :595; NULL => face index 1..nf assigned before the degenerate filter).  build_triangle (:555-566): tangents NaN,
+ * default uv (0,0),(1,0),(1,1).  Returns the 1-based BLAS index, 0 when no valid triangle remains. */
+uint32_t rco_scene_add_mesh(rco_scene*, const float* verts, const float* normals, const float* uvs, uint32_t nv,
+                            const uint32_t* indices, uint32_t nf, const uint32_t* face_meta);
+/* all_blas_prims as full Triangles (flat, Morton-sorted per BLAS).  Geometry added as plain soup (rco_scene_add_blas) has no
+ * mesh attributes: its normals are the geometric normal normalize((v1-v0) x (v2-v0)) on all three vertices, uv the default. */
+uint32_t rco_scene_triangles(const rco_scene*, rco_triangle* out);
+/* Shading epilogue of the reference's renderers (docs/src/wavefront-renderer.jl:382-387): per hit, the interpolated normal
+ * normalize(n0*b1 + n1*b2 + n2*b3) and uv0*b1 + uv1*b2 + uv2*b3 with (b1,b2,b3) = ((1-u)-v, u, v); zeros on a miss.
+ * normals: n x 3 floats, uvs: n x 2 floats (either may be NULL). */
+void rco_shading_attributes(const rco_scene*, const rco_hit* hits, uint64_t n, float* normals, float* uvs);
+
 #ifdef __cplusplus
 }
 #endif

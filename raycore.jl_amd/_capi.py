@@ -25,6 +25,9 @@ PRIM_DT = np.dtype([("v", "<f4", (3, 3)), ("meta", "<u4")])
 NODE4_DT = np.dtype([("child", "<u4", 4), ("aabb", "<f4", (4, 2, 3)), ("parent", "<u4"), ("child_count", "u1"),
                      ("primitive_count", "u1"), ("_pad1", "u1"), ("_pad2", "u1")])  # BVHNode4, src/bvh4.jl:40-69
 assert NODE4_DT.itemsize == 120
+TRIANGLE_DT = np.dtype([("vertices", "<f4", (3, 3)), ("normals", "<f4", (3, 3)), ("tangents", "<f4", (3, 3)), ("uv", "<f4", (3, 2)),
+                        ("metadata", "<u4")])  # Triangle{UInt32}, src/triangle_mesh.jl:1-7
+assert TRIANGLE_DT.itemsize == 136
 assert RAY_DT.itemsize == 32 and HIT_DT.itemsize == 32 and NODE_DT.itemsize == 60
 assert INSTANCE_DT.itemsize == 108 and DESC_DT.itemsize == 32 and PRIM_DT.itemsize == 40
 
@@ -81,6 +84,9 @@ SYMBOLS = [
     ("rc_collide_instances", _int, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("rc_collide_instances_device", _int, [_vp, _vp, _u64, C.POINTER(_u64), _vp]),
     ("rc_collide_instances_any", _int, [_vp, _u32, _u32, _pint]),
+    ("rc_add_mesh", _int, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _pu32]),
+    ("rc_export_triangles", _int, [_vp, _vp, _u32, _pu32]),
+    ("rc_shading_attributes_device", _int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     ("rc_last_kernel_ms", _int, [_vp, _pf]),
 ]
 

@@ -21,12 +21,19 @@ from ._capi import HIT_DT, RAY_DT, RaycoreError, check, lib, ptr
 
 TLASHandle = namedtuple("TLASHandle", ["id"])  # src/instanced-bvh.jl:180-182
 INVALID_HANDLE = TLASHandle(0)
-Triangle = namedtuple("Triangle", ["vertices", "metadata"])  # the fields of Triangle{UInt32} this path reads
+# Triangle{UInt32} (src/triangle_mesh.jl:1-7).  Positional order (vertices, metadata) is kept for the path's own use; the
+# shading fields default to None when a caller builds one by hand.
+Triangle = namedtuple("Triangle", ["vertices", "metadata", "normals", "tangents", "uv"], defaults=(None, None, None))
 Bounds3 = namedtuple("Bounds3", ["p_min", "p_max"])
 RayHit = namedtuple("RayHit", ["hit", "point", "metadata"])  # src/kernels.jl:1-5
 Ray = namedtuple("Ray", ["o", "d", "t_min", "t_max"], defaults=(0.0, np.inf))  # src/ray.jl:1-7 (time unused on the path)
 
-EMPTY_TRIANGLE = Triangle(np.zeros((3, 3), np.float32), np.uint32(0))  # empty_triangle, src/triangle_mesh.jl:49-57
+EMPTY_TRIANGLE = Triangle(np.zeros((3, 3), np.float32), np.uint32(0), np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32),
+                          np.zeros((3, 2), np.float32))  # empty_triangle, src/triangle_mesh.jl:49-57
+
+
+def _triangle(rec):
+    return Triangle(rec["vertices"].copy(), rec["metadata"], rec["normals"].copy(), rec["tangents"].copy(), rec["uv"].copy())
 
 
 def mat4_to_mat3x4(m):
@@ -91,6 +98,11 @@ class StaticTLAS:
     @property
     def all_blas_prims(self):
         return self._export(lib().rc_export_prims, _capi.PRIM_DT)
+
+    @property
+    def all_blas_triangles(self):
+        """all_blas_prims as full 136-byte Triangle{UInt32} records (vertices, normals, tangents, uv, metadata)."""
+        return self._export(lib().rc_export_triangles, _capi.TRIANGLE_DT)
 
     @property
     def blas_descriptors(self):
@@ -162,6 +174,35 @@ class TLAS:
         check(lib().rc_add_blas(self._h, ptr(verts), ptr(m), len(verts), C.byref(blas_id)))
         self._prims_cache = None
         return blas_id.value + 1
+
+    def add_mesh(self, verts, faces, normals, uvs=None, face_meta=None):
+        """build_and_append_blas! on a decomposed mesh (:581-608): verts / normals (nv, 3), faces (nf, 3) 0-based, uvs (nv, 2) or
+        None, face_meta per vertex (as after expand_faceviews, :595) or None.  Returns the 1-based BLAS index."""
+        v = np.ascontiguousarray(np.asarray(verts, dtype=np.float32).reshape(-1, 3))
+        nrm = np.ascontiguousarray(np.asarray(normals, dtype=np.float32).reshape(-1, 3))
+        f = np.ascontiguousarray(np.asarray(faces, dtype=np.uint32).reshape(-1, 3))
+        uv = None if uvs is None else np.ascontiguousarray(np.asarray(uvs, dtype=np.float32).reshape(-1, 2))
+        fm = None if face_meta is None else np.ascontiguousarray(face_meta, dtype=np.uint32)
+        if len(nrm) != len(v) or (uv is not None and len(uv) != len(v)) or (fm is not None and len(fm) != len(v)):
+            raise ValueError("normals / uvs / face_meta must have one entry per vertex")
+        blas_id = C.c_uint32()
+        check(lib().rc_add_mesh(self._h, ptr(v), ptr(nrm), ptr(uv), len(v), ptr(f), len(f), ptr(fm), C.byref(blas_id)))
+        self._prims_cache = None
+        return blas_id.value + 1
+
+    def push_mesh(self, verts, faces, normals, transforms=None, uvs=None, face_meta=None, instance_id=0, instance_ids=None):
+        """push!(tlas, mesh, transforms; instance_ids) (:639-676) for a decomposed mesh; returns the TLASHandle."""
+        blas_index = self.add_mesh(verts, faces, normals, uvs, face_meta)
+        if instance_ids is None and transforms is not None:
+            n_inst = len(_as_xforms(transforms))
+            instance_ids = np.full(n_inst, instance_id, np.uint32)
+        elif instance_ids is None:
+            instance_ids = np.array([instance_id], np.uint32)
+        return self.push_instances(blas_index, transforms, instance_ids)
+
+    def shading_attributes_device(self, d_hits, n, d_normals=None, d_uvs=None, stream=None):
+        """Interpolated shading normal / uv per hit on device buffers (docs/src/wavefront-renderer.jl:382-387)."""
+        check(lib().rc_shading_attributes_device(self._h, ptr(d_hits), int(n), ptr(d_normals), ptr(d_uvs), ptr(stream)))
 
     def add_geometry_device(self, d_verts, n, d_meta=None):
         """build_and_append_blas! from device-resident soup (d_verts: device pointer to n x 9 f32); returns the 1-based BLAS index."""
@@ -300,6 +341,12 @@ class TLAS:
             self._prims_cache = self._static.all_blas_prims
         return self._prims_cache
 
+    def _triangles(self):
+        if self._prims_cache is None or getattr(self, "_tri_cache_for", None) is not self._prims_cache:
+            self._tri_cache = self._static.all_blas_triangles
+            self._tri_cache_for = self._prims()
+        return self._tri_cache
+
 
 def _owner(accel):
     if isinstance(accel, StaticTLAS):
@@ -326,10 +373,9 @@ def _tuple_from_hit(t, h, miss_prim):
     """(hit, Triangle, t, bary, instance_idx) exactly as closest_hit/any_hit return it (:2010-2023, :2106-2139)."""
     if not h["hit"]:
         return (False, miss_prim, np.float32(0), np.zeros(3, np.float32), np.uint32(0))
-    p = t._prims()[h["primitive_id"]]
     u, v = h["bary_u"], h["bary_v"]
     w = (np.float32(1.0) - u) - v  # 1f0 - hit_u - hit_v (:2015)
-    return (True, Triangle(p["v"].copy(), p["meta"]), h["t"], np.array([w, u, v], np.float32), np.uint32(h["instance_id"] + 1))
+    return (True, _triangle(t._triangles()[h["primitive_id"]]), h["t"], np.array([w, u, v], np.float32), np.uint32(h["instance_id"] + 1))
 
 
 def closest_hit(accel, ray):
@@ -342,8 +388,8 @@ def any_hit(accel, ray):
     """any_hit(tlas, ray) (:2034-2140); on a miss the dummy primitive is all_blas_prims[1] (:2137)."""
     t = _owner(accel)
     h = t.trace(_as_rays(ray), mode="any")[0]
-    prims = t._prims()
-    dummy = Triangle(prims[0]["v"].copy(), prims[0]["meta"]) if len(prims) else EMPTY_TRIANGLE
+    tris = t._triangles()
+    dummy = _triangle(tris[0]) if len(tris) else EMPTY_TRIANGLE
     return _tuple_from_hit(t, h, dummy)
 
 

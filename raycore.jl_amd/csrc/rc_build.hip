@@ -78,9 +78,10 @@ __global__ void k_flag_valid_faces(const float* verts, uint32_t n, uint32_t* fla
 
 // cpu_triangles of build_and_append_blas! (:593-600) as a stream compaction: face i goes to slot pos[i] (exclusive scan
 // of the flags), order preserved; default metadata = face index BEFORE filtering (:595).
-__global__ void k_compact_faces(const float* verts, const uint32_t* meta, const uint32_t* flags, const uint32_t* pos, uint32_t n, RcPrim* out) {
+__global__ void k_compact_faces(const float* verts, const uint32_t* meta, const uint32_t* flags, const uint32_t* pos, uint32_t n, RcPrim* out, uint32_t* slot_face) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flags[i]) return;
+    if (slot_face) slot_face[pos[i]] = i;
     RcPrim t;
     const float* p = verts + 9 * (size_t)i;
 #pragma unroll
@@ -136,6 +137,81 @@ __global__ void k_blas_morton(const RcPrim* prims, uint32_t n, const uint32_t* e
 __global__ void k_gather_prims(const RcPrim* in, const uint32_t* perm, uint32_t n, RcPrim* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[perm[i]];
+}
+
+__global__ void k_gather_u32(const uint32_t* in, const uint32_t* perm, uint32_t n, uint32_t* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[perm[i]];
+}
+
+// build_and_append_blas! after the mesh decomposition (src/instanced-bvh.jl:591-600): face i -> three vertices by index;
+// metadata = face_meta[first vertex of the face] (per-vertex after expand_faceviews, :595) or the face index.
+__global__ void k_expand_mesh(const float* verts, const uint32_t* indices, const uint32_t* vertex_meta, uint32_t nf, float* soup, uint32_t* meta) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    const uint32_t i0 = indices[3 * (size_t)i], i1 = indices[3 * (size_t)i + 1], i2 = indices[3 * (size_t)i + 2];
+    float* o = soup + 9 * (size_t)i;
+    o[0] = verts[3 * (size_t)i0]; o[1] = verts[3 * (size_t)i0 + 1]; o[2] = verts[3 * (size_t)i0 + 2];
+    o[3] = verts[3 * (size_t)i1]; o[4] = verts[3 * (size_t)i1 + 1]; o[5] = verts[3 * (size_t)i1 + 2];
+    o[6] = verts[3 * (size_t)i2]; o[7] = verts[3 * (size_t)i2 + 1]; o[8] = verts[3 * (size_t)i2 + 2];
+    meta[i] = vertex_meta ? vertex_meta[i0] : (i + 1);
+}
+
+// normals (9 floats) + uv (6 floats) of every primitive of one BLAS: build_triangle (:555-566).  Soup geometry has no mesh
+// attributes: geometric normal on all three vertices, default uv.
+__global__ void k_fill_attrs(const RcPrim* prims, uint32_t n, const float* normals, const float* uvs, const uint32_t* indices,
+                             const uint32_t* src_face, float* out) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float* o = out + 15 * (size_t)j;
+    o[9] = 0.f; o[10] = 0.f; o[11] = 1.f; o[12] = 0.f; o[13] = 1.f; o[14] = 1.f;  // default uv (:561-565)
+    if (normals) {
+        const uint32_t* idx = indices + 3 * (size_t)src_face[j];
+        for (int k = 0; k < 3; ++k) {
+            const size_t v = idx[k];
+            o[3 * k] = normals[3 * v]; o[3 * k + 1] = normals[3 * v + 1]; o[3 * k + 2] = normals[3 * v + 2];
+            if (uvs) { o[9 + 2 * k] = uvs[2 * v]; o[10 + 2 * k] = uvs[2 * v + 1]; }
+        }
+    } else {
+        const RcPrim p = prims[j];
+        const float3_ v0 = mk3(p.v[0], p.v[1], p.v[2]), v1 = mk3(p.v[3], p.v[4], p.v[5]), v2 = mk3(p.v[6], p.v[7], p.v[8]);
+        const float3_ c = cross3(sub3(v1, v0), sub3(v2, v0));
+        const float len = __builtin_sqrtf(dot3(c, c));
+        for (int k = 0; k < 3; ++k) { o[3 * k] = c.x / len; o[3 * k + 1] = c.y / len; o[3 * k + 2] = c.z / len; }
+    }
+}
+
+// Triangle{UInt32} (src/triangle_mesh.jl:1-7), 136 bytes = 34 words: vertices 9, normals 9, tangents 9 (NaN), uv 6, metadata
+__global__ void k_export_triangles(const RcPrim* prims, const float* attrs, uint32_t n, uint32_t* out) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const RcPrim p = prims[j];
+    const float* a = attrs + 15 * (size_t)j;
+    uint32_t* o = out + 34 * (size_t)j;
+    for (int k = 0; k < 9; ++k) o[k] = __float_as_uint(p.v[k]);
+    for (int k = 0; k < 9; ++k) o[9 + k] = __float_as_uint(a[k]);
+    for (int k = 0; k < 9; ++k) o[18 + k] = 0x7FC00000u;  // Vec3f(NaN)
+    for (int k = 0; k < 6; ++k) o[27 + k] = __float_as_uint(a[9 + k]);
+    o[33] = p.meta;
+}
+
+// shading epilogue (docs/src/wavefront-renderer.jl:382-387): normalize(n0*b1 + n1*b2 + n2*b3), uv0*b1 + uv1*b2 + uv2*b3
+__global__ void k_shading_attributes(const RcHit* hits, uint64_t n, const float* attrs, float* normals, float* uvs) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RcHit h = hits[i];
+    float nx = 0.f, ny = 0.f, nz = 0.f, tu = 0.f, tv = 0.f;
+    if (h.hit) {
+        const float* a = attrs + 15 * (size_t)h.primitive_id;
+        const float b1 = (1.0f - h.bary_u) - h.bary_v, b2 = h.bary_u, b3 = h.bary_v;  // :2015
+        const float sx = (a[0] * b1 + a[3] * b2) + a[6] * b3, sy = (a[1] * b1 + a[4] * b2) + a[7] * b3, sz = (a[2] * b1 + a[5] * b2) + a[8] * b3;
+        const float len = __builtin_sqrtf((sx * sx + sy * sy) + sz * sz);
+        nx = sx / len; ny = sy / len; nz = sz / len;
+        tu = (a[9] * b1 + a[11] * b2) + a[13] * b3;
+        tv = (a[10] * b1 + a[12] * b2) + a[14] * b3;
+    }
+    if (normals) { normals[3 * i] = nx; normals[3 * i + 1] = ny; normals[3 * i + 2] = nz; }
+    if (uvs) { uvs[2 * i] = tu; uvs[2 * i + 1] = tv; }
 }
 
 // fill_bvhnode2_kernel! (src/instanced-bvh-kernels.jl:19-22) with the empty node of :1407-1410
@@ -418,16 +494,17 @@ void rc_mat3x4_inverse(const float m[12], float out[12]) {
 // Triangle ingestion on the device (build_and_append_blas! minus mesh decomposition, :581-601): raw n x 9 f32 soup
 // (+ optional metadata) already in device memory -> degenerate filter -> compacted RcPrim array in s->prim_tmp.
 // Returns the number of valid triangles (one 4-byte read-back).
-uint32_t rc_ingest_faces(rc_scene* s, const float* d_verts, const uint32_t* d_meta, uint32_t n) {
+uint32_t rc_ingest_faces(rc_scene* s, const float* d_verts, const uint32_t* d_meta, uint32_t n, bool keep_face_map) {
     if (n == 0) return 0;
     reserve_build_scratch(s, n);
     s->prim_tmp.reserve(n);
+    if (keep_face_map) s->slot_face.reserve(n);
     hipLaunchKernelGGL(k_flag_valid_faces, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, d_verts, n, s->keys_a.p);
     size_t tmp = 0;
     RC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, s->keys_a.p, s->keys_b.p, (int)n, s->stream));
     s->sort_tmp.reserve(tmp ? tmp : 1);
     RC_HIP(hipcub::DeviceScan::ExclusiveSum(s->sort_tmp.p, tmp, s->keys_a.p, s->keys_b.p, (int)n, s->stream));
-    hipLaunchKernelGGL(k_compact_faces, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, d_verts, d_meta, s->keys_a.p, s->keys_b.p, n, s->prim_tmp.p);
+    hipLaunchKernelGGL(k_compact_faces, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, d_verts, d_meta, s->keys_a.p, s->keys_b.p, n, s->prim_tmp.p, keep_face_map ? s->slot_face.p : nullptr);
     uint32_t last[2];
     RC_HIP(hipMemcpyAsync(&last[0], s->keys_b.p + (n - 1), 4, hipMemcpyDeviceToHost, s->stream));
     RC_HIP(hipMemcpyAsync(&last[1], s->keys_a.p + (n - 1), 4, hipMemcpyDeviceToHost, s->stream));
@@ -436,8 +513,42 @@ uint32_t rc_ingest_faces(rc_scene* s, const float* d_verts, const uint32_t* d_me
     return last[0] + last[1];
 }
 
+void rc_expand_mesh(rc_scene* s, const float* d_verts, const uint32_t* d_indices, const uint32_t* d_vertex_meta, uint32_t nf, float* d_soup, uint32_t* d_meta) {
+    if (nf == 0) return;
+    hipLaunchKernelGGL(k_expand_mesh, dim3(grid_for(nf)), dim3(kBlock), 0, s->stream, d_verts, d_indices, d_vertex_meta, nf, d_soup, d_meta);
+    RC_HIP(hipGetLastError());
+}
+
+void rc_ensure_flat_attrs(rc_scene* s) {
+    if (s->flat_attrs_valid) return;
+    s->flat_attrs.reserve(15 * (size_t)(s->n_flat_prims ? s->n_flat_prims : 1));
+    for (size_t i = 0; i < s->blas.size(); ++i) {
+        const Blas& b = s->blas[i];
+        hipLaunchKernelGGL(k_fill_attrs, dim3(grid_for(b.n_prims)), dim3(kBlock), 0, s->stream, b.prims.p, b.n_prims,
+                           b.has_attrs ? b.m_normals.p : (const float*)nullptr, b.has_uvs ? b.m_uvs.p : (const float*)nullptr, b.m_indices.p, b.src_face.p,
+                           s->flat_attrs.p + 15 * (size_t)s->descs[i].primitives_offset);
+    }
+    RC_HIP(hipGetLastError());
+    RC_HIP(hipStreamSynchronize(s->stream));  // later launches may run on a caller's stream
+    s->flat_attrs_valid = true;
+}
+
+void rc_launch_export_triangles(rc_scene* s, void* d_out, hipStream_t stream) {
+    if (s->n_flat_prims == 0) return;
+    rc_ensure_flat_attrs(s);
+    hipLaunchKernelGGL(k_export_triangles, dim3(grid_for(s->n_flat_prims)), dim3(kBlock), 0, stream, s->flat_prims.p, s->flat_attrs.p, s->n_flat_prims, (uint32_t*)d_out);
+    RC_HIP(hipGetLastError());
+}
+
+void rc_launch_shading_attributes(rc_scene* s, const RcHit* d_hits, uint64_t n, float* d_normals, float* d_uvs, hipStream_t stream) {
+    if (n == 0) return;
+    rc_ensure_flat_attrs(s);
+    hipLaunchKernelGGL(k_shading_attributes, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_hits, n, s->flat_attrs.p, d_normals, d_uvs);
+    RC_HIP(hipGetLastError());
+}
+
 // build_blas (src/instanced-bvh.jl:1376-1443) over the n compacted primitives waiting in s->prim_tmp
-void rc_build_blas(rc_scene* s, uint32_t n, Blas& out) {
+void rc_build_blas(rc_scene* s, uint32_t n, Blas& out, bool keep_face_map) {
     reserve_build_scratch(s, n);
     out.prims.reserve(n);
     out.nodes.reserve(2 * (size_t)n - 1);
@@ -449,6 +560,10 @@ void rc_build_blas(rc_scene* s, uint32_t n, Blas& out) {
     hipLaunchKernelGGL(k_blas_morton, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->prim_tmp.p, n, s->scene_enc.p, s->keys_a.p, s->vals_a.p);
     sort_pairs(s, n);
     hipLaunchKernelGGL(k_gather_prims, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->prim_tmp.p, s->vals_b.p, n, out.prims.p);
+    if (keep_face_map) {  // source face of every Morton-sorted primitive: the attributes stay per vertex and are looked up through it
+        out.src_face.reserve(n);
+        hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->slot_face.p, s->vals_b.p, n, out.src_face.p);
+    }
     emit_tree(s, out.nodes.p, n);
     hipLaunchKernelGGL(k_blas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, out.nodes.p, out.prims.p, n);
     run_refit(s, out.nodes.p, out.prims.p, n, 0);
@@ -475,6 +590,7 @@ void rc_build_tlas(rc_scene* s) {
         tn += s->blas[i].n_nodes; tp += s->blas[i].n_prims;
     }
     s->n_flat_nodes = tn; s->n_flat_prims = tp;
+    s->flat_attrs_valid = false;
     s->flat_nodes.reserve((size_t)tn + 2 * (size_t)n + 1);  // + room for the TLAS copy behind the BLAS nodes
     s->flat_prims.reserve(tp ? tp : 1);
     s->d_descs.reserve(nb ? nb : 1);

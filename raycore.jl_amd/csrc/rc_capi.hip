@@ -186,6 +186,72 @@ int rc_add_blas_device(rc_scene* s, const float* d_verts, const uint32_t* d_meta
     });
 }
 
+int rc_add_mesh(rc_scene* s, const float* verts, const float* normals, const float* uvs, uint32_t nv, const uint32_t* indices, uint32_t nf,
+                const uint32_t* face_meta, uint32_t* blas_id) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        if ((nv && (!verts || !normals)) || (nf && !indices)) throw RcError(RC_ERR_INVALID_ARGUMENT, "verts / normals / indices is NULL");
+        for (size_t i = 0; i < 3 * (size_t)nf; ++i)
+            if (indices[i] >= nv) throw RcError(RC_ERR_INVALID_ARGUMENT, "face index out of range");
+        Blas b;
+        DevBuf<float> d_verts;
+        DevBuf<uint32_t> d_vmeta;
+        d_verts.reserve(3 * (size_t)(nv ? nv : 1));
+        b.m_normals.reserve(3 * (size_t)(nv ? nv : 1));
+        b.m_indices.reserve(3 * (size_t)(nf ? nf : 1));
+        if (nv) {
+            RC_HIP(hipMemcpyAsync(d_verts.p, verts, sizeof(float) * 3 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
+            RC_HIP(hipMemcpyAsync(b.m_normals.p, normals, sizeof(float) * 3 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
+        }
+        if (uvs && nv) {
+            b.m_uvs.reserve(2 * (size_t)nv);
+            RC_HIP(hipMemcpyAsync(b.m_uvs.p, uvs, sizeof(float) * 2 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
+            b.has_uvs = true;
+        }
+        if (face_meta && nv) {
+            d_vmeta.reserve(nv);
+            RC_HIP(hipMemcpyAsync(d_vmeta.p, face_meta, sizeof(uint32_t) * (size_t)nv, hipMemcpyHostToDevice, s->stream));
+        }
+        if (nf) RC_HIP(hipMemcpyAsync(b.m_indices.p, indices, sizeof(uint32_t) * 3 * (size_t)nf, hipMemcpyHostToDevice, s->stream));
+        s->vert_stage.reserve(9 * (size_t)(nf ? nf : 1));
+        s->meta_stage.reserve(nf ? nf : 1);
+        rc_expand_mesh(s, d_verts.p, b.m_indices.p, face_meta ? d_vmeta.p : nullptr, nf, s->vert_stage.p, s->meta_stage.p);
+        const uint32_t valid = rc_ingest_faces(s, s->vert_stage.p, s->meta_stage.p, nf, true);
+        if (valid == 0) throw RcError(RC_ERR_EMPTY_GEOMETRY, "Geometry has no valid triangles");  // :601
+        rc_build_blas(s, valid, b, true);
+        b.has_attrs = true;
+        s->blas.push_back(std::move(b));
+        if (blas_id) *blas_id = (uint32_t)s->blas.size() - 1;
+    });
+}
+
+int rc_export_triangles(rc_scene* s, rc_triangle* out, uint32_t capacity, uint32_t* count) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        if (count) *count = s->n_flat_prims;
+        if (!out || s->n_flat_prims == 0) return;
+        if (capacity < s->n_flat_prims) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
+        DevBuf<uint32_t> tmp;
+        tmp.reserve(34 * (size_t)s->n_flat_prims);
+        rc_launch_export_triangles(s, tmp.p, s->stream);
+        RC_HIP(hipMemcpyAsync(out, tmp.p, sizeof(rc_triangle) * (size_t)s->n_flat_prims, hipMemcpyDeviceToHost, s->stream));
+        RC_HIP(hipStreamSynchronize(s->stream));
+    });
+}
+
+int rc_shading_attributes_device(rc_scene* s, const rc_hit* d_hits, uint64_t n, float* d_normals, float* d_uvs, void* stream) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        if (n && !d_hits) throw RcError(RC_ERR_INVALID_ARGUMENT, "hits is NULL");
+        rc_launch_shading_attributes(s, reinterpret_cast<const RcHit*>(d_hits), n, d_normals, d_uvs, (hipStream_t)stream);
+    });
+}
+
 int rc_add_instances_with_inverse(rc_scene* s, uint32_t blas_id, const float* xforms, const float* inv_xforms,
                                   const uint32_t* instance_ids, uint32_t m, uint32_t* handle) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
@@ -408,6 +474,7 @@ int rc_trace_any_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint6
 
 // ---- BVH4 (src/bvh4.jl) ------------------------------------------------------------------------------------------
 static_assert(sizeof(rc_bvh4_node) == 120, "BVHNode4 is 120 bytes");
+static_assert(sizeof(rc_triangle) == 136, "Triangle{UInt32} is 136 bytes");
 
 static Blas& blas4_of(rc_scene* s, uint32_t blas_id) {
     if (blas_id >= s->blas.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "blas_id out of range");

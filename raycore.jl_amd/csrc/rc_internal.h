@@ -55,6 +55,10 @@ struct Blas {  // one geometry: build_blas output (src/instanced-bvh.jl:111-118)
     uint32_t n_prims = 0;
     uint32_t n_nodes = 0;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    // mesh attributes (rc_add_mesh): per-vertex normals / uvs, the face indices and the source face of every sorted primitive
+    DevBuf<float> m_normals, m_uvs;
+    DevBuf<uint32_t> m_indices, src_face;
+    bool has_attrs = false, has_uvs = false;
     // BLAS4 (src/bvh4.jl:154-162), built on request by rc_blas4_build
     DevBuf<RcNode4> nodes4;
     uint32_t n_nodes4 = 0;
@@ -121,6 +125,9 @@ struct rc_scene {
     DevBuf<uint32_t> meta_stage;
     DevBuf<uint32_t> c4_tasks_a, c4_tasks_b, c4_gather, c4_totals;  // BVH4 collapse scratch (rc_bvh4.hip)
     DevBuf<unsigned long long> c4_counts, c4_offsets;
+    DevBuf<uint32_t> slot_face;       // rc_add_mesh: source face of every compacted slot
+    DevBuf<float> flat_attrs;         // 15 floats per flat primitive (normals 9, uv 6), built on demand after a rebuild
+    bool flat_attrs_valid = false;
     DevBuf<uint32_t> collide_counts;  // collide_instances' per-leaf counts / prefix sums (the reference's `cache`)
     DevBuf<uint2> contact_stage;
 
@@ -128,8 +135,12 @@ struct rc_scene {
 };
 
 // rc_build.hip
-uint32_t rc_ingest_faces(rc_scene* s, const float* d_verts, const uint32_t* d_meta, uint32_t n);  // -> s->prim_tmp
-void rc_build_blas(rc_scene* s, uint32_t n, Blas& out);  // builds from s->prim_tmp
+uint32_t rc_ingest_faces(rc_scene* s, const float* d_verts, const uint32_t* d_meta, uint32_t n, bool keep_face_map = false);  // -> s->prim_tmp (+ s->slot_face)
+void rc_build_blas(rc_scene* s, uint32_t n, Blas& out, bool keep_face_map = false);  // builds from s->prim_tmp
+void rc_expand_mesh(rc_scene* s, const float* d_verts, const uint32_t* d_indices, const uint32_t* d_vertex_meta, uint32_t nf, float* d_soup, uint32_t* d_meta);
+void rc_ensure_flat_attrs(rc_scene* s);  // fills s->flat_attrs for the current flat primitive array
+void rc_launch_export_triangles(rc_scene* s, void* d_out, hipStream_t stream);  // 136-byte Triangle{UInt32} records
+void rc_launch_shading_attributes(rc_scene* s, const RcHit* d_hits, uint64_t n, float* d_normals, float* d_uvs, hipStream_t stream);
 void rc_build_tlas(rc_scene* s);   // build_tlas_topology + flat arrays -> StaticTLAS
 void rc_refit_tlas(rc_scene* s);   // refit_tlas!
 void rc_mat3x4_inverse(const float m[12], float out[12]);

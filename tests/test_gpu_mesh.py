@@ -1,0 +1,105 @@
+"""GPU parity: rc_add_mesh (device-side expansion + filter + build), rc_export_triangles (136-byte Triangle records) and
+rc_shading_attributes_device against the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from helpers import assert_hits_equal
+from test_oracle_mesh import grid_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rc():
+    import raycore_jl_amd
+    assert raycore_jl_amd.device_count() > 0, "no GPU visible: the product has no CPU fallback"
+    return raycore_jl_amd
+
+
+def both(rc, po, meshes, soups=()):
+    t, s = rc.TLAS(), po.Scene()
+    for (v, f, nrm, uv, fm) in meshes:
+        t.push_mesh(v, f, nrm, uvs=uv, face_meta=fm)
+        s.add_instance(s.add_mesh(v, f, nrm, uv, fm))
+    for (soup, meta) in soups:
+        t.push(soup, meta=meta)
+        s.add_instance(s.add_blas(soup, meta))
+    t.sync()
+    s.build()
+    return t, s
+
+
+def test_triangles_identical(rc, oracle):
+    v, f, nrm, uv = grid_mesh(40, seed=1)
+    f[17] = [5, 5, 5]
+    f[100] = [7, 8, 7]
+    v2, f2, nrm2, _ = grid_mesh(9, seed=2, with_uv=False)
+    fm2 = np.arange(500, 500 + len(v2), dtype=np.uint32)
+    soup = np.array([[0, 0, 3, 1, 0, 3, 0, 1, 3], [0, 0, 4, 2, 0, 4, 0, 2, 4]], np.float32)
+    t, s = both(rc, oracle, [(v, f, nrm, uv, None), (v2, f2, nrm2, None, fm2)], [(soup, [11, 12])])
+    st = t.adapt()
+    assert st.all_blas_nodes.tobytes() == s.blas_nodes.tobytes()
+    got, want = st.all_blas_triangles, s.triangles
+    assert len(got) == len(want) == len(f) - 2 + len(f2) + 2
+    assert got.tobytes() == want.tobytes()  # NaN tangents included: same bit pattern
+
+
+def test_closest_hit_returns_full_triangle(rc, oracle):
+    v, f, nrm, uv = grid_mesh(10, seed=5)
+    t, s = both(rc, oracle, [(v, f, nrm, uv, None)])
+    hit, tri, dist, bary, inst = rc.closest_hit(t, rc.Ray((0.31, 0.47, 2.0), (0, 0, -1)))
+    assert hit and inst == 1
+    face = f[tri.metadata - 1]
+    assert np.array_equal(tri.vertices, v[face]) and np.array_equal(tri.normals, nrm[face]) and np.array_equal(tri.uv, uv[face])
+    assert np.isnan(tri.tangents).all()
+    miss = rc.closest_hit(t, rc.Ray((5, 5, 2.0), (0, 0, -1)))
+    assert not miss[0] and not miss[1].normals.any() and not miss[1].uv.any()  # empty_triangle (src/triangle_mesh.jl:49-57)
+
+
+def test_shading_attributes_device(rc, oracle):
+    import torch
+    v, f, nrm, uv = grid_mesh(64, seed=6)
+    t, s = both(rc, oracle, [(v, f, nrm, uv, None)], [(np.array([[0, 0, 1, 1, 0, 1, 0, 1, 1]], np.float32), [9])])
+    g = np.random.default_rng(7)
+    n = 100000
+    o = np.c_[g.random((n, 2)) * 1.2 - 0.1, np.full(n, 2.0)].astype(np.float32)
+    rays = rc.scenes.make_rays(o, np.tile([0, 0, -1], (n, 1)))
+    hits = t.trace(rays)
+    assert_hits_equal(hits, s.trace(rays, nthreads=4), "mesh closest")
+    d_h = torch.from_numpy(hits.view(np.uint8).reshape(-1)).cuda()
+    d_n = torch.full((n, 3), 7.0, dtype=torch.float32, device="cuda")
+    d_uv = torch.full((n, 2), 7.0, dtype=torch.float32, device="cuda")
+    t.shading_attributes_device(d_h.data_ptr(), n, d_n.data_ptr(), d_uv.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    wn, wuv = s.shading_attributes(hits)
+    assert np.array_equal(d_n.cpu().numpy().view(np.uint32), wn.view(np.uint32))
+    assert np.array_equal(d_uv.cpu().numpy().view(np.uint32), wuv.view(np.uint32))
+    assert 0 < hits["hit"].sum() < n
+
+
+def test_mesh_errors(rc):
+    v, f, nrm, uv = grid_mesh(3)
+    t = rc.TLAS()
+    bad = f.copy()
+    bad[0, 0] = len(v)
+    with pytest.raises(rc.RaycoreError):
+        t.add_mesh(v, bad, nrm)
+    with pytest.raises(rc.RaycoreError):  # all faces degenerate => "Geometry has no valid triangles" (:601)
+        t.add_mesh(v, np.zeros((4, 3), np.uint32), nrm)
+    with pytest.raises(ValueError):
+        t.add_mesh(v, f, nrm[:-1])
+
+
+def test_mesh_survives_compaction_and_update(rc, oracle):
+    v, f, nrm, uv = grid_mesh(6, seed=8)
+    t = rc.TLAS()
+    h1 = t.push(np.array([[0, 0, 5, 1, 0, 5, 0, 1, 5]], np.float32))
+    h2 = t.push_mesh(v, f, nrm, uvs=uv)
+    t.sync()
+    t.delete(h1)
+    t.sync()  # the mesh BLAS is renumbered by compact_instances!; its attributes must follow
+    tris = t.adapt().all_blas_triangles
+    assert len(tris) == len(f)
+    for tr in tris[:20]:
+        face = f[tr["metadata"] - 1]
+        assert np.array_equal(tr["normals"], nrm[face]) and np.array_equal(tr["uv"], uv[face])
