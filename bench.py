@@ -121,25 +121,25 @@ def main():
             extras[name + "_error"] = f"{type(e).__name__}: {e}"[:300]
 
     def extra_traces():
-        def timed(rs, mode, reps=3):
+        def timed(scene, rs, mode, reps=3):
             dr = torch.from_numpy(rs.view(np.uint8).reshape(-1)).cuda()
             dh = torch.empty(len(rs) * 32, dtype=torch.uint8, device="cuda")
             best = 1e30
             for _ in range(reps):
-                t.trace_device(dr.data_ptr(), dh.data_ptr(), len(rs), mode=mode, stream=stream.cuda_stream)
-                best = min(best, t.last_kernel_ms())
+                scene.trace_device(dr.data_ptr(), dh.data_ptr(), len(rs), mode=mode, stream=stream.cuda_stream)
+                best = min(best, scene.last_kernel_ms())
             return round(len(rs) / best / 1e3, 1)
         shadow = sc.c3_shadow_rays(cfg, rays, hits)
-        extras["c3_any_hit_shadow_mrays_s"] = timed(shadow, "any")
+        extras["c3_any_hit_shadow_mrays_s"] = timed(t, shadow, "any")
         bounce = sc.c4_bounce_rays(cfg, rays, hits, 4 * n)
-        extras["c4_incoherent_16M_closest_mrays_s"] = timed(bounce, "closest")
+        extras["c4_incoherent_16M_closest_mrays_s"] = timed(t, bounce, "closest")
         del bounce, shadow
         cfg2 = sc.config_c2()
         t2 = rc.TLAS(local_rank)
         t2.add_geometry(*cfg2["blas"][0])
         t2.push_instances(1, cfg2["instances"][0][1], cfg2["instances"][0][2])
         t2.sync()
-        extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"]), "closest", reps=5)
+        extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(t2, rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"]), "closest", reps=5)
         t2.free()
 
     if not args.no_extras and rank == 0:
@@ -164,6 +164,38 @@ def main():
 
     if not args.no_extras and rank == 0:
         guarded_extra("builds", extra_builds)
+
+    def extra_bvh4_and_collision():
+        # BVH4 (row a16): collapse time and closest_hit4 rate on C2's 100k-triangle BLAS, same coherent 1 M rays as the BVH2 extra
+        cfg2 = sc.config_c2()
+        t2 = rc.TLAS(local_rank)
+        t2.add_geometry(*cfg2["blas"][0])
+        t2.push_instances(1, cfg2["instances"][0][1], cfg2["instances"][0][2])
+        t2.sync()
+        rs = rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"])
+        t2.free()
+        b4 = rc.build_blas4(*cfg2["blas"][0], device=local_rank)
+        collapse_ms = b4.last_kernel_ms()
+        dr = torch.from_numpy(rs.view(np.uint8).reshape(-1)).cuda()
+        dh = torch.empty(len(rs) * 32, dtype=torch.uint8, device="cuda")
+        best = 1e30
+        for _ in range(5):
+            b4.trace_device(dr.data_ptr(), dh.data_ptr(), len(rs), stream=stream.cuda_stream)
+            best = min(best, b4.last_kernel_ms())
+        extras["bvh4_c2"] = {"collapse_ms": round(collapse_ms, 3), "nodes4": int(b4.num_interior),
+                             "closest_hit4_1M_coherent_mrays_s": round(len(rs) / best / 1e3, 1)}
+        # collision broad phase (src/collision.jl) on 5000 instances
+        g = np.random.default_rng(11)
+        xf = np.tile(sc.IDENTITY3x4, (5000, 1))
+        xf[:, [3, 7, 11]] = (g.random((5000, 3)) * 20).astype(np.float32)
+        tc = rc.TLAS(local_rank)
+        tc.push(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 0, 1, 1, 0, 1, 0, 1, 1]], np.float32), xf)
+        res = rc.collide_instances(tc)
+        extras["collide_instances_5000"] = {"pairs": res.num_contacts, "device_ms": round(tc.last_kernel_ms(), 3)}
+        tc.free()
+
+    if not args.no_extras and rank == 0:
+        guarded_extra("bvh4_collision", extra_bvh4_and_collision)
 
     def extra_view_factors():
         # view_factors (BASELINE config C5: ~50k-triangle closed scene, rays_per_triangle = 4096 => 204.9 M rays, N x N
