@@ -273,6 +273,19 @@ int rc_export_triangles(rc_scene* scene, rc_triangle* out, uint32_t capacity, ui
  * (b1, b2, b3) = ((1-u)-v, u, v); zeros on a miss.  Either output may be NULL.  Saves returning 136-byte Triangles. */
 int rc_shading_attributes_device(rc_scene* scene, const rc_hit* d_hits, uint64_t n, float* d_normals, float* d_uvs, void* stream);
 
+/* More wavefront stages (device buffers, enqueued on `stream`):
+ * rc_primary_rays_lookat_device: generate_primary_rays_lookat! (docs/src/wavefront-renderer.jl:219-254): width*height*samples
+ * rays, ray (pixel-1)*samples + s for the row-major pixel (x, y); u = 2(x - 0.5 + j1)/width - 1, v = 1 - 2(y - 0.5 + j2)/height,
+ * d = normalize(forward + right*(u*half_width) + up*(v*half_height)), t_min 0, t_max Inf.  The reference draws the jitter
+ * from rand(Vec2f); here it is Philox4x32-10 keyed by `seed` with the ray index as counter (jitter != 0) or the pixel
+ * centre (jitter == 0).
+ * rc_compact_hits_device: ascending indices of the rays whose hit flag is set (d_indices, capacity n) and their number
+ * (*d_count, a device u32) -- the queue compaction between stages; the reference's demo keeps dummy rays instead (:445). */
+int rc_primary_rays_lookat_device(rc_scene* scene, const float camera_pos[3], const float camera_right[3], const float camera_up[3],
+                                  const float camera_forward[3], float half_width, float half_height, uint32_t width, uint32_t height,
+                                  uint32_t samples, uint64_t seed, int jitter, rc_ray* d_rays, void* stream);
+int rc_compact_hits_device(rc_scene* scene, const rc_hit* d_hits, uint64_t n, uint32_t* d_indices, uint32_t* d_count, void* stream);
+
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);

@@ -100,6 +100,7 @@ def lib():
         L.rco_scene_triangles.restype = u32
         L.rco_scene_triangles.argtypes = [vp, vp]
         L.rco_shading_attributes.argtypes = [vp, vp, u64, vp, vp]
+        L.rco_primary_rays_lookat.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, u32, u32, u32, u64, C.c_int, vp]
         _lib = L
     return _lib
 
@@ -282,6 +283,14 @@ class Scene:
         out = np.zeros(1, dtype=RAY_DT)
         lib().rco_view_factor_ray(self._h, src_idx0, ray_idx, seed, _p(out))
         return out[0]
+
+
+def primary_rays_lookat(pos, right, up, forward, half_width, half_height, width, height, samples=1, seed=0, jitter=True):
+    out = np.zeros(width * height * samples, dtype=RAY_DT)
+    v = [_f32(a) for a in (pos, right, up, forward)]
+    lib().rco_primary_rays_lookat(_p(v[0]), _p(v[1]), _p(v[2]), _p(v[3]), half_width, half_height, width, height, samples, seed,
+                                  1 if jitter else 0, _p(out))
+    return out
 
 
 def make_rays(origins, directions, tmin=0.0, tmax=np.inf):

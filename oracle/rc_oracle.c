@@ -1283,3 +1283,27 @@ void rco_shading_attributes(const rco_scene* s, const rco_hit* hits, uint64_t n,
         if (uvs) memcpy(uvs + 2 * i, uv, 8);
     }
 }
+
+void rco_primary_rays_lookat(const float pos[3], const float right[3], const float up[3], const float forward[3], float half_width,
+                             float half_height, uint32_t width, uint32_t height, uint32_t samples, uint64_t seed, int jitter, rco_ray* out) {
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (uint32_t y = 1; y <= height; ++y)
+        for (uint32_t x = 1; x <= width; ++x) {
+            uint64_t pixel_idx = (uint64_t)(y - 1) * width + x; /* :234 */
+            for (uint32_t sidx = 1; sidx <= samples; ++sidx) {
+                uint64_t ray_idx = (pixel_idx - 1) * samples + sidx; /* 1-based :237 */
+                uint64_t i = ray_idx - 1;
+                float j1 = 0.5f, j2 = 0.5f;
+                if (jitter) {
+                    uint32_t ctr[4] = {(uint32_t)i, (uint32_t)(i >> 32), 0u, 0x50524159u}, rnd[4];
+                    rco_philox4x32_10(ctr, key, rnd);
+                    j1 = u32_to_unit(rnd[0]); j2 = u32_to_unit(rnd[1]);
+                }
+                float u = 2.0f * ((float)x - 0.5f + j1) / (float)width - 1.0f;   /* :241 */
+                float v = 1.0f - 2.0f * ((float)y - 0.5f + j2) / (float)height;  /* :242 */
+                v3 d = v3_normalize(v3_add(v3_add(v3_from(forward), v3_scale(v3_from(right), u * half_width)), v3_scale(v3_from(up), v * half_height)));
+                rco_ray r = {pos[0], pos[1], pos[2], 0.0f, d.x, d.y, d.z, INFINITY};
+                out[i] = r;
+            }
+        }
+}

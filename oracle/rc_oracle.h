@@ -196,6 +196,11 @@ uint32_t rco_scene_triangles(const rco_scene*, rco_triangle* out);
  * normals: n x 3 floats, uvs: n x 2 floats (either may be NULL). */
 void rco_shading_attributes(const rco_scene*, const rco_hit* hits, uint64_t n, float* normals, float* uvs);
 
+/* generate_primary_rays_lookat! (docs/src/wavefront-renderer.jl:219-254) with rand(Vec2f) replaced by Philox4x32-10 keyed by
+ * `seed`, counter (ray_lo, ray_hi, 0, 0x50524159) -> (j1, j2); jitter == 0 => pixel centres.  out: width*height*samples rays. */
+void rco_primary_rays_lookat(const float pos[3], const float right[3], const float up[3], const float forward[3], float half_width,
+                             float half_height, uint32_t width, uint32_t height, uint32_t samples, uint64_t seed, int jitter, rco_ray* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,8 @@ SYMBOLS = [
     ("rc_add_mesh", _int, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _pu32]),
     ("rc_export_triangles", _int, [_vp, _vp, _u32, _pu32]),
     ("rc_shading_attributes_device", _int, [_vp, _vp, _u64, _vp, _vp, _vp]),
+    ("rc_primary_rays_lookat_device", _int, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _u32, _u32, _u32, _u64, _int, _vp, _vp]),
+    ("rc_compact_hits_device", _int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     ("rc_last_kernel_ms", _int, [_vp, _pf]),
 ]
 

@@ -200,6 +200,17 @@ class TLAS:
             instance_ids = np.array([instance_id], np.uint32)
         return self.push_instances(blas_index, transforms, instance_ids)
 
+    def primary_rays_lookat_device(self, camera_pos, right, up, forward, half_width, half_height, width, height, d_rays, samples=1, seed=0,
+                                   jitter=True, stream=None):
+        """generate_primary_rays_lookat! (docs/src/wavefront-renderer.jl:219-254) into a device RTRay buffer of width*height*samples."""
+        v = [np.ascontiguousarray(a, dtype=np.float32) for a in (camera_pos, right, up, forward)]
+        check(lib().rc_primary_rays_lookat_device(self._h, ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), float(half_width), float(half_height),
+                                                  int(width), int(height), int(samples), int(seed), 1 if jitter else 0, ptr(d_rays), ptr(stream)))
+
+    def compact_hits_device(self, d_hits, n, d_indices, d_count, stream=None):
+        """Ascending indices of the hit rays + their count (device u32): queue compaction between wavefront stages."""
+        check(lib().rc_compact_hits_device(self._h, ptr(d_hits), int(n), ptr(d_indices), ptr(d_count), ptr(stream)))
+
     def shading_attributes_device(self, d_hits, n, d_normals=None, d_uvs=None, stream=None):
         """Interpolated shading normal / uv per hit on device buffers (docs/src/wavefront-renderer.jl:382-387)."""
         check(lib().rc_shading_attributes_device(self._h, ptr(d_hits), int(n), ptr(d_normals), ptr(d_uvs), ptr(stream)))

@@ -590,6 +590,25 @@ int rc_collide_instances_any(rc_scene* s, uint32_t handle_a, uint32_t handle_b, 
     });
 }
 
+int rc_primary_rays_lookat_device(rc_scene* s, const float camera_pos[3], const float camera_right[3], const float camera_up[3], const float camera_forward[3],
+                                  float half_width, float half_height, uint32_t width, uint32_t height, uint32_t samples, uint64_t seed, int jitter,
+                                  rc_ray* d_rays, void* stream) {
+    if (!s || !camera_pos || !camera_right || !camera_up || !camera_forward || !d_rays) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        rc_launch_primary_rays(s, camera_pos, camera_right, camera_up, camera_forward, half_width, half_height, width, height, samples, seed, jitter,
+                               reinterpret_cast<RcRay*>(d_rays), (hipStream_t)stream);
+    });
+}
+
+int rc_compact_hits_device(rc_scene* s, const rc_hit* d_hits, uint64_t n, uint32_t* d_indices, uint32_t* d_count, void* stream) {
+    if (!s || !d_count || (n && (!d_hits || !d_indices))) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        rc_launch_compact_hits(s, reinterpret_cast<const RcHit*>(d_hits), n, d_indices, d_count, (hipStream_t)stream);
+    });
+}
+
 int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     if (!s || !name) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     std::string k(name);

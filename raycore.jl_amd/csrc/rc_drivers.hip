@@ -13,6 +13,8 @@
 // f64 with fixed-order polynomial kernels (fdlibm coefficients) and rounded once to f32 -- Julia's Float32
 // trig also evaluates in higher precision and rounds once -- so the CPU oracle, which uses the same formulas,
 // generates bit-identical rays.
+#include <hipcub/hipcub.hpp>
+
 #include "rc_traverse_core.h"
 
 #include <cmath>
@@ -258,6 +260,47 @@ __global__ void k_shadow_rays(SceneView v, const RcRay* rays, const RcHit* hits,
     }
 }
 
+// generate_primary_rays_lookat! (docs/src/wavefront-renderer.jl:219-254): ray (pixel_idx-1)*samples + s for pixel (x, y)
+// (1-based, row-major pixel_idx = (y-1)*width + x); jitter = rand(Vec2f) there, Philox4x32-10(seed; ray index) here, or the
+// pixel centre when jitter is off.  u, v as written: 2*(x - 0.5 + j1)/width - 1 and 1 - 2*(y - 0.5 + j2)/height.
+struct CameraParams {
+    float pos[3], right[3], up[3], forward[3];
+    float half_width, half_height;
+    uint32_t width, height, samples, jitter;
+    uint32_t k0, k1;
+};
+__global__ void k_primary_rays(CameraParams c, uint64_t n, RcRay* out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t pixel = i / c.samples;
+        const uint32_t x = (uint32_t)(pixel % c.width) + 1u, y = (uint32_t)(pixel / c.width) + 1u;
+        float j1 = 0.5f, j2 = 0.5f;
+        if (c.jitter) {
+            uint32_t rnd[4];
+            philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), 0u, 0x50524159u, c.k0, c.k1, rnd);
+            j1 = u32_to_unit(rnd[0]); j2 = u32_to_unit(rnd[1]);
+        }
+        const float u = 2.0f * ((float)x - 0.5f + j1) / (float)c.width - 1.0f;
+        const float v = 1.0f - 2.0f * ((float)y - 0.5f + j2) / (float)c.height;
+        const float su = u * c.half_width, sv = v * c.half_height;
+        const float3_ d = normalize3(add3(add3(mk3(c.forward[0], c.forward[1], c.forward[2]), scale3(mk3(c.right[0], c.right[1], c.right[2]), su)),
+                                          scale3(mk3(c.up[0], c.up[1], c.up[2]), sv)));
+        float4* q = reinterpret_cast<float4*>(out + i);
+        q[0] = make_float4(c.pos[0], c.pos[1], c.pos[2], 0.0f);
+        q[1] = make_float4(d.x, d.y, d.z, INFINITY);  // Ray(o=..., d=...): t_min 0, t_max Inf (src/ray.jl:1-7)
+    }
+}
+
+__global__ void k_hit_flags(const RcHit* hits, uint64_t n, uint32_t* flags) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = hits[i].hit ? 1u : 0u;
+}
+__global__ void k_scatter_hit_indices(const uint32_t* flags, const uint32_t* pos, uint64_t n, uint32_t* indices, uint32_t* count) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) indices[pos[i]] = (uint32_t)i;
+    if (i == n - 1) *count = pos[i] + flags[i];
+}
+
 float3_ h_normalize(float3_ a) {
     float n = sqrtf(dot3(a, a));
     return mk3(a.x / n, a.y / n, a.z / n);
@@ -364,5 +407,36 @@ void rc_launch_shadow_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits
     if (n == 0) return;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cus * 8);
     hipLaunchKernelGGL(k_shadow_rays, dim3(blocks), dim3(256), 0, stream, rc_scene_view(s, 0), d_rays, d_hits, n, light[0], light[1], light[2], bias, d_out);
+    RC_HIP(hipGetLastError());
+}
+
+void rc_launch_primary_rays(rc_scene* s, const float pos[3], const float right[3], const float up[3], const float forward[3], float half_width,
+                            float half_height, uint32_t width, uint32_t height, uint32_t samples, uint64_t seed, int jitter, RcRay* d_out, hipStream_t stream) {
+    const uint64_t n = (uint64_t)width * height * samples;
+    if (n == 0) return;
+    CameraParams c;
+    for (int k = 0; k < 3; ++k) { c.pos[k] = pos[k]; c.right[k] = right[k]; c.up[k] = up[k]; c.forward[k] = forward[k]; }
+    c.half_width = half_width; c.half_height = half_height;
+    c.width = width; c.height = height; c.samples = samples; c.jitter = jitter ? 1u : 0u;
+    c.k0 = (uint32_t)seed; c.k1 = (uint32_t)(seed >> 32);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cus * 16);
+    hipLaunchKernelGGL(k_primary_rays, dim3(blocks), dim3(256), 0, stream, c, n, d_out);
+    RC_HIP(hipGetLastError());
+}
+
+// Indices of the rays that hit, ascending, and their number: the compaction step between wavefront stages (the reference's
+// demo renderer keeps dummy rays instead, docs/src/wavefront-renderer.jl:445, so every later stage runs over all slots).
+void rc_launch_compact_hits(rc_scene* s, const RcHit* d_hits, uint64_t n, uint32_t* d_indices, uint32_t* d_count, hipStream_t stream) {
+    if (n == 0) { RC_HIP(hipMemsetAsync(d_count, 0, 4, stream)); return; }
+    if (n > 0x7FFFFFFFull) throw RcError(1, "rc_compact_hits: more than 2^31 - 1 rays");
+    s->compact_flags.reserve(n);
+    s->compact_pos.reserve(n);
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(k_hit_flags, dim3(blocks), dim3(256), 0, stream, d_hits, n, s->compact_flags.p);
+    size_t tmp = 0;
+    RC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, s->compact_flags.p, s->compact_pos.p, (int)n, stream));
+    s->compact_tmp.reserve(tmp ? tmp : 1);
+    RC_HIP(hipcub::DeviceScan::ExclusiveSum(s->compact_tmp.p, tmp, s->compact_flags.p, s->compact_pos.p, (int)n, stream));
+    hipLaunchKernelGGL(k_scatter_hit_indices, dim3(blocks), dim3(256), 0, stream, s->compact_flags.p, s->compact_pos.p, n, d_indices, d_count);
     RC_HIP(hipGetLastError());
 }

@@ -128,6 +128,8 @@ struct rc_scene {
     DevBuf<uint32_t> slot_face;       // rc_add_mesh: source face of every compacted slot
     DevBuf<float> flat_attrs;         // 15 floats per flat primitive (normals 9, uv 6), built on demand after a rebuild
     bool flat_attrs_valid = false;
+    DevBuf<uint32_t> compact_flags, compact_pos;  // rc_compact_hits scratch
+    DevBuf<unsigned char> compact_tmp;
     DevBuf<uint32_t> collide_counts;  // collide_instances' per-leaf counts / prefix sums (the reference's `cache`)
     DevBuf<uint2> contact_stage;
 
@@ -163,6 +165,10 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
 void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end,
                             uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix, uint64_t row_stride,
                             uint64_t col_stride, uint32_t row_offset, uint32_t flags, hipStream_t stream);
+
+void rc_launch_primary_rays(rc_scene* s, const float pos[3], const float right[3], const float up[3], const float forward[3], float half_width,
+                            float half_height, uint32_t width, uint32_t height, uint32_t samples, uint64_t seed, int jitter, RcRay* d_out, hipStream_t stream);
+void rc_launch_compact_hits(rc_scene* s, const RcHit* d_hits, uint64_t n, uint32_t* d_indices, uint32_t* d_count, hipStream_t stream);
 
 // rc_traverse.hip helpers shared with rc_drivers.hip
 namespace rc { struct SceneView; }

@@ -550,6 +550,40 @@ def test_wavefront_stages(rc, oracle):
 
 
 # ---- lifecycle (handles, dirty flags, refit identity, errors) -------------------------------------------------
+def test_primary_rays_and_hit_compaction(rc, oracle):
+    """generate_primary_rays_lookat! (docs/src/wavefront-renderer.jl:219-254) bit-exact against the oracle, and the hit-index
+    compaction stage against numpy."""
+    import torch
+    cfg = rc.scenes.config_c1()
+    t = build_product(rc, cfg)
+    pos, fwd = np.array([0.1, -0.2, -3.0], np.float32), np.array([0.0, 0.05, 1.0], np.float32)
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, [0, 1, 0]).astype(np.float32)
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd).astype(np.float32)
+    w, h, spp = 97, 61, 3
+    for jitter in (True, False):
+        d_r = torch.zeros(w * h * spp * 32, dtype=torch.uint8, device="cuda")
+        t.primary_rays_lookat_device(pos, right, up, fwd, 0.4, 0.25, w, h, d_r.data_ptr(), samples=spp, seed=0xABCDEF0123, jitter=jitter)
+        torch.cuda.synchronize()
+        got = d_r.cpu().numpy().view(rc.RAY_DT)
+        want = oracle.primary_rays_lookat(pos, right, up, fwd, 0.4, 0.25, w, h, spp, 0xABCDEF0123, jitter)
+        assert got.tobytes() == want.tobytes()
+    assert np.all(np.abs(np.linalg.norm(got["d"], axis=1) - 1) < 1e-6)
+    hits = t.trace(got)
+    assert 0 < hits["hit"].sum() < len(hits)
+    d_h = torch.from_numpy(hits.view(np.uint8).reshape(-1)).cuda()
+    d_idx = torch.full((len(hits),), -1, dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    t.compact_hits_device(d_h.data_ptr(), len(hits), d_idx.data_ptr(), d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    want_idx = np.nonzero(hits["hit"])[0]
+    assert int(d_cnt.item()) == len(want_idx) and np.array_equal(d_idx.cpu().numpy()[:len(want_idx)], want_idx)
+    t.compact_hits_device(d_h.data_ptr(), 0, d_idx.data_ptr(), d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_cnt.item()) == 0
+
+
 def test_lifecycle_handles_and_errors(rc):  # test/test_instanced_bvh.jl:417-589, test/test_tlas_stress.jl:585-617
     m1, m2 = UNIT_TRI, UNIT_TRI + np.tile([5, 0, 0], 3).astype(np.float32)
     t, hs = rc.TLAS_from_meshes([m1, m2])
