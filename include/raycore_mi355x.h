@@ -286,6 +286,13 @@ int rc_primary_rays_lookat_device(rc_scene* scene, const float camera_pos[3], co
                                   uint32_t samples, uint64_t seed, int jitter, rc_ray* d_rays, void* stream);
 int rc_compact_hits_device(rc_scene* scene, const rc_hit* d_hits, uint64_t n, uint32_t* d_indices, uint32_t* d_count, void* stream);
 
+/* Scene files.  The reference has no on-disk format; this one keeps what a rebuild would recompute (per geometry: sorted
+ * primitives, BVH2 nodes, mesh attributes; plus instance descriptors and the handle table).  rc_scene_save needs a synced
+ * scene; rc_scene_load returns an unsynced scene whose handles are the saved ones -- rc_sync rebuilds the TLAS, after
+ * which it traces bit-identically to the saved scene. */
+int rc_scene_save(rc_scene* scene, const char* path);
+int rc_scene_load(int device, const char* path, rc_scene** out);
+
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);

@@ -125,6 +125,20 @@ class TLAS:
         self._prims_cache = None
 
     # -- lifetime -------------------------------------------------------------------------------------
+    def save(self, path):
+        """Write the synced scene to a file (geometry BVHs, attributes, instances, handles); see rc_scene_save."""
+        self.sync()
+        check(lib().rc_scene_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load(cls, path, device=0):
+        """Read a scene file written by save(); handles keep their ids."""
+        t = cls.__new__(cls)
+        h = C.c_void_p()
+        check(lib().rc_scene_load(int(device), str(path).encode(), C.byref(h)))
+        t._h, t.device, t._static, t._prims_cache = h, device, StaticTLAS(t), None
+        return t
+
     def free(self):  # free!, :383-399
         if getattr(self, "_h", None):
             lib().rc_scene_destroy(self._h)

@@ -5,6 +5,7 @@
 // All compute happens in the HIP kernels of rc_build.hip / rc_traverse.hip / rc_drivers.hip; there is no
 // CPU fallback -- without a device every entry point that needs one fails with RC_ERR_NO_DEVICE.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 #include "../../include/raycore_mi355x.h"
@@ -98,6 +99,28 @@ void export_nodes(rc_scene* s, const RcNode* d, uint32_t n, rc_bvh_node* out, ui
     }
 }
 
+}  // namespace
+
+namespace {
+constexpr char kSceneMagic[8] = {'R', 'C', 'M', 'I', '3', '5', '5', 'X'};
+constexpr uint32_t kSceneVersion = 1;
+
+struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
+void put(FILE* f, const void* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene file: write failed"); }
+void get(FILE* f, void* p, size_t n) { if (n && fread(p, 1, n, f) != n) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene file: truncated"); }
+template <typename T> void put_dev(FILE* f, const T* d, size_t n, std::vector<unsigned char>& tmp) {
+    if (!n) return;
+    tmp.resize(n * sizeof(T));
+    RC_HIP(hipMemcpy(tmp.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
+    put(f, tmp.data(), tmp.size());
+}
+template <typename T> void get_dev(FILE* f, DevBuf<T>& d, size_t n, std::vector<unsigned char>& tmp) {
+    d.reserve(n ? n : 1);
+    if (!n) return;
+    tmp.resize(n * sizeof(T));
+    get(f, tmp.data(), tmp.size());
+    RC_HIP(hipMemcpy(d.p, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
+}
 }  // namespace
 
 extern "C" {
@@ -221,6 +244,7 @@ int rc_add_mesh(rc_scene* s, const float* verts, const float* normals, const flo
         if (valid == 0) throw RcError(RC_ERR_EMPTY_GEOMETRY, "Geometry has no valid triangles");  // :601
         rc_build_blas(s, valid, b, true);
         b.has_attrs = true;
+        b.n_mesh_verts = nv; b.n_mesh_faces = nf;
         s->blas.push_back(std::move(b));
         if (blas_id) *blas_id = (uint32_t)s->blas.size() - 1;
     });
@@ -607,6 +631,98 @@ int rc_compact_hits_device(rc_scene* s, const rc_hit* d_hits, uint64_t n, uint32
         use_device(s);
         rc_launch_compact_hits(s, reinterpret_cast<const RcHit*>(d_hits), n, d_indices, d_count, (hipStream_t)stream);
     });
+}
+
+// ---- scene files ------------------------------------------------------------------------------------------------------
+// The reference has no on-disk format; this one stores what a rebuild would otherwise recompute: per
+// geometry the Morton-sorted primitives, the BVH2 nodes and the mesh attributes, plus the instance descriptors and the handle
+// table.  Loading uploads the arrays and lets rc_sync rebuild the (cheap) TLAS, so a loaded scene traces bit-identically.
+int rc_scene_save(rc_scene* s, const char* path) {
+    if (!s || !path) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);  // compaction has run: no deleted handles, no unreferenced geometry
+        RC_HIP(hipStreamSynchronize(s->stream));
+        FileCloser fc{fopen(path, "wb")};
+        if (!fc.f) throw RcError(RC_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path);
+        std::vector<unsigned char> tmp;
+        const uint32_t hdr[6] = {kSceneVersion, (uint32_t)s->blas.size(), (uint32_t)s->instances.size(), s->next_handle_id,
+                                 (uint32_t)s->handle_to_range.size(), 0u};
+        put(fc.f, kSceneMagic, 8);
+        put(fc.f, hdr, sizeof(hdr));
+        for (auto& kv : s->handle_to_range) {
+            const uint32_t rec[3] = {kv.first, kv.second.first, kv.second.count};
+            put(fc.f, rec, sizeof(rec));
+        }
+        put(fc.f, s->instances.data(), sizeof(RcInstanceDesc) * s->instances.size());
+        for (const Blas& b : s->blas) {
+            const uint32_t bh[6] = {b.n_prims, b.n_nodes, b.has_attrs ? 1u : 0u, b.has_uvs ? 1u : 0u, b.n_mesh_verts, b.n_mesh_faces};
+            put(fc.f, bh, sizeof(bh));
+            put(fc.f, b.root_min, 12);
+            put(fc.f, b.root_max, 12);
+            put_dev(fc.f, b.prims.p, b.n_prims, tmp);
+            put_dev(fc.f, b.nodes.p, b.n_nodes, tmp);
+            if (b.has_attrs) {
+                put_dev(fc.f, b.m_normals.p, 3 * (size_t)b.n_mesh_verts, tmp);
+                if (b.has_uvs) put_dev(fc.f, b.m_uvs.p, 2 * (size_t)b.n_mesh_verts, tmp);
+                put_dev(fc.f, b.m_indices.p, 3 * (size_t)b.n_mesh_faces, tmp);
+                put_dev(fc.f, b.src_face.p, b.n_prims, tmp);
+            }
+        }
+        if (fflush(fc.f) != 0) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene file: flush failed");
+    });
+}
+
+int rc_scene_load(int device, const char* path, rc_scene** out) {
+    if (!path || !out) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    rc_scene* s = nullptr;
+    int rc = rc_scene_create(device, &s);
+    if (rc != RC_OK) return rc;
+    rc = guarded([&] {
+        use_device(s);
+        FileCloser fc{fopen(path, "rb")};
+        if (!fc.f) throw RcError(RC_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path);
+        char magic[8];
+        uint32_t hdr[6];
+        get(fc.f, magic, 8);
+        get(fc.f, hdr, sizeof(hdr));
+        if (memcmp(magic, kSceneMagic, 8) != 0 || hdr[0] != kSceneVersion) throw RcError(RC_ERR_INVALID_ARGUMENT, "not a raycore-mi355x scene file (or wrong version)");
+        const uint32_t n_blas = hdr[1], n_inst = hdr[2], n_handles = hdr[4];
+        s->next_handle_id = hdr[3];
+        for (uint32_t i = 0; i < n_handles; ++i) {
+            uint32_t rec[3];
+            get(fc.f, rec, sizeof(rec));
+            if ((uint64_t)rec[1] + rec[2] > n_inst) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene file: handle range out of bounds");
+            s->handle_to_range[rec[0]] = HandleRange{rec[1], rec[2]};
+        }
+        s->instances.resize(n_inst);
+        get(fc.f, s->instances.data(), sizeof(RcInstanceDesc) * n_inst);
+        for (auto& in : s->instances)
+            if (in.blas_index < 1 || in.blas_index > n_blas) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene file: instance refers to a missing geometry");
+        std::vector<unsigned char> tmp;
+        s->blas.resize(n_blas);
+        for (Blas& b : s->blas) {
+            uint32_t bh[6];
+            get(fc.f, bh, sizeof(bh));
+            b.n_prims = bh[0]; b.n_nodes = bh[1]; b.has_attrs = bh[2] != 0; b.has_uvs = bh[3] != 0; b.n_mesh_verts = bh[4]; b.n_mesh_faces = bh[5];
+            if (b.n_prims == 0 || b.n_nodes != 2 * b.n_prims - 1) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene file: inconsistent geometry header");
+            get(fc.f, b.root_min, 12);
+            get(fc.f, b.root_max, 12);
+            get_dev(fc.f, b.prims, b.n_prims, tmp);
+            get_dev(fc.f, b.nodes, b.n_nodes, tmp);
+            if (b.has_attrs) {
+                get_dev(fc.f, b.m_normals, 3 * (size_t)b.n_mesh_verts, tmp);
+                if (b.has_uvs) get_dev(fc.f, b.m_uvs, 2 * (size_t)b.n_mesh_verts, tmp);
+                get_dev(fc.f, b.m_indices, 3 * (size_t)b.n_mesh_faces, tmp);
+                get_dev(fc.f, b.src_face, b.n_prims, tmp);
+            }
+        }
+        s->dirty = true;  // the TLAS and the flat arrays are rebuilt by the next rc_sync
+    });
+    if (rc != RC_OK) { rc_scene_destroy(s); return rc; }
+    *out = s;
+    return RC_OK;
 }
 
 int rc_set_option(rc_scene* s, const char* name, int64_t value) {

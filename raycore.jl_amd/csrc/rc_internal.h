@@ -59,6 +59,7 @@ struct Blas {  // one geometry: build_blas output (src/instanced-bvh.jl:111-118)
     DevBuf<float> m_normals, m_uvs;
     DevBuf<uint32_t> m_indices, src_face;
     bool has_attrs = false, has_uvs = false;
+    uint32_t n_mesh_verts = 0, n_mesh_faces = 0;
     // BLAS4 (src/bvh4.jl:154-162), built on request by rc_blas4_build
     DevBuf<RcNode4> nodes4;
     uint32_t n_nodes4 = 0;

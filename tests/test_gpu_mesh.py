@@ -103,3 +103,36 @@ def test_mesh_survives_compaction_and_update(rc, oracle):
     for tr in tris[:20]:
         face = f[tr["metadata"] - 1]
         assert np.array_equal(tr["normals"], nrm[face]) and np.array_equal(tr["uv"], uv[face])
+
+
+def test_scene_save_load_roundtrip(rc, oracle, tmp_path):
+    """rc_scene_save / rc_scene_load: a loaded scene exports the same arrays, keeps its handles and traces bit-identically."""
+    v, f, nrm, uv = grid_mesh(20, seed=9)
+    soup = rc.scenes.random_triangles(500, 3, lo=-1, hi=1, edge=0.3)
+    t = rc.TLAS()
+    xf, _, _ = rc.scenes.lattice_transforms(2, 2, 1, 2.5, 4)
+    h_mesh = t.push_mesh(v, f, nrm, transforms=xf[:3].reshape(3, 12), uvs=uv, instance_ids=[5, 6, 7])
+    h_soup = t.push(soup, xf[3:4].reshape(1, 12), instance_id=9)
+    h_gone = t.push(soup[:10])
+    t.sync()
+    t.delete(h_gone)
+    path = tmp_path / "scene.rcs"
+    t.save(path)
+    u = rc.TLAS.load(path)
+    assert not u.is_valid(h_gone) and u.is_valid(h_mesh) and u.n_instances(h_mesh) == 3 and u.n_instances(h_soup) == 1
+    a, b = t.adapt(), u.adapt()
+    for name in ("nodes", "instances", "all_blas_nodes", "all_blas_prims", "blas_descriptors", "all_blas_triangles"):
+        assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), name
+    g = np.random.default_rng(1)
+    rays = rc.scenes.make_rays(g.uniform(-4, 4, (20000, 3)), rc.scenes.normalize(g.normal(size=(20000, 3))))
+    assert_hits_equal(u.trace(rays), t.trace(rays), "loaded scene")
+    # the loaded scene is a live, mutable TLAS: handles work, new handle ids do not collide
+    u.update_transforms(h_mesh, xf[:3].reshape(3, 12) * np.float32(1.0))
+    h_new = u.push(soup[:5])
+    assert h_new.id not in (h_mesh.id, h_soup.id, h_gone.id)
+    u.sync()
+    with pytest.raises(rc.RaycoreError):
+        rc.TLAS.load(tmp_path / "missing.rcs")
+    (tmp_path / "junk.rcs").write_bytes(b"not a scene file at all, definitely")
+    with pytest.raises(rc.RaycoreError):
+        rc.TLAS.load(tmp_path / "junk.rcs")
