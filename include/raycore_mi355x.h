@@ -264,6 +264,9 @@ typedef struct rc_triangle {
  * Expansion, is_degenerate_face filtering (:573-577), build_triangle (:555-566) and the LBVH build run on the device. */
 int rc_add_mesh(rc_scene* scene, const float* verts, const float* normals, const float* uvs, uint32_t nv,
                 const uint32_t* indices, uint32_t nf, const uint32_t* face_meta, uint32_t* blas_id);
+/* update!(tlas, handle, new_mesh) (src/instanced-bvh.jl:808-857) for a decomposed mesh: replaces the BLAS the handle uses. */
+int rc_update_geometry_mesh(rc_scene* scene, uint32_t handle, const float* verts, const float* normals, const float* uvs, uint32_t nv,
+                            const uint32_t* indices, uint32_t nf, const uint32_t* face_meta);
 /* all_blas_prims as full Triangles (synced scene; count query when out == NULL).  Geometry that came in as plain soup
  * (rc_add_blas*) has no mesh attributes: normals = geometric normal normalize((v1-v0) x (v2-v0)), uv = the reference's
  * default (0,0),(1,0),(1,1) (:561-565); tangents are NaN as in build_triangle. */

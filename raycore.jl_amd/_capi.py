@@ -85,6 +85,7 @@ SYMBOLS = [
     ("rc_collide_instances_device", _int, [_vp, _vp, _u64, C.POINTER(_u64), _vp]),
     ("rc_collide_instances_any", _int, [_vp, _u32, _u32, _pint]),
     ("rc_add_mesh", _int, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _pu32]),
+    ("rc_update_geometry_mesh", _int, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _u32, _vp]),
     ("rc_export_triangles", _int, [_vp, _vp, _u32, _pu32]),
     ("rc_shading_attributes_device", _int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     ("rc_primary_rays_lookat_device", _int, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _u32, _u32, _u32, _u64, _int, _vp, _vp]),

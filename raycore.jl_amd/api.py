@@ -204,6 +204,19 @@ class TLAS:
         self._prims_cache = None
         return blas_id.value + 1
 
+    def update_mesh(self, handle, verts, faces, normals, uvs=None, face_meta=None):
+        """update!(tlas, handle, new_mesh) (:808-857) for a decomposed mesh."""
+        v = np.ascontiguousarray(np.asarray(verts, dtype=np.float32).reshape(-1, 3))
+        nrm = np.ascontiguousarray(np.asarray(normals, dtype=np.float32).reshape(-1, 3))
+        f = np.ascontiguousarray(np.asarray(faces, dtype=np.uint32).reshape(-1, 3))
+        uv = None if uvs is None else np.ascontiguousarray(np.asarray(uvs, dtype=np.float32).reshape(-1, 2))
+        fm = None if face_meta is None else np.ascontiguousarray(face_meta, dtype=np.uint32)
+        if len(nrm) != len(v) or (uv is not None and len(uv) != len(v)) or (fm is not None and len(fm) != len(v)):
+            raise ValueError("normals / uvs / face_meta must have one entry per vertex")
+        check(lib().rc_update_geometry_mesh(self._h, handle.id, ptr(v), ptr(nrm), ptr(uv), len(v), ptr(f), len(f), ptr(fm)))
+        self._prims_cache = None
+        return handle
+
     def push_mesh(self, verts, faces, normals, transforms=None, uvs=None, face_meta=None, instance_id=0, instance_ids=None):
         """push!(tlas, mesh, transforms; instance_ids) (:639-676) for a decomposed mesh; returns the TLASHandle."""
         blas_index = self.add_mesh(verts, faces, normals, uvs, face_meta)

@@ -209,44 +209,65 @@ int rc_add_blas_device(rc_scene* s, const float* d_verts, const uint32_t* d_meta
     });
 }
 
+// build_and_append_blas! body for a decomposed mesh (src/instanced-bvh.jl:581-600): upload, expand by index, filter, build
+static void build_mesh_blas(rc_scene* s, const float* verts, const float* normals, const float* uvs, uint32_t nv, const uint32_t* indices, uint32_t nf,
+                            const uint32_t* face_meta, Blas& b) {
+    if ((nv && (!verts || !normals)) || (nf && !indices)) throw RcError(RC_ERR_INVALID_ARGUMENT, "verts / normals / indices is NULL");
+    for (size_t i = 0; i < 3 * (size_t)nf; ++i)
+        if (indices[i] >= nv) throw RcError(RC_ERR_INVALID_ARGUMENT, "face index out of range");
+    DevBuf<float> d_verts;
+    DevBuf<uint32_t> d_vmeta;
+    d_verts.reserve(3 * (size_t)(nv ? nv : 1));
+    b.m_normals.reserve(3 * (size_t)(nv ? nv : 1));
+    b.m_indices.reserve(3 * (size_t)(nf ? nf : 1));
+    if (nv) {
+        RC_HIP(hipMemcpyAsync(d_verts.p, verts, sizeof(float) * 3 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
+        RC_HIP(hipMemcpyAsync(b.m_normals.p, normals, sizeof(float) * 3 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
+    }
+    if (uvs && nv) {
+        b.m_uvs.reserve(2 * (size_t)nv);
+        RC_HIP(hipMemcpyAsync(b.m_uvs.p, uvs, sizeof(float) * 2 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
+        b.has_uvs = true;
+    }
+    if (face_meta && nv) {
+        d_vmeta.reserve(nv);
+        RC_HIP(hipMemcpyAsync(d_vmeta.p, face_meta, sizeof(uint32_t) * (size_t)nv, hipMemcpyHostToDevice, s->stream));
+    }
+    if (nf) RC_HIP(hipMemcpyAsync(b.m_indices.p, indices, sizeof(uint32_t) * 3 * (size_t)nf, hipMemcpyHostToDevice, s->stream));
+    s->vert_stage.reserve(9 * (size_t)(nf ? nf : 1));
+    s->meta_stage.reserve(nf ? nf : 1);
+    rc_expand_mesh(s, d_verts.p, b.m_indices.p, face_meta ? d_vmeta.p : nullptr, nf, s->vert_stage.p, s->meta_stage.p);
+    const uint32_t valid = rc_ingest_faces(s, s->vert_stage.p, s->meta_stage.p, nf, true);
+    if (valid == 0) throw RcError(RC_ERR_EMPTY_GEOMETRY, "Geometry has no valid triangles");  // :601
+    rc_build_blas(s, valid, b, true);  // synchronises the stream: the temporaries above may go
+    b.has_attrs = true;
+    b.n_mesh_verts = nv; b.n_mesh_faces = nf;
+}
+
 int rc_add_mesh(rc_scene* s, const float* verts, const float* normals, const float* uvs, uint32_t nv, const uint32_t* indices, uint32_t nf,
                 const uint32_t* face_meta, uint32_t* blas_id) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
     return guarded([&] {
         use_device(s);
-        if ((nv && (!verts || !normals)) || (nf && !indices)) throw RcError(RC_ERR_INVALID_ARGUMENT, "verts / normals / indices is NULL");
-        for (size_t i = 0; i < 3 * (size_t)nf; ++i)
-            if (indices[i] >= nv) throw RcError(RC_ERR_INVALID_ARGUMENT, "face index out of range");
         Blas b;
-        DevBuf<float> d_verts;
-        DevBuf<uint32_t> d_vmeta;
-        d_verts.reserve(3 * (size_t)(nv ? nv : 1));
-        b.m_normals.reserve(3 * (size_t)(nv ? nv : 1));
-        b.m_indices.reserve(3 * (size_t)(nf ? nf : 1));
-        if (nv) {
-            RC_HIP(hipMemcpyAsync(d_verts.p, verts, sizeof(float) * 3 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
-            RC_HIP(hipMemcpyAsync(b.m_normals.p, normals, sizeof(float) * 3 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
-        }
-        if (uvs && nv) {
-            b.m_uvs.reserve(2 * (size_t)nv);
-            RC_HIP(hipMemcpyAsync(b.m_uvs.p, uvs, sizeof(float) * 2 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
-            b.has_uvs = true;
-        }
-        if (face_meta && nv) {
-            d_vmeta.reserve(nv);
-            RC_HIP(hipMemcpyAsync(d_vmeta.p, face_meta, sizeof(uint32_t) * (size_t)nv, hipMemcpyHostToDevice, s->stream));
-        }
-        if (nf) RC_HIP(hipMemcpyAsync(b.m_indices.p, indices, sizeof(uint32_t) * 3 * (size_t)nf, hipMemcpyHostToDevice, s->stream));
-        s->vert_stage.reserve(9 * (size_t)(nf ? nf : 1));
-        s->meta_stage.reserve(nf ? nf : 1);
-        rc_expand_mesh(s, d_verts.p, b.m_indices.p, face_meta ? d_vmeta.p : nullptr, nf, s->vert_stage.p, s->meta_stage.p);
-        const uint32_t valid = rc_ingest_faces(s, s->vert_stage.p, s->meta_stage.p, nf, true);
-        if (valid == 0) throw RcError(RC_ERR_EMPTY_GEOMETRY, "Geometry has no valid triangles");  // :601
-        rc_build_blas(s, valid, b, true);
-        b.has_attrs = true;
-        b.n_mesh_verts = nv; b.n_mesh_faces = nf;
+        build_mesh_blas(s, verts, normals, uvs, nv, indices, nf, face_meta, b);
         s->blas.push_back(std::move(b));
         if (blas_id) *blas_id = (uint32_t)s->blas.size() - 1;
+    });
+}
+
+int rc_update_geometry_mesh(rc_scene* s, uint32_t handle, const float* verts, const float* normals, const float* uvs, uint32_t nv, const uint32_t* indices,
+                            uint32_t nf, const uint32_t* face_meta) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        HandleRange& r = live_range(s, handle);
+        if (r.count == 0) throw RcError(RC_ERR_INVALID_HANDLE, "Handle has no instances");
+        const uint32_t blas_idx = s->instances[r.first].blas_index;  // :814-816
+        Blas b;
+        build_mesh_blas(s, verts, normals, uvs, nv, indices, nf, face_meta, b);
+        s->blas[blas_idx - 1] = std::move(b);
+        s->dirty = true;
     });
 }
 

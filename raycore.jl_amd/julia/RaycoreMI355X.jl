@@ -52,17 +52,27 @@ function Raycore.free!(t::MI355XTLAS)                                   # free!,
     return nothing
 end
 
-# ---- mesh ingestion stays in Julia: GeometryBasics decomposition as in build_and_append_blas! (:581-600) ----
-function triangle_soup(mesh::GeometryBasics.Mesh)
+# ---- mesh ingestion: the GeometryBasics decomposition stays in Julia exactly as in build_and_append_blas! (:581-590); the
+# per-face work (index expansion, degenerate filter, build_triangle, LBVH) happens in the library (rc_add_mesh).
+function decomposed(mesh::GeometryBasics.Mesh)
     nmesh = GeometryBasics.expand_faceviews(mesh)
     fs = decompose(TriangleFace{UInt32}, nmesh)
     verts = decompose(Point3f, nmesh)
-    soup = Vector{Float32}(undef, 9 * length(fs))
-    for (i, f) in enumerate(fs), k in 1:3, c in 1:3
-        soup[9 * (i - 1) + 3 * (k - 1) + c] = verts[f[k]][c]
-    end
-    meta = hasproperty(nmesh, :face_meta) ? UInt32[nmesh.face_meta[f[1]] for f in fs] : nothing   # :595
-    return soup, meta, length(fs)
+    norms = Raycore.Normal3f.(decompose_normals(nmesh))
+    uvs_raw = GeometryBasics.decompose_uv(nmesh)
+    indices = collect(reinterpret(UInt32, fs)) .- UInt32(1)                                     # 0-based at the C boundary
+    face_meta = hasproperty(nmesh, :face_meta) ? UInt32.(nmesh.face_meta) : nothing             # per vertex after expand_faceviews (:595)
+    return (verts = collect(reinterpret(Float32, verts)), normals = collect(reinterpret(Float32, norms)),
+            uvs = isnothing(uvs_raw) ? nothing : collect(reinterpret(Float32, Point2f.(uvs_raw))),
+            nv = length(verts), indices = indices, nf = length(fs), face_meta = face_meta)
+end
+function add_mesh!(t, mesh::GeometryBasics.Mesh)
+    d = decomposed(mesh)
+    blas = Ref{UInt32}(0)
+    check(ccall((:rc_add_mesh, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{UInt32}, Ref{UInt32}),
+                t.ptr, d.verts, d.normals, d.uvs === nothing ? C_NULL : d.uvs, d.nv, d.indices, d.nf,
+                d.face_meta === nothing ? C_NULL : d.face_meta, blas))
+    return blas[]
 end
 
 xforms_buffer(ts::AbstractVector{Mat3x4f}) = collect(reinterpret(Float32, ts))     # Mat3x4f bytes == Vulkan 3x4 (:28-31)
@@ -72,10 +82,7 @@ function Base.push!(t::MI355XTLAS, mesh::GeometryBasics.Mesh, transforms::Abstra
                     instance_ids::Union{Nothing, AbstractVector{<:Integer}} = nothing, sbt_offset::UInt32 = UInt32(0))
     instance_ids !== nothing && length(instance_ids) != length(transforms) &&
         throw(ArgumentError("instance_ids length $(length(instance_ids)) != transforms length $(length(transforms))"))   # :664-666
-    soup, meta, n = triangle_soup(mesh)
-    blas = Ref{UInt32}(0); handle = Ref{UInt32}(0)
-    check(ccall((:rc_add_blas, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{UInt32}, UInt32, Ref{UInt32}),
-                t.ptr, soup, meta === nothing ? C_NULL : meta, n, blas))
+    blas = Ref{UInt32}(add_mesh!(t, mesh)); handle = Ref{UInt32}(0)
     ids = instance_ids === nothing ? C_NULL : UInt32.(instance_ids)
     check(ccall((:rc_add_instances, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{Float32}, Ptr{UInt32}, UInt32, Ref{UInt32}),
                 t.ptr, blas[], xforms_buffer(transforms), ids, length(transforms), handle))
@@ -103,9 +110,10 @@ function Raycore.update_transform!(t::MI355XTLAS, h::TLASHandle, transform)     
     Raycore.update_transforms!(t, h, [transform])
 end
 function Raycore.update!(t::MI355XTLAS, h::TLASHandle, mesh::GeometryBasics.Mesh)              # :808-857
-    soup, meta, n = triangle_soup(mesh)
-    check(ccall((:rc_update_geometry, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{Float32}, Ptr{UInt32}, UInt32),
-                t.ptr, h.id, soup, meta === nothing ? C_NULL : meta, n))
+    d = decomposed(mesh)
+    check(ccall((:rc_update_geometry_mesh, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{UInt32}),
+                t.ptr, h.id, d.verts, d.normals, d.uvs === nothing ? C_NULL : d.uvs, d.nv, d.indices, d.nf,
+                d.face_meta === nothing ? C_NULL : d.face_meta))
     t.prims_valid = false
     return nothing
 end
@@ -164,19 +172,13 @@ function trace(a::MI355XStaticTLAS, rays::Vector{RTRay}; any::Bool = false)
     return hits
 end
 
-function primitives(a::MI355XStaticTLAS)            # all_blas_prims: vertices + metadata from the library, shading fields from the caller's meshes
+function primitives(a::MI355XStaticTLAS)            # all_blas_prims as Triangle{UInt32} values: the library's 136-byte records ARE that struct
     t = a.owner
     if !t.prims_valid
         n = Ref{UInt32}(0)
-        check(ccall((:rc_export_prims, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ref{UInt32}), t.ptr, C_NULL, 0, n))
-        raw = Vector{NTuple{10, UInt32}}(undef, n[])
-        check(ccall((:rc_export_prims, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ref{UInt32}), t.ptr, raw, n[], n))
-        t.prims = map(raw) do p
-            v = reinterpret.(Float32, p[1:9])
-            Triangle{UInt32}(SVector(Point3f(v[1:3]...), Point3f(v[4:6]...), Point3f(v[7:9]...)),
-                             SVector{3, Raycore.Normal3f}(ntuple(_ -> Raycore.Normal3f(0), 3)), SVector{3, Vec3f}(ntuple(_ -> Vec3f(NaN), 3)),
-                             SVector(Point2f(0), Point2f(1, 0), Point2f(1, 1)), p[10])
-        end
+        check(ccall((:rc_export_triangles, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ref{UInt32}), t.ptr, C_NULL, 0, n))
+        t.prims = Vector{Triangle{UInt32}}(undef, n[])       # sizeof(Triangle{UInt32}) == 136 (src/triangle_mesh.jl:1-7)
+        check(ccall((:rc_export_triangles, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ref{UInt32}), t.ptr, t.prims, n[], n))
         t.prims_valid = true
     end
     return t.prims
@@ -217,9 +219,7 @@ struct MI355XBLAS4
 end
 function build_blas4_mi355x(backend::MI355XBackend, mesh::GeometryBasics.Mesh)                   # build_blas4, :511-522
     t = MI355XTLAS(backend)
-    verts, meta = triangle_soup(mesh)
-    id = Ref{UInt32}(0); n = Ref{UInt32}(0)
-    check(ccall((:rc_add_blas, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{UInt32}, UInt32, Ref{UInt32}), t.ptr, verts, meta, length(meta), id))
+    id = Ref{UInt32}(add_mesh!(t, mesh)); n = Ref{UInt32}(0)
     check(ccall((:rc_blas4_build, LIB), Cint, (Ptr{Cvoid}, UInt32, Ref{UInt32}), t.ptr, id[], n))
     return MI355XBLAS4(t, id[], Int32(n[]))
 end

@@ -136,3 +136,17 @@ def test_scene_save_load_roundtrip(rc, oracle, tmp_path):
     (tmp_path / "junk.rcs").write_bytes(b"not a scene file at all, definitely")
     with pytest.raises(rc.RaycoreError):
         rc.TLAS.load(tmp_path / "junk.rcs")
+
+
+def test_update_mesh_replaces_geometry(rc, oracle):
+    v, f, nrm, uv = grid_mesh(8, seed=10)
+    v2, f2, nrm2, uv2 = grid_mesh(5, seed=11)
+    t = rc.TLAS()
+    h = t.push_mesh(v, f, nrm, uvs=uv)
+    t.sync()
+    t.update_mesh(h, v2 + np.float32(0.25), f2, nrm2, uvs=uv2)
+    s = oracle.Scene()
+    s.add_instance(s.add_mesh(v2 + np.float32(0.25), f2, nrm2, uv2))
+    s.build()
+    st = t.adapt()
+    assert st.all_blas_nodes.tobytes() == s.blas_nodes.tobytes() and st.all_blas_triangles.tobytes() == s.triangles.tobytes()
