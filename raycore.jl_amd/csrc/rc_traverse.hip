@@ -429,17 +429,17 @@ static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hip
 #define RC_LAUNCH_P(L, W) hipLaunchKernelGGL((k_trace_persistent<ANY, L, W, false>), dim3(blocks), dim3(kBlock), 0, stream, a)
 #define RC_LAUNCH_S(L, W) hipLaunchKernelGGL((k_trace_simple<ANY, L, W>), dim3(blocks), dim3(kBlock), 0, stream, a)
     if (s->opt.kernel == 4) {
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[ANY ? 1 : 0]) {
+        bool& attr_set = s->lds_attr_set[ANY ? 1 : 0];  // per scene = per device: the attribute belongs to the function on one device
+        if (!attr_set) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kBigBlock, kLdsStack, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes));
-            attr_set[ANY ? 1 : 0] = true;
+            attr_set = true;
         }
         hipLaunchKernelGGL((k_trace_phased_lds<ANY, kBigBlock, kLdsStack, true, 4>), dim3(blocks), dim3(kBigBlock), kBigLdsBytes, stream, a);
     } else if (s->opt.kernel == 5) {
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[ANY ? 1 : 0]) {
+        bool& attr_set = s->lds_attr_set[2 + (ANY ? 1 : 0)];
+        if (!attr_set) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, false, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
-            attr_set[ANY ? 1 : 0] = true;
+            attr_set = true;
         }
         hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, false, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
     } else if (s->opt.kernel == 3) {
