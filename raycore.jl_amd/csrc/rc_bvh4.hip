@@ -427,9 +427,7 @@ void rc_launch_trace4(rc_scene* s, const Blas& b, const RcRay* d_rays, RcHit* d_
     a.nodes = b.nodes4.p; a.n_nodes = b.n_nodes4; a.root_word = b.root_word4; a.n_prims = b.n_prims;
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
     a.work_counter = reinterpret_cast<unsigned long long*>(rc_counter_slot(s));
-    uint64_t per = n / ((uint64_t)(total_threads / 64) * 4);
-    per = (per / 64) * 64;
-    a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : (per < 64 ? 64 : (per > 128 ? 128 : per)));
+    a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
     a.refill = (int)s->opt.refill;
     a.int_thr = (int)s->opt.sched_thr;
     a.overflow = s->overflow_stack.p; a.total_threads = total_threads;

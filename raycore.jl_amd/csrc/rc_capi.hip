@@ -755,6 +755,7 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "refill") s->opt.refill = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (k == "stats") s->opt.stats = value;
     else if (k == "pool") s->opt.pool = value;
+    else if (k == "tail") s->opt.tail = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
     return RC_OK;
@@ -767,6 +768,7 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "n_cus") *value = s->n_cus;
     else if (k == "lds_stack") *value = s->opt.lds_stack;
     else if (k == "refill") *value = s->opt.refill;
+    else if (k == "tail") *value = s->opt.tail;
     else if (k.rfind("stat", 0) == 0 && k.size() == 5 && k[4] >= '0' && k[4] <= '7') {
         unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipSetDevice(s->device);

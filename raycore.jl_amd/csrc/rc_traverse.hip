@@ -136,7 +136,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     if (INST_LDS)
         for (uint32_t i = threadIdx.x; i < a.v.n_inst * 4u; i += BLOCK) il[i] = reinterpret_cast<const float4*>(a.v.inst)[i];
     __syncthreads();
-    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats};
+    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div};
     phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, INST_LDS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, tl, il);
 }
 constexpr int kMidBlock = 768, kMidStack = 16;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
 template <bool ANY, int LDS_N, int MINW, bool STATS>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
     __shared__ uint32_t lds_stack[LDS_N * kBlock];
-    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats};
+    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div};
     phased_trace<ANY, LDS_N, STATS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits});
 }
 
@@ -407,12 +407,11 @@ rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_th
     rc::PersistArgs p;
     p.n_items = n_items;
     p.work_counter = reinterpret_cast<unsigned long long*>(rc_counter_slot(s));
-    uint64_t per = n_items / ((uint64_t)(total_threads / 64) * 4);
-    per = (per / 64) * 64;
-    p.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : (per < 64 ? 64 : (per > 128 ? 128 : per)));
+    p.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
     p.refill = (int)s->opt.refill;
     p.int_thr = (int)s->opt.sched_thr;
     p.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
+    p.tail_div = (uint32_t)((total_threads / 64) * (uint64_t)s->opt.tail);
     return p;
 }
 
@@ -495,12 +494,11 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.work_counter = reinterpret_cast<unsigned long long*>(rc_counter_slot(s));
     a.refill = (int)s->opt.refill;
     {
-        uint64_t per = n / ((uint64_t)(total_threads / 64) * 4);
-        per = (per / 64) * 64;
-        a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : (per < 64 ? 64 : (per > 128 ? 128 : per)));
+        a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
     }
     a.sched_thr = (int)s->opt.sched_thr;
     a.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
+    a.tail_div = (uint32_t)((total_threads / 64) * (uint64_t)s->opt.tail);
     RC_HIP(hipEventRecord(s->ev0, stream));
     if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
     s->opt.kernel = saved_kernel;

@@ -37,6 +37,7 @@ struct TraceArgs {
     uint32_t pool;                     // persistent kernels: ray indices claimed per atomic
     int sched_thr;                     // scheduled kernel: run a leaf/entry batch once this many lanes wait for it
     unsigned long long* stats;         // optional instrumentation (dev builds), else nullptr
+    uint32_t tail_div = 0;             // phased kernels: see PersistArgs
 };
 
 // Address-space-qualified pointers keep the two halves of the stack on their own instruction paths
@@ -314,6 +315,7 @@ struct PersistArgs {
     int refill;                        // refill when this many lanes are free
     int int_thr;                       // leave the interior loop when fewer lanes than this have an interior node pending
     unsigned long long* stats;
+    uint32_t tail_div = 0;             // guided self-scheduling: a claim takes min(pool, remaining / tail_div) items (0 = always `pool`)
 };
 
 // TLAS_LDS: the block has staged the whole top level in LDS before the call (see k_trace_phased_lds): `tl` holds the packed
@@ -338,7 +340,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     // the node array addressed by 1-based node index: the base sits one record before element 0 (never dereferenced: index 0 is not a node)
     const __amdgpu_buffer_rsrc_t nrs1 = make_rsrc(reinterpret_cast<const char*>(av.blas_nodes) - 64, (av.n_nodes_total + 1u) * 64u);
     const __amdgpu_buffer_rsrc_t irs = make_rsrc(av.inst, av.n_inst * 64u);
-    unsigned long long pool_next = 0, pool_end = 0;
+    unsigned long long pool_next = 0, pool_end = 0, seen = 0;
     bool exhausted = false;
     uint64_t my_ray = 0;
     float3_ wo = mk3(0, 0, 0), wd = mk3(0, 0, 0), winv = mk3(0, 0, 0);
@@ -486,14 +488,24 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                     if (nf == 0) break;
                     if (pool_next == pool_end) {
                         if (exhausted) break;
+                        // Large claims keep a wave on neighbouring rays (coherent fetches); towards the end of the batch they would leave
+                        // some waves with a full slice while others have nothing, so the claim shrinks with what is left (guided
+                        // self-scheduling on the counter value this wave saw last).
+                        unsigned long long chunk = a.pool;
+                        if (a.tail_div) {
+                            unsigned long long c = ((a.n_items > seen ? a.n_items - seen : 0ull) / a.tail_div) & ~15ull;
+                            if (c < 16) c = 16;
+                            if (c < chunk) chunk = c;
+                        }
                         unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)a.pool);
+                        if (lane == 0) base = atomicAdd(a.work_counter, chunk);
                         unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
                         unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
                         base = ((unsigned long long)hi << 32) | lo;
                         if (base >= a.n_items) { exhausted = true; break; }
                         pool_next = base;
-                        pool_end = base + a.pool;
+                        pool_end = base + chunk;
+                        seen = pool_end;
                         if (pool_end >= a.n_items) { pool_end = a.n_items; exhausted = true; }
                     }
                     const unsigned long long left = pool_end - pool_next;
