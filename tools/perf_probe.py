@@ -57,16 +57,25 @@ def main():
     ms, hits3 = time_trace(t3, rays3, "closest", 1)
     shadow = sc.c3_shadow_rays(cfg3, rays3, hits3)
     bounce = sc.c4_bounce_rays(cfg3, rays3, hits3, 4 * len(rays3))
+    wl_extra = {}
+    for key, nt in (("r1m", 1_000_000), ("r4m", 4_000_000)):
+        if key in args.workloads.split(","):
+            tb = rc.TLAS(0)
+            tb.add_geometry(sc.random_triangles(nt, 42, edge=0.01))
+            tb.push_instances(1)
+            tb.sync()
+            wl_extra[key] = (f"random {nt//1000}k tris", tb, rc.generate_ray_grid(tb, (0.3, 0.2, 1.0), 1000), "closest")
     wl = {"c2": ("C2 closest", t2, rays2, "closest"), "c3": ("C3 primary", t3, rays3, "closest"),
           "shadow": ("C3 shadow-any", t3, shadow, "any"), "c4": ("C4 bounce", t3, bounce, "closest")}
-    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 32, "pool": 0, "tail": 1}
+    wl.update(wl_extra)
+    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 32, "pool": 0, "tail": 1, "xcd_split": -1}
     for var in args.variants.split(";"):
         opts = dict(defaults)
         for kv in var.split(","):
             if kv:
                 k, v = kv.split("=")
                 opts[k] = int(v)
-        for t in (t2, t3):
+        for t in [t2, t3] + [w[1] for w in wl_extra.values()]:
             for k, v in opts.items():
                 t.set_option(k, v)
         for w in args.workloads.split(","):
