@@ -296,6 +296,16 @@ int rc_compact_hits_device(rc_scene* scene, const rc_hit* d_hits, uint64_t n, ui
 int rc_scene_save(rc_scene* scene, const char* path);
 int rc_scene_load(int device, const char* path, rc_scene** out);
 
+/* instance_buffer(tlas, handle) (a stub for GPU back ends in the reference, src/Raycore.jl:117-128) + refit_tlas!
+ * (src/instanced-bvh.jl:2197-2222): *d_descs receives the device address of the handle's InstanceDescriptor records (108 bytes
+ * each, rc_instance_desc layout) inside the synced scene.  The caller's own kernels may rewrite `transform` (and
+ * `inv_transform`) there; rc_refit_device then commits: recompute_inverse != 0 => inv_transform = mat3x4_inverse(transform) is
+ * recomputed on the device for every instance first; then instance boxes, TLAS refit and traversal records are refreshed
+ * in place -- no host round trip.  The host mirror is refreshed lazily (rc_get_instances / rc_export_instances / the next
+ * mutation).  The address is valid until the next rebuilding rc_sync. */
+int rc_instance_buffer_device(rc_scene* scene, uint32_t handle, rc_instance_desc** d_descs, uint32_t* count);
+int rc_refit_device(rc_scene* scene, int recompute_inverse);
+
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);

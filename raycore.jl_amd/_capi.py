@@ -92,6 +92,8 @@ SYMBOLS = [
     ("rc_compact_hits_device", _int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     ("rc_scene_save", _int, [_vp, C.c_char_p]),
     ("rc_scene_load", _int, [_int, C.c_char_p, C.POINTER(_vp)]),
+    ("rc_instance_buffer_device", _int, [_vp, _u32, C.POINTER(_vp), _pu32]),
+    ("rc_refit_device", _int, [_vp, _int]),
     ("rc_last_kernel_ms", _int, [_vp, _pf]),
 ]
 

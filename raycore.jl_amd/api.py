@@ -272,6 +272,19 @@ class TLAS:
         check(lib().rc_update_geometry(self._h, handle.id, ptr(verts), ptr(m), len(verts)))
         self._prims_cache = None
 
+    def instance_buffer(self, handle):
+        """instance_buffer(tlas, handle) (src/Raycore.jl:117-128): (device address, count) of the handle's 108-byte InstanceDescriptor
+        records in the synced scene; rewrite them with your own kernels, then call refit_device()."""
+        self.sync()
+        p, n = C.c_void_p(), C.c_uint32()
+        check(lib().rc_instance_buffer_device(self._h, handle.id, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def refit_device(self, recompute_inverse=True):
+        """refit_tlas!(tlas) on descriptors rewritten in device memory: no host round trip."""
+        check(lib().rc_refit_device(self._h, 1 if recompute_inverse else 0))
+        return self
+
     def sync(self):  # sync!, :894-921
         a = C.c_int()
         check(lib().rc_sync(self._h, C.byref(a)))

@@ -478,17 +478,16 @@ void host_root_aabb(const RcNode& root, bool tlas, float mn[3], float mx[3]) {
 
 // mat3x4_inverse (src/instanced-bvh.jl:1675-1687) with StaticArrays' 3x3 inverse (columns x0,x1,x2;
 // y0 = x1 x x2; d = x0.y0; x0/=d; y0/=d; y1 = x2 x x0; y2 = x0 x x1).  Host code, -ffp-contract=off.
-void rc_mat3x4_inverse(const float m[12], float out[12]) {
-    float3_ x0 = mk3(m[0], m[1], m[2]), x1 = mk3(m[4], m[5], m[6]), x2 = mk3(m[8], m[9], m[10]);
-    float3_ y0 = cross3(x1, x2);
-    float d = dot3(x0, y0);
-    x0 = mk3(x0.x / d, x0.y / d, x0.z / d);
-    y0 = mk3(y0.x / d, y0.y / d, y0.z / d);
-    float3_ y1 = cross3(x2, x0), y2 = cross3(x0, x1);
-    float tx = m[3], ty = m[7], tz = m[11];
-    out[0] = y0.x; out[1] = y1.x; out[2] = y2.x; out[3] = -(y0.x * tx + y1.x * ty + y2.x * tz);
-    out[4] = y0.y; out[5] = y1.y; out[6] = y2.y; out[7] = -(y0.y * tx + y1.y * ty + y2.y * tz);
-    out[8] = y0.z; out[9] = y1.z; out[10] = y2.z; out[11] = -(y0.z * tx + y1.z * ty + y2.z * tz);
+void rc_mat3x4_inverse(const float m[12], float out[12]) { rc_mat3x4_inverse_hd(m, out); }
+
+// inv_transform = mat3x4_inverse(transform) for descriptors rewritten on the device (instance_buffer + refit, src/Raycore.jl:117-128)
+__global__ void k_update_inverses(RcInstanceDesc* inst, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float m[12], o[12];
+    for (int k = 0; k < 12; ++k) m[k] = inst[i].transform[k];
+    rc_mat3x4_inverse_hd(m, o);
+    for (int k = 0; k < 12; ++k) inst[i].inv_transform[k] = o[k];
 }
 
 // Triangle ingestion on the device (build_and_append_blas! minus mesh decomposition, :581-601): raw n x 9 f32 soup
@@ -633,11 +632,18 @@ void rc_build_tlas(rc_scene* s) {
 }
 
 // refit_tlas! (src/instanced-bvh.jl:2197-2222): new transforms -> leaf AABBs -> bottom-up refit, in place
-void rc_refit_tlas(rc_scene* s) {
+// from_device: the descriptors in s->d_instances were rewritten on the device (rc_instance_buffer_device); keep them, optionally
+// recompute their inverses there, and mark the host mirror stale instead of uploading it.
+void rc_refit_tlas(rc_scene* s, bool from_device, bool recompute_inverse) {
     const uint32_t n = (uint32_t)s->instances.size();
     if (n == 0) return;
     reserve_build_scratch(s, n);
-    RC_HIP(hipMemcpyAsync(s->d_instances.p, s->instances.data(), sizeof(RcInstanceDesc) * n, hipMemcpyHostToDevice, s->stream));
+    if (from_device) {
+        if (recompute_inverse) hipLaunchKernelGGL(k_update_inverses, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, n);
+        s->host_instances_stale = true;
+    } else {
+        RC_HIP(hipMemcpyAsync(s->d_instances.p, s->instances.data(), sizeof(RcInstanceDesc) * n, hipMemcpyHostToDevice, s->stream));
+    }
     hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p);
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, (const uint32_t*)nullptr, s->d_instances.p, s->d_descs.p, n);
     run_refit(s, s->tlas_nodes.p, nullptr, n, 1);

@@ -75,6 +75,17 @@ void compact_instances(rc_scene* s) {
     s->instances.swap(fresh);
 }
 
+// The host mirror of tlas.instances is authoritative except after a device-side rewrite (rc_refit_device): pull it back
+// before anything reads or edits it.
+void sync_host_instances(rc_scene* s) {
+    if (!s->host_instances_stale) return;
+    RC_HIP(hipSetDevice(s->device));
+    RC_HIP(hipStreamSynchronize(s->stream));
+    if (!s->instances.empty())
+        RC_HIP(hipMemcpy(s->instances.data(), s->d_instances.p, sizeof(RcInstanceDesc) * s->instances.size(), hipMemcpyDeviceToHost));
+    s->host_instances_stale = false;
+}
+
 void require_synced(rc_scene* s) {
     if (!s->has_static || s->dirty || s->transforms_dirty)
         throw RcError(RC_ERR_NOT_SYNCED, "scene has pending mutations: call rc_sync before tracing (Adapt.adapt does this per dispatch)");
@@ -260,6 +271,7 @@ int rc_update_geometry_mesh(rc_scene* s, uint32_t handle, const float* verts, co
                             uint32_t nf, const uint32_t* face_meta) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
     return guarded([&] {
+        sync_host_instances(s);
         use_device(s);
         HandleRange& r = live_range(s, handle);
         if (r.count == 0) throw RcError(RC_ERR_INVALID_HANDLE, "Handle has no instances");
@@ -301,6 +313,7 @@ int rc_add_instances_with_inverse(rc_scene* s, uint32_t blas_id, const float* xf
                                   const uint32_t* instance_ids, uint32_t m, uint32_t* handle) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
     return guarded([&] {
+        sync_host_instances(s);
         if (blas_id >= s->blas.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "blas_id out of range");
         HandleRange r{(uint32_t)s->instances.size(), m};
         for (uint32_t i = 0; i < m; ++i) {  // :670-674
@@ -327,6 +340,7 @@ int rc_add_instances(rc_scene* s, uint32_t blas_id, const float* xforms, const u
 int rc_update_transforms(rc_scene* s, uint32_t handle, const float* xforms, uint32_t m) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
     return guarded([&] {
+        sync_host_instances(s);
         HandleRange& r = live_range(s, handle);
         if (m != r.count) throw RcError(RC_ERR_INVALID_ARGUMENT, "Transform count (" + std::to_string(m) + ") != instance count (" + std::to_string(r.count) + ")");
         if (!xforms) throw RcError(RC_ERR_INVALID_ARGUMENT, "xforms is NULL");
@@ -342,6 +356,7 @@ int rc_update_transforms(rc_scene* s, uint32_t handle, const float* xforms, uint
 int rc_update_geometry(rc_scene* s, uint32_t handle, const float* verts, const uint32_t* meta, uint32_t n) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
     return guarded([&] {
+        sync_host_instances(s);
         use_device(s);
         HandleRange& r = live_range(s, handle);
         if (r.count == 0) throw RcError(RC_ERR_INVALID_HANDLE, "Handle has no instances");
@@ -382,6 +397,7 @@ int rc_handle_instance_count(rc_scene* s, uint32_t handle, uint32_t* count) {
 int rc_get_instances(rc_scene* s, uint32_t handle, rc_instance_desc* out, uint32_t capacity, uint32_t* count) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
     return guarded([&] {
+        sync_host_instances(s);
         HandleRange& r = live_range(s, handle);
         if (count) *count = r.count;
         if (!out) return;
@@ -396,6 +412,7 @@ int rc_sync(rc_scene* s, int* action) {
     if (!s->dirty && !s->transforms_dirty && s->has_static) return RC_OK;  // :898-900, no device sync
     return guarded([&] {
         use_device(s);
+        sync_host_instances(s);
         if (s->dirty || !s->has_static) {  // rebuild_bvh! + rebuild_static_tlas! (:902-905, :911-915)
             if (!s->deleted_handles.empty()) compact_instances(s);
             rc_build_tlas(s);
@@ -458,6 +475,7 @@ int rc_export_blas_nodes(rc_scene* s, rc_bvh_node* out, uint32_t capacity, uint3
 int rc_export_instances(rc_scene* s, rc_instance_desc* out, uint32_t capacity, uint32_t* count) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
     return guarded([&] {
+        sync_host_instances(s);
         require_synced(s);
         if (count) *count = (uint32_t)s->instances.size();
         if (!out) return;
@@ -661,6 +679,7 @@ int rc_compact_hits_device(rc_scene* s, const rc_hit* d_hits, uint64_t n, uint32
 int rc_scene_save(rc_scene* s, const char* path) {
     if (!s || !path) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {
+        sync_host_instances(s);
         use_device(s);
         require_synced(s);  // compaction has run: no deleted handles, no unreferenced geometry
         RC_HIP(hipStreamSynchronize(s->stream));
@@ -744,6 +763,30 @@ int rc_scene_load(int device, const char* path, rc_scene** out) {
     if (rc != RC_OK) { rc_scene_destroy(s); return rc; }
     *out = s;
     return RC_OK;
+}
+
+// instance_buffer(tlas, handle) + refit_tlas!(tlas) (src/Raycore.jl:117-128, src/instanced-bvh.jl:2197-2222): the handle's
+// descriptors as they sit in device memory, to be rewritten by the caller's own kernels and committed without a host round trip.
+int rc_instance_buffer_device(rc_scene* s, uint32_t handle, rc_instance_desc** d_descs, uint32_t* count) {
+    if (!s || !d_descs) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        const HandleRange r = live_range(s, handle);
+        *d_descs = reinterpret_cast<rc_instance_desc*>(s->d_instances.p + r.first);
+        if (count) *count = r.count;
+    });
+}
+
+int rc_refit_device(rc_scene* s, int recompute_inverse) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        RC_HIP(hipEventRecord(s->ev0, s->stream));
+        rc_refit_tlas(s, true, recompute_inverse != 0);
+        RC_HIP(hipEventRecord(s->ev1, s->stream));
+    });
 }
 
 int rc_set_option(rc_scene* s, const char* name, int64_t value) {

@@ -127,6 +127,21 @@ __host__ __device__ inline float3_ xf_dir(const float* m, float3_ v) {
                m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
 
+// mat3x4_inverse (src/instanced-bvh.jl:1675-1687): StaticArrays' 3x3 inverse (cross-product form) of the Julia-indexed upper block,
+// then the translation.  Host and device: the same expression order either way.
+__host__ __device__ inline void rc_mat3x4_inverse_hd(const float m[12], float out[12]) {
+    float3_ x0 = mk3(m[0], m[1], m[2]), x1 = mk3(m[4], m[5], m[6]), x2 = mk3(m[8], m[9], m[10]);
+    float3_ y0 = cross3(x1, x2);
+    float d = dot3(x0, y0);
+    x0 = mk3(x0.x / d, x0.y / d, x0.z / d);
+    y0 = mk3(y0.x / d, y0.y / d, y0.z / d);
+    float3_ y1 = cross3(x2, x0), y2 = cross3(x0, x1);
+    float tx = m[3], ty = m[7], tz = m[11];
+    out[0] = y0.x; out[1] = y1.x; out[2] = y2.x; out[3] = -(y0.x * tx + y1.x * ty + y2.x * tz);
+    out[4] = y0.y; out[5] = y1.y; out[6] = y2.y; out[7] = -(y0.y * tx + y1.y * ty + y2.y * tz);
+    out[8] = y0.z; out[9] = y1.z; out[10] = y2.z; out[11] = -(y0.z * tx + y1.z * ty + y2.z * tz);
+}
+
 // safe_invdir (src/instanced-bvh.jl:1742-1748)
 __host__ __device__ inline float safe_inv1(float d) {
     const float ooeps = 1.0e-5f;

@@ -95,6 +95,7 @@ struct rc_scene {
     std::set<uint32_t> deleted_handles;
     uint32_t next_handle_id = 1;
     bool dirty = true, transforms_dirty = false, has_static = false;
+    bool host_instances_stale = false;  // descriptors were rewritten on the device (rc_instance_buffer_device + rc_refit_device)
 
     // StaticTLAS (src/instanced-bvh.jl:155-168): the adapted form owned by rc_sync
     DevBuf<RcNode> tlas_nodes;
@@ -148,7 +149,7 @@ void rc_ensure_flat_attrs(rc_scene* s);  // fills s->flat_attrs for the current 
 void rc_launch_export_triangles(rc_scene* s, void* d_out, hipStream_t stream);  // 136-byte Triangle{UInt32} records
 void rc_launch_shading_attributes(rc_scene* s, const RcHit* d_hits, uint64_t n, float* d_normals, float* d_uvs, hipStream_t stream);
 void rc_build_tlas(rc_scene* s);   // build_tlas_topology + flat arrays -> StaticTLAS
-void rc_refit_tlas(rc_scene* s);   // refit_tlas!
+void rc_refit_tlas(rc_scene* s, bool from_device = false, bool recompute_inverse = false);   // refit_tlas!
 void rc_mat3x4_inverse(const float m[12], float out[12]);
 
 // rc_traverse.hip

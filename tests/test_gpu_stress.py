@@ -190,3 +190,47 @@ def test_c_client_example_runs(rc, tmp_path):
     assert out[1].startswith("ray 1: hit=1 t=2 ") and "instance=1 custom=22" in out[1]
     assert out[2].startswith("ray 2: hit=0")
     assert out[3].startswith("ray 3: hit=1 t=3 ") and "instance=0" in out[3]
+
+
+def test_instance_buffer_device_refit(rc):
+    """instance_buffer + refit_tlas! without a host round trip (src/Raycore.jl:117-128): descriptors rewritten in device memory
+    through a torch view of the library's buffer give the same arrays and hits as update_transforms! + sync! from the host."""
+    import torch
+    sc = rc.scenes
+    verts = sc.fan_sphere(10, 6, radius=0.5)
+    xf0, _, _ = sc.lattice_transforms(4, 4, 2, 1.6, 3)
+    xf1, _, _ = sc.lattice_transforms(4, 4, 2, 1.9, 4)
+    n = len(xf0)
+    a, b = rc.TLAS(), rc.TLAS()
+    ha = a.push(verts, xf0.reshape(n, 12), instance_ids=np.arange(n, dtype=np.uint32))
+    hb = b.push(verts, xf0.reshape(n, 12), instance_ids=np.arange(n, dtype=np.uint32))
+    a.sync(); b.sync()
+    # host path
+    a.update_transforms(ha, xf1.reshape(n, 12))
+    a.sync()
+    assert a.last_sync_action == "refit"
+    # device path: alias the 108-byte records as 27 floats each and overwrite the transform words [2, 14)
+    ptr, cnt = b.instance_buffer(hb)
+    assert cnt == n
+
+    class Alias:
+        __cuda_array_interface__ = {"shape": (n, 27), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+    recs = torch.as_tensor(Alias(), device="cuda")
+    recs[:, 2:14] = torch.from_numpy(xf1.reshape(n, 12)).cuda()
+    torch.cuda.synchronize()
+    b.refit_device(recompute_inverse=True)
+    sa, sb = a.adapt(), b.adapt()
+    assert sa.nodes.tobytes() == sb.nodes.tobytes()
+    assert sa.instances.tobytes() == sb.instances.tobytes()      # host mirror pulled back lazily, inverses recomputed on the device
+    assert np.array_equal(a.world_bound().p_min, b.world_bound().p_min) and np.array_equal(a.world_bound().p_max, b.world_bound().p_max)
+    g = np.random.default_rng(5)
+    rays = sc.make_rays(g.uniform(-2, 8, (30000, 3)), sc.normalize(g.normal(size=(30000, 3))))
+    ha_, hb_ = a.trace(rays), b.trace(rays)
+    assert ha_.tobytes() == hb_.tobytes() and ha_["hit"].sum() > 100
+    got = b.get_instances(hb)
+    assert np.array_equal(got["transform"], xf1.reshape(n, 12))
+    # a later host-side mutation starts from the refreshed mirror
+    b.update_transform(b.push(verts[:4]), np.eye(4, dtype=np.float32))
+    b.sync()
+    assert np.array_equal(b.get_instances(hb)["transform"], xf1.reshape(n, 12))
