@@ -430,7 +430,7 @@ void rc_launch_trace4(rc_scene* s, const Blas& b, const RcRay* d_rays, RcHit* d_
     a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
     a.refill = (int)s->opt.refill;
     a.int_thr = (int)s->opt.sched_thr;
-    a.overflow = s->overflow_stack.p; a.total_threads = total_threads;
+    a.overflow = s->cur_overflow; a.total_threads = total_threads;
     a.status = rc_counter_slot(s) + 4;
     RC_HIP(hipEventRecord(s->ev0, stream));
     if (any_hit) hipLaunchKernelGGL((k_trace4<true, 24>), dim3(blocks), dim3(kBlock), 0, stream, a);

@@ -118,7 +118,11 @@ struct rc_scene {
     DevBuf<unsigned char> sort_tmp;
     DevBuf<float> aabb_tmp;
     DevBuf<RcPrim> prim_tmp;
-    DevBuf<uint32_t> overflow_stack;  // global spill area of the traversal stacks
+    // global spill areas of the traversal stacks: one per stream that has launched on this scene (launches on one stream are
+    // ordered and share theirs; launches on different streams may overlap and must not), at most kMaxOverflowRegions
+    static constexpr int kMaxOverflowRegions = 4;
+    std::vector<std::pair<hipStream_t, DevBuf<uint32_t>>> overflow_regions;
+    uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared (rc_prepare_launch)
     DevBuf<uint32_t> counters;        // 64 slots x 64 words: per-launch work counter [0..1], status [4], stats [8..]
     uint64_t launch_seq = 0;
     DevBuf<RcRay> ray_stage;

@@ -386,7 +386,23 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
 // Scratch shared by every traversal launch: the lane-stack spill area (sized for the largest persistent
 // grid: n_cus x 8 blocks) and the counter / status words, zeroed on the launch stream.
 void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
-    s->overflow_stack.reserve((size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock);
+    {
+        size_t idx = 0;
+        for (; idx < s->overflow_regions.size(); ++idx)
+            if (s->overflow_regions[idx].first == stream) break;
+        if (idx == s->overflow_regions.size()) {
+            if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // a fifth stream: wait for the oldest region's stream, then take it over
+                RC_HIP(hipStreamSynchronize(s->overflow_regions[0].first));
+                std::rotate(s->overflow_regions.begin(), s->overflow_regions.begin() + 1, s->overflow_regions.end());
+                idx -= 1;
+                s->overflow_regions[idx].first = stream;
+            } else {
+                s->overflow_regions.emplace_back(stream, DevBuf<uint32_t>());
+            }
+        }
+        s->overflow_regions[idx].second.reserve((size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock);
+        s->cur_overflow = s->overflow_regions[idx].second.p;
+    }
     // one 256-byte slot of counter / status words per launch, rotated over 64 slots, so launches of one scene that
     // are in flight on different streams never share a work counter
     s->counters.reserve(64 * 64);
@@ -398,7 +414,7 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     rc::SceneView v;
     v.tlas_nodes = s->tlas_nodes.p; v.blas_nodes = s->flat_nodes.p; v.inst = s->inst_recs.p; v.prims = s->flat_prims.p;
     v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims; v.tlas_off = s->n_flat_nodes; v.n_nodes_total = s->n_flat_nodes + s->n_tlas_nodes; v.n_inst = s->n_static_instances;
-    v.overflow = s->overflow_stack.p; v.total_threads = total_threads;
+    v.overflow = s->cur_overflow; v.total_threads = total_threads;
     v.status = rc_counter_slot(s) + 4;
     return v;
 }

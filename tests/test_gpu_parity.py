@@ -364,7 +364,7 @@ def test_deep_trees_use_the_stack_spill_path(rc, oracle):
     max_sp = t.get_option("stat2")
     t.set_option("stats", 0)
     assert max_sp > 24, f"scene too shallow to reach the spill path (max stack {max_sp})"
-    for k in (0, 2, 3, 4):
+    for k in (0, 2, 3, 4, 5):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(rays), want, f"deep k{k}")
         assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any", nthreads=8), f"deep any k{k}")

@@ -234,3 +234,44 @@ def test_instance_buffer_device_refit(rc):
     b.update_transform(b.push(verts[:4]), np.eye(4, dtype=np.float32))
     b.sync()
     assert np.array_equal(b.get_instances(hb)["transform"], xf1.reshape(n, 12))
+
+
+def test_overlapping_launches_on_two_streams(rc):
+    """Launches of one scene on different streams may overlap; each stream has its own stack spill region and every launch its own
+    counter slot, so results equal the serial ones even when the stacks run through the spill path (deep chain scene)."""
+    import torch
+    def chain(levels, fat=0.3):
+        tris = []
+        for j in range(1, levels + 1):
+            for axis in range(3):
+                size = 2.0 ** (-j + 1)
+                p = np.full(3, fat * size); p[axis] = size
+                q = p.copy(); q[(axis + 1) % 3] += 0.5 * size * fat
+                r = np.full(3, -1e-4 * (1 + 0.5 * j))
+                tris.append(np.concatenate([r, p, q]))
+        return np.array(tris, dtype=np.float32)
+    sc = rc.scenes
+    xf = np.tile(sc.IDENTITY3x4, (4, 1)).astype(np.float32)
+    xf[1, [0, 5, 10]] = 0.5
+    xf[2, [0, 5, 10]] = 0.25
+    xf[3, [3, 7, 11]] = [0.01, 0.0, 0.0]
+    t = rc.TLAS()
+    t.push(chain(10), xf, instance_ids=np.arange(4, dtype=np.uint32))
+    t.sync()
+    g = sc.rng(21)
+    n = 1_500_000
+    sets = []
+    for k in range(2):
+        rays = sc.make_rays(g.uniform(-0.2, 0.0, size=(n, 3)), sc.normalize(g.uniform(0.05, 1.0, size=(n, 3))))
+        sets.append((rays, t.trace(rays)))  # serial reference results
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    d_rays = [torch.from_numpy(r.view(np.uint8).reshape(-1)).cuda() for r, _ in sets]
+    d_hits = [torch.zeros(n * 32, dtype=torch.uint8, device="cuda") for _ in sets]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for k in (0, 1):
+            t.trace_device(d_rays[k].data_ptr(), d_hits[k].data_ptr(), n, stream=streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        got = d_hits[k].cpu().numpy().view(rc.HIT_DT)
+        assert got.tobytes() == sets[k][1].tobytes(), f"stream {k}"
