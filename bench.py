@@ -129,6 +129,24 @@ def main():
                 scene.trace_device(dr.data_ptr(), dh.data_ptr(), len(rs), mode=mode, stream=stream.cuda_stream)
                 best = min(best, scene.last_kernel_ms())
             return round(len(rs) / best / 1e3, 1)
+        # Throughput with consecutive batches overlapped on two streams (fill / drain of one launch hidden behind the next; each
+        # stream has its own stack spill region, each launch its own counters).  Not the headline: per-launch attribution is lost.
+        def pipelined(kernel_opt):
+            t.set_option("kernel", kernel_opt)
+            st2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+            dh2 = [torch.empty(n * 32, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            for j in (0, 1):
+                t.trace_device(d_rays.data_ptr(), dh2[j].data_ptr(), n, stream=st2[j].cuda_stream)
+            torch.cuda.synchronize()
+            k = 40
+            p0 = time.perf_counter()
+            for i in range(k):
+                t.trace_device(d_rays.data_ptr(), dh2[i % 2].data_ptr(), n, stream=st2[i % 2].cuda_stream)
+            torch.cuda.synchronize()
+            rate = round(n * k / (time.perf_counter() - p0) / 1e6, 1)
+            t.set_option("kernel", -1)
+            return rate
+        extras["c3_two_stream_pipelined_mrays_s"] = {"kernel3": pipelined(3), "kernel5": pipelined(5)}
         shadow = sc.c3_shadow_rays(cfg, rays, hits)
         extras["c3_any_hit_shadow_mrays_s"] = timed(t, shadow, "any")
         bounce = sc.c4_bounce_rays(cfg, rays, hits, 4 * n)
