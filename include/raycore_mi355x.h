@@ -140,7 +140,8 @@ int rc_counts(rc_scene* scene, uint32_t* n_live_instances, uint32_t* n_total_ins
               uint32_t* n_prims, uint32_t* n_tlas_nodes, uint32_t* n_blas_nodes);
 /* world_bound(tlas) (src/instanced-bvh.jl:2147-2149): out = {min xyz, max xyz}. */
 int rc_world_bound(rc_scene* scene, float out[6]);
-/* wait_for_gpu! (src/instanced-bvh.jl:2418-2421) */
+/* wait_for_gpu! (src/instanced-bvh.jl:2418-2421).  Also the place where asynchronous launches (the *_device entry points) report a
+ * traversal-stack overflow (RC_ERR_STACK_OVERFLOW): the host-buffer entry points check after every call, the device ones cannot. */
 int rc_wait(rc_scene* scene);
 
 /* Reference-layout copies of the synced StaticTLAS arrays (src/instanced-bvh.jl:155-168).  Pass NULL

@@ -453,7 +453,22 @@ int rc_world_bound(rc_scene* s, float out[6]) {
 
 int rc_wait(rc_scene* s) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
-    return guarded([&] { use_device(s); RC_HIP(hipDeviceSynchronize()); });
+    return guarded([&] {
+        use_device(s);
+        RC_HIP(hipDeviceSynchronize());
+        // asynchronous launches (the *_device entry points) cannot report a traversal-stack overflow themselves: their status words
+        // (one per launch slot) are collected here
+        if (s->counters.p) {
+            std::vector<uint32_t> words(64 * 64);
+            RC_HIP(hipMemcpy(words.data(), s->counters.p, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            bool overflow = false;
+            for (int slot = 0; slot < 64; ++slot) overflow |= words[slot * 64 + 4] != 0;
+            if (overflow) {
+                RC_HIP(hipMemset(s->counters.p, 0, words.size() * sizeof(uint32_t)));
+                throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow in an earlier asynchronous launch (tree deeper than 128 levels)");
+            }
+        }
+    });
 }
 
 int rc_export_tlas_nodes(rc_scene* s, rc_bvh_node* out, uint32_t capacity, uint32_t* count) {
