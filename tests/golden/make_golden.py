@@ -24,7 +24,9 @@ def case_c1():
     o = build_oracle(po, cfg)
     rays = o.ray_grid(cfg["viewdir"], cfg["grid"])
     return {"rays": rays, "closest": o.trace(rays), "any": o.trace(rays, mode="any"), "tlas_nodes": o.tlas_nodes,
-            "blas_nodes": o.blas_nodes, "illumination": o.get_illumination(cfg["viewdir"], cfg["grid"])}
+            "blas_nodes": o.blas_nodes, "illumination": o.get_illumination(cfg["viewdir"], cfg["grid"]),
+            "blas4_nodes": o.blas4_nodes(1), "closest4": o.trace4(1, rays), "any4": o.trace4(1, rays, mode="any"),
+            "triangles": o.triangles}
 
 
 def case_instanced():
@@ -39,7 +41,8 @@ def case_instanced():
     rays["tmax"][::4] = 3.0
     n = len(o.blas_prims)
     return {"xforms": xf, "rays": rays, "closest": o.trace(rays), "any": o.trace(rays, mode="any"), "tlas_nodes": o.tlas_nodes,
-            "blas_nodes": o.blas_nodes, "instances": o.instances, "view_factors_16": o.view_factors(16, seed=5), "n_prims": np.array([n])}
+            "blas_nodes": o.blas_nodes, "instances": o.instances, "view_factors_16": o.view_factors(16, seed=5), "n_prims": np.array([n]),
+            "contacts": o.collide_instances()[0], "blas4_nodes_2": o.blas4_nodes(2)}
 
 
 if __name__ == "__main__":

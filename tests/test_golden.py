@@ -42,12 +42,16 @@ def test_oracle_reproduces_golden(rc, oracle):
     assert_hits_equal(o.trace(g["rays"]), g["closest"], "golden C1 closest")
     assert_hits_equal(o.trace(g["rays"], mode="any"), g["any"], "golden C1 any")
     assert np.array_equal(o.get_illumination(cfg["viewdir"], cfg["grid"]), g["illumination"])
+    assert o.blas4_nodes(1).tobytes() == g["blas4_nodes"].tobytes() and o.triangles.tobytes() == g["triangles"].tobytes()
+    assert_hits_equal(o.trace4(1, g["rays"]), g["closest4"], "golden C1 closest4")
+    assert_hits_equal(o.trace4(1, g["rays"], mode="any"), g["any4"], "golden C1 any4")
     g2 = np.load(os.path.join(HERE, "instanced_small.npz"))
     o2 = build_oracle(oracle, cfg_instanced(rc, g2))
     assert o2.instances.tobytes() == g2["instances"].tobytes() and o2.tlas_nodes.tobytes() == g2["tlas_nodes"].tobytes()
     assert_hits_equal(o2.trace(g2["rays"]), g2["closest"], "golden instanced closest")
     assert_hits_equal(o2.trace(g2["rays"], mode="any"), g2["any"], "golden instanced any")
     assert np.array_equal(o2.view_factors(16, seed=5), g2["view_factors_16"])
+    assert np.array_equal(o2.collide_instances()[0], g2["contacts"]) and o2.blas4_nodes(2).tobytes() == g2["blas4_nodes_2"].tobytes()
 
 
 @pytest.mark.gpu
@@ -66,3 +70,12 @@ def test_hip_path_matches_golden(rc):
     assert_hits_equal(t2.trace(g2["rays"]), g2["closest"], "golden instanced closest")
     assert_hits_equal(t2.trace(g2["rays"], mode="any"), g2["any"], "golden instanced any")
     assert np.array_equal(rc.view_factors(t2, rays_per_triangle=16, seed=5), g2["view_factors_16"])
+    # BVH4, full triangles, collision pairs
+    assert st.all_blas_triangles.tobytes() == g["triangles"].tobytes()
+    b4 = rc.build_blas4(*cfg["blas"][0])
+    assert b4.nodes.tobytes() == g["blas4_nodes"].tobytes()
+    assert_hits_equal(b4.trace(g["rays"]), g["closest4"], "golden C1 closest4")
+    assert_hits_equal(b4.trace(g["rays"], mode="any"), g["any4"], "golden C1 any4")
+    res = rc.collide_instances(t2)
+    assert np.array_equal(np.stack([res.contacts["instance_a"], res.contacts["instance_b"]], axis=1), g2["contacts"])
+    assert rc.build_blas4(*cfg_instanced(rc, g2)["blas"][1]).nodes.tobytes() == g2["blas4_nodes_2"].tobytes()
