@@ -326,7 +326,10 @@ def main():
                        "kernel": {-1: "auto (phased persistent, TLAS in LDS)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased", 4: "phased + TLAS/instances in LDS", 5: "phased + TLAS in LDS"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": {-1: "k_trace_phased_lds<false, 768, 16, false, 6>", 5: "k_trace_phased_lds<false, 768, 16, false, 6>", 3: "k_trace_phased<false, 24, 6, false>"}.get(t.get_option("kernel"), f"kernel option {t.get_option('kernel')}"), "avg_launch_ms": round(launch_ms, 4),
-                         "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3)},
+                         "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3),
+                         # the scene is L1/L2 resident (see traffic), so the physical ceiling is the 64-byte gather rate of the vector-memory / LDS
+                         # paths, not HBM: 64 B per node or instance-record visit against the 11.7 TB/s measured by tools/td_probe.hip
+                         "cache_gather": {"achieved_GBs": round((node_f + inst_f) * 64.0 * n / (launch_ms * 1e-3) / 1e9, 1), "measured_ceiling_GBs": 11700.0}},
             "cpu_baseline": cpu_baseline,
             "extras": extras,
         }
