@@ -92,6 +92,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Untimed: bring the GPU clocks up before the W warm-up steps (a cold MI355X runs its first few dozen milliseconds of kernels
+    # ~10 % slower; with small W and K that would be what gets timed).
+    for _ in range(40):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -339,6 +344,12 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
+        # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit, AFTER the JSON line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
 
