@@ -192,3 +192,28 @@ def test_drain_to_empty_and_rebuild(rc):  # :808-836
         live, geoms, prims, blas_nodes, tlas_nodes = counts(t)
         assert (live, geoms, prims, blas_nodes, tlas_nodes) == (0, 0, 0, 0, 0)
         assert not rc.closest_hit(t, rc.Ray((0, 0, 5), (0, 0, -1)))[0]
+
+
+def test_adapt_per_dispatch_sees_mutations_and_refit_path(rc):  # test/test_mesh_update.jl:118-223
+    def xl(z):
+        m = np.eye(4, dtype=np.float32)
+        m[2, 3] = z
+        return m
+    ray = rc.Ray((0, 0, 5), (0, 0, -1))
+    t = rc.TLAS()
+    h = t.push(sphere(rc, 16), xl(0))
+    st = t.adapt()                                   # first adapt builds the adapted form
+    hit, _, dist, _, _ = rc.closest_hit(st, ray)
+    assert hit and abs(dist - 4.0) < 0.05
+    t.delete(h)
+    h = t.push(sphere(rc, 48), xl(2.0))              # mutate: the canonical consumer re-adapts per dispatch and must see it
+    hit, _, dist, _, _ = rc.closest_hit(t.adapt(), ray)
+    assert hit and abs(dist - 2.0) < 0.1
+    assert t.sync().last_sync_action == "noop"       # clean sync: no-op (:898-900)
+    # refit path: update_transform! + sync! moves the instance in place
+    t.update_transform(h, xl(1.5))
+    assert t.sync().last_sync_action == "refit"
+    hit, _, dist, _, _ = rc.closest_hit(t, ray)
+    assert hit and abs(dist - 2.5) < 0.05
+    for _ in range(3):
+        assert t.sync().last_sync_action == "noop"
