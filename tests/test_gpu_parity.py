@@ -96,6 +96,31 @@ def test_kat_tlas_items_ctor(rc):  # test/test_intersection.jl:57-103
     assert accel.instances["instance_id"].tolist() == [1, 2, 3]
 
 
+def test_kat_dynamic_scenes(rc):  # test/test_instanced_bvh.jl:1044-1132, 1178-1194
+    t = rc.TLAS()
+    h = t.push(UNIT_TRI)
+    t.sync()
+    assert rc.closest_hit(t.adapt(), rc.Ray((0.25, 0.25, 1.0), (0, 0, -1)))[0]
+    t.update_transform(h, xlat(10, 0, 0))
+    t.sync()
+    st = t.adapt()
+    assert not rc.closest_hit(st, rc.Ray((0.25, 0.25, 1.0), (0, 0, -1)))[0]
+    hit, _, dist, _, _ = rc.closest_hit(st, rc.Ray((10.25, 0.25, 1.0), (0, 0, -1)))
+    assert hit and dist == pytest.approx(1.0)
+    # add an instance of a second mesh between dispatches
+    t2 = rc.TLAS()
+    t2.push(UNIT_TRI)
+    rays = [rc.Ray((0.25, 0.25, 1.0), (0, 0, -1)), rc.Ray((5.25, 0.25, 1.0), (0, 0, -1))]
+    assert [r[0] for r in rc.trace_rays(t2.adapt(), rays)] == [True, False]
+    t2.push(UNIT_TRI + np.array([5, 0, 0] * 3, np.float32))
+    assert [r[0] for r in rc.trace_rays(t2.adapt(), rays)] == [True, True]
+    # world bound of the adapted form = the TLAS root box
+    t3 = rc.TLAS()
+    t3.push(UNIT_TRI, [xlat(0, 0, 0), xlat(10, 10, 0)])
+    wb, root = t3.world_bound(), t3.adapt().root_aabb
+    assert np.allclose(wb.p_min, [0, 0, 0]) and np.allclose(wb.p_max, [11, 11, 0]) and np.array_equal(root.p_min, wb.p_min)
+
+
 def test_empty_tlas_traces_miss(rc):  # test/test_tlas_stress.jl:808-831
     t = rc.TLAS()
     for it in range(3):
