@@ -117,6 +117,7 @@ def test_kat_dynamic_scenes(rc):  # test/test_instanced_bvh.jl:1044-1132, 1178-1
     # world bound of the adapted form = the TLAS root box
     t3 = rc.TLAS()
     t3.push(UNIT_TRI, [xlat(0, 0, 0), xlat(10, 10, 0)])
+    t3.sync()  # root_aabb is the synced TLAS's (the reference test syncs before reading it)
     wb, root = t3.world_bound(), t3.adapt().root_aabb
     assert np.allclose(wb.p_min, [0, 0, 0]) and np.allclose(wb.p_max, [11, 11, 0]) and np.array_equal(root.p_min, wb.p_min)
 
