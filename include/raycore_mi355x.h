@@ -100,7 +100,9 @@ int rc_scene_destroy(rc_scene* scene);
 /* build_and_append_blas! minus the GeometryBasics mesh decomposition (src/instanced-bvh.jl:581-608):
  * verts = n x 9 f32 triangle soup, meta = n u32 or NULL (=> face index 1..n, assigned BEFORE the
  * degenerate filter, :595).  Degenerate faces (is_degenerate, src/triangle_mesh.jl:14-17) are dropped,
- * the LBVH is built on the device (build_blas, :1376-1443).  *blas_id receives the 0-based geometry id. */
+ * the LBVH is built on the device (build_blas, :1376-1443).  *blas_id receives the 0-based geometry id; like the reference's
+ * blas_index it is renumbered when an rc_sync after rc_delete drops unreferenced geometries (compact_instances!, :996-1065), so
+ * use it right away (rc_add_instances, rc_blas4_build) or re-derive it from rc_get_instances(...).blas_index - 1. */
 int rc_add_blas(rc_scene* scene, const float* verts, const uint32_t* meta, uint32_t n, uint32_t* blas_id);
 /* Same with the triangle soup already in device memory (the reference builds BLASes "directly on the backend",
  * src/instanced-bvh.jl:16-21): no host staging; filter, sort and tree construction all run on the GPU. */
