@@ -114,7 +114,7 @@ struct rc_scene {
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 
     // scratch
-    DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b, flags, scene_enc;
+    DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b, flags, scene_enc, bounds_partials;
     DevBuf<unsigned char> sort_tmp;
     DevBuf<float> aabb_tmp;
     DevBuf<RcPrim> prim_tmp;
