@@ -291,6 +291,10 @@ int rc_primary_rays_lookat_device(rc_scene* scene, const float camera_pos[3], co
                                   const float camera_forward[3], float half_width, float half_height, uint32_t width, uint32_t height,
                                   uint32_t samples, uint64_t seed, int jitter, rc_ray* d_rays, void* stream);
 int rc_compact_hits_device(rc_scene* scene, const rc_hit* d_hits, uint64_t n, uint32_t* d_indices, uint32_t* d_count, void* stream);
+/* generate_reflection_rays! for perfect mirrors (docs/src/wavefront-renderer.jl:431-476, roughness 0) on reflect (src/math.jl:80):
+ * per hit, origin = hit_point + shading_normal * bias, direction = reflect(-ray.d, shading_normal), t_max = Inf; misses get the
+ * reference's dummy ray (d = (0,0,1), t_max = 0).  Material tests (metallic / roughness) stay with the caller. */
+int rc_reflection_rays_device(rc_scene* scene, const rc_ray* d_rays, const rc_hit* d_hits, uint64_t n, float bias, rc_ray* d_out, void* stream);
 
 /* Scene files.  The reference has no on-disk format; this one keeps what a rebuild would recompute (per geometry: sorted
  * primitives, BVH2 nodes, mesh attributes; plus instance descriptors and the handle table).  rc_scene_save needs a synced

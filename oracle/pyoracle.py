@@ -101,6 +101,7 @@ def lib():
         L.rco_scene_triangles.argtypes = [vp, vp]
         L.rco_shading_attributes.argtypes = [vp, vp, u64, vp, vp]
         L.rco_primary_rays_lookat.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, u32, u32, u32, u64, C.c_int, vp]
+        L.rco_reflection_rays.argtypes = [vp, vp, vp, u64, C.c_float, vp]
         _lib = L
     return _lib
 
@@ -277,6 +278,11 @@ class Scene:
     def shadow_rays(self, rays, hits, light, bias=0.01):
         out = np.zeros(len(rays), dtype=RAY_DT)
         lib().rco_shadow_rays(self._h, _p(np.ascontiguousarray(rays)), _p(np.ascontiguousarray(hits)), len(rays), _p(_f32(light)), bias, _p(out))
+        return out
+
+    def reflection_rays(self, rays, hits, bias=0.01):
+        out = np.zeros(len(rays), dtype=RAY_DT)
+        lib().rco_reflection_rays(self._h, _p(np.ascontiguousarray(rays)), _p(np.ascontiguousarray(hits)), len(rays), bias, _p(out))
         return out
 
     def view_factor_ray(self, src_idx0, ray_idx, seed=0):

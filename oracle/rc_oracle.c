@@ -1307,3 +1307,23 @@ void rco_primary_rays_lookat(const float pos[3], const float right[3], const flo
             }
         }
 }
+
+void rco_reflection_rays(const rco_scene* s, const rco_ray* rays, const rco_hit* hits, uint64_t n, float bias, rco_ray* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        rco_ray rr = {0, 0, 0, 0, 0, 0, 1, 0}; /* dummy_ray :445 */
+        if (hits[i].hit) {
+            float nn[3];
+            rco_shading_attributes(s, &hits[i], 1, nn, NULL);
+            v3 nrm = v3_from(nn);
+            v3 o = V(rays[i].ox, rays[i].oy, rays[i].oz), d = V(rays[i].dx, rays[i].dy, rays[i].dz);
+            v3 hp = v3_add(o, v3_scale(d, hits[i].t));                       /* ray.o + ray.d * dist :453 */
+            v3 wo = V(-d.x, -d.y, -d.z);
+            float k = 2.0f * v3_dot(wo, nrm);                                /* reflect (src/math.jl:80) */
+            v3 rd = v3_add(V(-wo.x, -wo.y, -wo.z), v3_scale(nrm, k));
+            v3 ro = v3_add(hp, v3_scale(nrm, bias));                         /* :467 */
+            rr.ox = ro.x; rr.oy = ro.y; rr.oz = ro.z; rr.tmin = 0.0f;
+            rr.dx = rd.x; rr.dy = rd.y; rr.dz = rd.z; rr.tmax = INFINITY;
+        }
+        out[i] = rr;
+    }
+}

@@ -201,6 +201,11 @@ void rco_shading_attributes(const rco_scene*, const rco_hit* hits, uint64_t n, f
 void rco_primary_rays_lookat(const float pos[3], const float right[3], const float up[3], const float forward[3], float half_width,
                              float half_height, uint32_t width, uint32_t height, uint32_t samples, uint64_t seed, int jitter, rco_ray* out);
 
+/* generate_reflection_rays! for perfect mirrors (docs/src/wavefront-renderer.jl:431-476 with roughness 0) on reflect (src/math.jl:80):
+ * per hit, normal = the interpolated shading normal of rco_shading_attributes, origin = (o + d*t) + normal*bias, direction =
+ * reflect(-d, normal) = -wo + (2*(wo.n))*n, t_min 0, t_max Inf; misses get the dummy ray (o = 0, d = (0,0,1), t_max = 0). */
+void rco_reflection_rays(const rco_scene*, const rco_ray* rays, const rco_hit* hits, uint64_t n, float bias, rco_ray* out);
+
 #ifdef __cplusplus
 }
 #endif

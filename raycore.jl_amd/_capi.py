@@ -89,6 +89,7 @@ SYMBOLS = [
     ("rc_export_triangles", _int, [_vp, _vp, _u32, _pu32]),
     ("rc_shading_attributes_device", _int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     ("rc_primary_rays_lookat_device", _int, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _u32, _u32, _u32, _u64, _int, _vp, _vp]),
+    ("rc_reflection_rays_device", _int, [_vp, _vp, _vp, _u64, C.c_float, _vp, _vp]),
     ("rc_compact_hits_device", _int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     ("rc_scene_save", _int, [_vp, C.c_char_p]),
     ("rc_scene_load", _int, [_int, C.c_char_p, C.POINTER(_vp)]),

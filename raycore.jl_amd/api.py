@@ -234,6 +234,10 @@ class TLAS:
         check(lib().rc_primary_rays_lookat_device(self._h, ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), float(half_width), float(half_height),
                                                   int(width), int(height), int(samples), int(seed), 1 if jitter else 0, ptr(d_rays), ptr(stream)))
 
+    def reflection_rays_device(self, d_rays, d_hits, n, d_out, bias=0.01, stream=None):
+        """Mirror-reflection rays from hits (generate_reflection_rays! with roughness 0; reflect, src/math.jl:80)."""
+        check(lib().rc_reflection_rays_device(self._h, ptr(d_rays), ptr(d_hits), int(n), float(bias), ptr(d_out), ptr(stream)))
+
     def compact_hits_device(self, d_hits, n, d_indices, d_count, stream=None):
         """Ascending indices of the hit rays + their count (device u32): queue compaction between wavefront stages."""
         check(lib().rc_compact_hits_device(self._h, ptr(d_hits), int(n), ptr(d_indices), ptr(d_count), ptr(stream)))

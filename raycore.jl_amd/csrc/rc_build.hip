@@ -234,6 +234,32 @@ __global__ void k_shading_attributes(const RcHit* hits, uint64_t n, const float*
     if (uvs) { uvs[2 * i] = tu; uvs[2 * i + 1] = tv; }
 }
 
+// generate_reflection_rays! with roughness 0 (docs/src/wavefront-renderer.jl:431-476) on reflect (src/math.jl:80)
+__global__ void k_reflection_rays(const RcRay* rays, const RcHit* hits, uint64_t n, const float* attrs, float bias, RcRay* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RcHit h = hits[i];
+    RcRay rr{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    if (h.hit) {
+        const RcRay r = rays[i];
+        const float* a = attrs + 15 * (size_t)h.primitive_id;
+        const float b1 = (1.0f - h.bary_u) - h.bary_v, b2 = h.bary_u, b3 = h.bary_v;
+        const float sx = (a[0] * b1 + a[3] * b2) + a[6] * b3, sy = (a[1] * b1 + a[4] * b2) + a[7] * b3, sz = (a[2] * b1 + a[5] * b2) + a[8] * b3;
+        const float len = __builtin_sqrtf((sx * sx + sy * sy) + sz * sz);
+        const float3_ nrm = mk3(sx / len, sy / len, sz / len);
+        const float3_ o = mk3(r.ox, r.oy, r.oz), d = mk3(r.dx, r.dy, r.dz);
+        const float3_ hp = add3(o, scale3(d, h.t));
+        const float3_ wo = mk3(-d.x, -d.y, -d.z);
+        const float k = 2.0f * dot3(wo, nrm);
+        const float3_ rd = add3(mk3(-wo.x, -wo.y, -wo.z), scale3(nrm, k));
+        const float3_ ro = add3(hp, scale3(nrm, bias));
+        rr = RcRay{ro.x, ro.y, ro.z, 0.0f, rd.x, rd.y, rd.z, INFINITY};
+    }
+    float4* q = reinterpret_cast<float4*>(out + i);
+    q[0] = make_float4(rr.ox, rr.oy, rr.oz, rr.tmin);
+    q[1] = make_float4(rr.dx, rr.dy, rr.dz, rr.tmax);
+}
+
 // fill_bvhnode2_kernel! (src/instanced-bvh-kernels.jl:19-22) with the empty node of :1407-1410
 __global__ void k_fill_nodes(RcNode* nodes, uint32_t n_nodes) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -563,6 +589,13 @@ void rc_launch_shading_attributes(rc_scene* s, const RcHit* d_hits, uint64_t n, 
     if (n == 0) return;
     rc_ensure_flat_attrs(s);
     hipLaunchKernelGGL(k_shading_attributes, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_hits, n, s->flat_attrs.p, d_normals, d_uvs);
+    RC_HIP(hipGetLastError());
+}
+
+void rc_launch_reflection_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float bias, RcRay* d_out, hipStream_t stream) {
+    if (n == 0) return;
+    rc_ensure_flat_attrs(s);
+    hipLaunchKernelGGL(k_reflection_rays, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_rays, d_hits, n, s->flat_attrs.p, bias, d_out);
     RC_HIP(hipGetLastError());
 }
 

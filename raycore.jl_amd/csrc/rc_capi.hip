@@ -679,6 +679,16 @@ int rc_primary_rays_lookat_device(rc_scene* s, const float camera_pos[3], const 
     });
 }
 
+int rc_reflection_rays_device(rc_scene* s, const rc_ray* d_rays, const rc_hit* d_hits, uint64_t n, float bias, rc_ray* d_out, void* stream) {
+    if (!s || (n && (!d_rays || !d_hits || !d_out))) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        rc_launch_reflection_rays(s, reinterpret_cast<const RcRay*>(d_rays), reinterpret_cast<const RcHit*>(d_hits), n, bias,
+                                  reinterpret_cast<RcRay*>(d_out), (hipStream_t)stream);
+    });
+}
+
 int rc_compact_hits_device(rc_scene* s, const rc_hit* d_hits, uint64_t n, uint32_t* d_indices, uint32_t* d_count, void* stream) {
     if (!s || !d_count || (n && (!d_hits || !d_indices))) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {

@@ -151,6 +151,7 @@ void rc_build_blas(rc_scene* s, uint32_t n, Blas& out, bool keep_face_map = fals
 void rc_expand_mesh(rc_scene* s, const float* d_verts, const uint32_t* d_indices, const uint32_t* d_vertex_meta, uint32_t nf, float* d_soup, uint32_t* d_meta);
 void rc_ensure_flat_attrs(rc_scene* s);  // fills s->flat_attrs for the current flat primitive array
 void rc_launch_export_triangles(rc_scene* s, void* d_out, hipStream_t stream);  // 136-byte Triangle{UInt32} records
+void rc_launch_reflection_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float bias, RcRay* d_out, hipStream_t stream);
 void rc_launch_shading_attributes(rc_scene* s, const RcHit* d_hits, uint64_t n, float* d_normals, float* d_uvs, hipStream_t stream);
 void rc_build_tlas(rc_scene* s);   // build_tlas_topology + flat arrays -> StaticTLAS
 void rc_refit_tlas(rc_scene* s, bool from_device = false, bool recompute_inverse = false);   // refit_tlas!

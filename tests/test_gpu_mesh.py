@@ -75,6 +75,12 @@ def test_shading_attributes_device(rc, oracle):
     assert np.array_equal(d_n.cpu().numpy().view(np.uint32), wn.view(np.uint32))
     assert np.array_equal(d_uv.cpu().numpy().view(np.uint32), wuv.view(np.uint32))
     assert 0 < hits["hit"].sum() < n
+    # mirror reflection rays from the same hits (reflect, src/math.jl:80)
+    d_r = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+    d_o = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    t.reflection_rays_device(d_r.data_ptr(), d_h.data_ptr(), n, d_o.data_ptr(), bias=0.01)
+    torch.cuda.synchronize()
+    assert d_o.cpu().numpy().tobytes() == s.reflection_rays(rays, hits, 0.01).tobytes()
 
 
 def test_mesh_errors(rc):
