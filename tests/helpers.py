@@ -22,14 +22,16 @@ def build_oracle(po, cfg):
 
 
 def assert_hits_equal(got, want, what=""):
-    """Bit-exact comparison of RTHitResult arrays: ids exact, t/u/v identical bit patterns."""
+    """Bit-exact comparison of RTHitResult arrays: ids exact, t/u/v identical bit patterns (NaN payloads aside)."""
     assert len(got) == len(want)
     for f in ("hit", "primitive_id", "instance_id", "instance_custom_index"):
         bad = np.nonzero(got[f] != want[f])[0]
         assert len(bad) == 0, f"{what}: {len(bad)} rays differ in {f}, first {bad[:5]}: got {got[f][bad[:5]]} want {want[f][bad[:5]]}"
     for f in ("t", "bary_u", "bary_v"):
         a, b = got[f].view(np.uint32), want[f].view(np.uint32)
-        bad = np.nonzero(a != b)[0]
+        # a NaN must be a NaN on both sides; its sign / payload bits are the hardware's (x86 generates 0xFFC00000 for 0*inf,
+        # gfx950 0x7FC00000), not the algorithm's
+        bad = np.nonzero((a != b) & ~(np.isnan(got[f]) & np.isnan(want[f])))[0]
         assert len(bad) == 0, f"{what}: {len(bad)} rays differ in {f} bits, first {bad[:5]}: got {got[f][bad[:5]]} want {want[f][bad[:5]]}"
 
 
