@@ -81,3 +81,41 @@ def test_random_hostile_scenes(rc, oracle, seed):
         t.set_option("kernel", kern)
         assert_hits_equal(t.trace(rays), want_c, f"seed {seed} closest k{kern}")
         assert_hits_equal(t.trace(rays, mode="any"), want_a, f"seed {seed} any k{kern}")
+
+
+@pytest.mark.parametrize("seed", range(max(4, N_SEEDS // 3)))
+def test_random_bvh4_and_collision(rc, oracle, seed):
+    """BVH4 collapse + closest_hit4 / any_hit4 and the collision broad phase on random inputs, bit for bit against the oracle."""
+    sc = rc.scenes
+    g = np.random.default_rng(5000 + seed)
+    nt = int(g.choice([1, 2, 3, 4, 5, 9, 33, 257, 2000]))
+    verts = sc.random_triangles(nt, 77 * seed + 1, lo=-0.5, hi=0.5, edge=float(g.choice([0.02, 0.2, 1.0])))
+    if nt > 4 and g.random() < 0.4:
+        verts[2] = verts[1]
+    s = oracle.Scene()
+    b = s.add_blas(verts)
+    s.add_instance(b)
+    s.build()
+    blas = rc.build_blas4(verts)
+    assert blas.nodes.tobytes() == s.blas4_nodes(b).tobytes()
+    n = 4000
+    org = g.uniform(-1.5, 1.5, size=(n, 3))
+    d = sc.normalize(g.uniform(-0.6, 0.6, size=(n, 3)) - org)
+    rays = sc.make_rays(org, d)
+    rays["tmax"][::6] = g.uniform(0, 3, len(rays["tmax"][::6]))
+    assert_hits_equal(blas.trace(rays), s.trace4(b, rays, nthreads=2), f"seed {seed} closest4")
+    assert_hits_equal(blas.trace(rays, mode="any"), s.trace4(b, rays, mode="any", nthreads=2), f"seed {seed} any4")
+    # collision: many instances with hostile transforms
+    m = int(g.choice([1, 2, 3, 17, 300]))
+    xf = np.stack([hostile_transform(g, int(g.integers(0, 7)) if g.random() < 0.3 else 0) for _ in range(m)])
+    xf[:, [3, 7, 11]] *= np.float32(g.choice([0.3, 1.0, 3.0]))
+    t, o = rc.TLAS(), oracle.Scene()
+    t.push(verts, xf.reshape(m, 12))
+    ob = o.add_blas(verts)
+    for x in xf:
+        o.add_instance(ob, x, 0)
+    o.build()
+    want, _ = o.collide_instances()
+    res = rc.collide_instances(t)
+    got = np.stack([res.contacts["instance_a"], res.contacts["instance_b"]], axis=1) if res.num_contacts else np.zeros((0, 2), np.uint32)
+    assert np.array_equal(got, want), f"seed {seed} contacts"
