@@ -195,13 +195,13 @@ struct Trace4Args {
     uint32_t* status;
 };
 
-// fast_intersect_bbox4 (:533-554); cull_t = closest t with NaN mapped to -inf (see RayState in rc_traverse_core.h)
+// fast_intersect_bbox4 (:533-554); closest_t = closest t with NaN mapped to -inf (see RayState in rc_traverse_core.h)
 __device__ inline bool slab4(const float3_ inv, const float3_ ox, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                             float tmin, float cull_t, float& t_entry) {
+                             float tmin, float closest_t, float& t_entry) {
     const float fx = mxx * inv.x + ox.x, fy = mxy * inv.y + ox.y, fz = mxz * inv.z + ox.z;
     const float nx = mnx * inv.x + ox.x, ny = mny * inv.y + ox.y, nz = mnz * inv.z + ox.z;
-    const float max_t = fminf(fminf(fminf(fmaxf(fx, nx), fmaxf(fy, ny)), fmaxf(fz, nz)), cull_t);
-    const float min_t = fmaxf(fmaxf(fmaxf(fminf(fx, nx), fminf(fy, ny)), fminf(fz, nz)), tmin);
+    const float max_t = jl_minf(jl_minf(jl_minf(jl_maxf(fx, nx), jl_maxf(fy, ny)), jl_maxf(fz, nz)), closest_t);
+    const float min_t = jl_maxf(jl_maxf(jl_maxf(jl_minf(fx, nx), jl_minf(fy, ny)), jl_minf(fz, nz)), tmin);
     t_entry = min_t;
     return min_t <= max_t;
 }
@@ -219,14 +219,12 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
     bool exhausted = false;
     uint64_t my_ray = 0;
     float3_ o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0), ox = mk3(0, 0, 0);
-    float closest_t = 0.f, cull_t = 0.f, hit_u = 0.f, hit_v = 0.f;
+    float closest_t = 0.f, hit_u = 0.f, hit_v = 0.f;
     uint32_t closest_prim = RC_INVALID_NODE;
     uint32_t node = RC_INVALID_NODE;  // INVALID + !live = empty lane; INVALID + live = finished
     int sp = 0;
     bool live = false;
     const float tmin = 0.0f;  // closest_hit4 / any_hit4 both start from ray_mint = 0 (:610, :700)
-    float stmin = 0.0f;       // slab-test lower bound: +inf for a ray whose box tests all fail under NaN propagation (box_tests_dead)
-    bool dead = false;
 
     for (;;) {
         for (;;) {
@@ -240,10 +238,10 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                              b4 = buf_f4(nrs, off + 80), b5 = buf_f4(nrs, off + 96);
                 // intersect_all_children4 (:562-599): slots in order, unused slots (child == INVALID) never hit
                 float t0, t1, t2, t3;
-                const bool h0 = slab4(inv, ox, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, stmin, cull_t, t0) && ch.x != RC_INVALID_NODE;
-                const bool h1 = slab4(inv, ox, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, stmin, cull_t, t1) && ch.y != RC_INVALID_NODE;
-                const bool h2 = slab4(inv, ox, b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, stmin, cull_t, t2) && ch.z != RC_INVALID_NODE;
-                const bool h3 = slab4(inv, ox, b4.z, b4.w, b5.x, b5.y, b5.z, b5.w, stmin, cull_t, t3) && ch.w != RC_INVALID_NODE;
+                const bool h0 = slab4(inv, ox, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tmin, closest_t, t0) && ch.x != RC_INVALID_NODE;
+                const bool h1 = slab4(inv, ox, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, tmin, closest_t, t1) && ch.y != RC_INVALID_NODE;
+                const bool h2 = slab4(inv, ox, b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, tmin, closest_t, t2) && ch.z != RC_INVALID_NODE;
+                const bool h3 = slab4(inv, ox, b4.z, b4.w, b5.x, b5.y, b5.z, b5.w, tmin, closest_t, t3) && ch.w != RC_INVALID_NODE;
                 // position of each hit child after the reference's stable insertion sort by entry distance (:590-596):
                 // hits from earlier slots with t <= mine and from later slots with t < mine come first
                 const int r0 = (int)(h1 && t1 < t0) + (int)(h2 && t2 < t0) + (int)(h3 && t3 < t0);
@@ -288,7 +286,6 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                                  !(u < 0.0f || u > 1.0f) && !(v < 0.0f || (u + v) > 1.0f) && !(t < tmin || t > closest_t);
                 closest_prim = hit ? prim_idx : closest_prim;
                 closest_t = hit ? t : closest_t;
-                cull_t = hit ? slab_cull(dead, t) : cull_t;
                 hit_u = hit ? u : hit_u;
                 hit_v = hit ? v : hit_v;
                 if (ANY && hit) node = RC_INVALID_NODE;  // :744-749
@@ -341,9 +338,6 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                         inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
                         ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
                         closest_t = r.tmax;
-                        dead = box_tests_dead(ox, tmin);
-                        cull_t = slab_cull(dead, closest_t);
-                        stmin = slab_tmin(dead, tmin);
                         hit_u = hit_v = 0.0f;
                         closest_prim = RC_INVALID_NODE;
                         sp = 0;

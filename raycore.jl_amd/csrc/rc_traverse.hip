@@ -183,8 +183,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
     // per-lane ray state (see RayState); kept in scalars so each block touches only what it owns
     float3_ wo = mk3(0, 0, 0), wd = mk3(0, 0, 0);
     float3_ o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0), ox = mk3(0, 0, 0);
-    float tmin = 0.f, closest_t = 0.f, cull_t = 0.f, stmin = 0.f, hit_u = 0.f, hit_v = 0.f;
-    bool dead = false;  // see box_tests_dead (rc_traverse_core.h)
+    float tmin = 0.f, closest_t = 0.f, hit_u = 0.f, hit_v = 0.f;
     uint32_t closest_prim = RC_INVALID_NODE, node = RC_INVALID_NODE, cur_off = 0, n_level = 0;
     int closest_inst = -1, cur_inst = -1, sp = 0, kind = K_EMPTY;
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0};
@@ -250,9 +249,6 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                     ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
                     tmin = ANY ? 0.0f : r.tmin;
                     closest_t = r.tmax;
-                    dead = box_tests_dead(ox, tmin);
-                    cull_t = slab_cull(dead, closest_t);
-                    stmin = slab_tmin(dead, tmin);
                     hit_u = hit_v = 0.0f;
                     closest_prim = RC_INVALID_NODE;
                     closest_inst = -1; cur_inst = -1;
@@ -286,10 +282,10 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                 const v2f nf0z = v2f{nc.x, nc.y} * izz + ozz, nf1z = v2f{nc.z, nc.w} * izz + ozz;
                 const float f0x = f0xy.x, f0y = f0xy.y, f0z = nf0z.y, n0x = n0xy.x, n0y = n0xy.y, n0z = nf0z.x;
                 const float f1x = f1xy.x, f1y = f1xy.y, f1z = nf1z.y, n1x = n1xy.x, n1y = n1xy.y, n1z = nf1z.x;
-                const float t0_max = fminf(fminf(fminf(fmaxf(f0x, n0x), fmaxf(f0y, n0y)), fmaxf(f0z, n0z)), cull_t);
-                const float t0_min = fmaxf(fmaxf(fmaxf(fminf(f0x, n0x), fminf(f0y, n0y)), fminf(f0z, n0z)), stmin);
-                const float t1_max = fminf(fminf(fminf(fmaxf(f1x, n1x), fmaxf(f1y, n1y)), fmaxf(f1z, n1z)), cull_t);
-                const float t1_min = fmaxf(fmaxf(fmaxf(fminf(f1x, n1x), fminf(f1y, n1y)), fminf(f1z, n1z)), stmin);
+                const float t0_max = jl_minf(jl_minf(jl_minf(jl_maxf(f0x, n0x), jl_maxf(f0y, n0y)), jl_maxf(f0z, n0z)), closest_t);
+                const float t0_min = jl_maxf(jl_maxf(jl_maxf(jl_minf(f0x, n0x), jl_minf(f0y, n0y)), jl_minf(f0z, n0z)), tmin);
+                const float t1_max = jl_minf(jl_minf(jl_minf(jl_maxf(f1x, n1x), jl_maxf(f1y, n1y)), jl_maxf(f1z, n1z)), closest_t);
+                const float t1_min = jl_maxf(jl_maxf(jl_maxf(jl_minf(f1x, n1x), jl_minf(f1y, n1y)), jl_minf(f1z, n1z)), tmin);
                 const uint32_t trav0 = (t0_min <= t0_max) ? ch.x : RC_INVALID_NODE;
                 const uint32_t trav1 = (t1_min <= t1_max) ? ch.y : RC_INVALID_NODE;
                 const bool first0 = (t0_min < t1_min) && (trav0 != RC_INVALID_NODE);
@@ -319,7 +315,6 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                 const bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || (u + v) > 1.0f) && !(t < tmin || t > closest_t);
                 if (hit) {
                     closest_t = t;
-                    cull_t = slab_cull(dead, t);
                     closest_inst = cur_inst;
                     closest_prim = node - n_level + 1u;  // leaf of sorted primitive j sits at n-1+j (child1 = j)
                     hit_u = u; hit_v = v;
@@ -338,9 +333,6 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                     o = wo; d = wd;
                     inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
                     ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-                    dead = box_tests_dead(ox, tmin);
-                    cull_t = slab_cull(dead, closest_t);
-                    stmin = slab_tmin(dead, tmin);
                 } else {
                     // top-level leaf: enter the instance (:1961-1977)
                     cur_inst = (int)(nodes + (cur_off + node - 1))->child1;
@@ -357,9 +349,6 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                             m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
                     inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
                     ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-                    dead = box_tests_dead(ox, tmin);
-                    cull_t = slab_cull(dead, closest_t);
-                    stmin = slab_tmin(dead, tmin);
                 }
                 kind = classify(node);
             }

@@ -85,23 +85,17 @@ __device__ inline NodeRegs load_node(const RcNode* p) {
     return r;
 }
 
-// Box tests under Julia's NaN-propagating min/max (fast_intersect_bbox :1841-1859).  With finite node boxes a NaN can only come
-// from the ray -- a NaN (-o)*inv component (NaN origin or direction, or inf*0) or a NaN t_min -- and then EVERY box test of that
-// level fails, because min_t or max_t is NaN.  v_min_f32 / v_max_f32 drop NaNs instead, so for such a ray (at such a level) the
-// kernels run the slab test against (t_min, closest) = (+inf, -inf), which fails every test the same way.  A NaN closest t (a
-// NaN-t "hit") is the same case.  Triangle tests need nothing: they use plain comparisons on both sides.
-__device__ inline bool box_tests_dead(const float3_& ox, float tmin) { return (ox.x != ox.x) || (ox.y != ox.y) || (ox.z != ox.z) || (tmin != tmin); }
-__device__ inline float slab_cull(bool dead, float closest_t) { return (dead || closest_t != closest_t) ? -INFINITY : closest_t; }
-__device__ inline float slab_tmin(bool dead, float tmin) { return dead ? INFINITY : tmin; }
+// Box tests under Julia's NaN-propagating min / max (fast_intersect_bbox :1841-1859): a NaN anywhere in a slab test -- a NaN
+// (-o)*inv component (NaN origin or direction, inf*0), a NaN t_min, a NaN closest t (a NaN-t "hit") or a NaN
+// node box (NaN vertices) -- makes min_t or max_t NaN and the test fail.  jl_minf / jl_maxf compile to gfx950's v_minimum3_f32 /
+// v_maximum3_f32, which have exactly that semantics (v_min_f32 / v_max_f32 would drop the NaN), so the kernels need no special
+// cases.  Triangle tests use plain comparisons on both sides.
 
-// Per-ray traversal state.  `cull_t` is closest_t with NaN mapped to -inf: Julia's min(x, NaN) = NaN makes
-// every later box test fail once a NaN-t hit was accepted; comparing against -inf
-// gives the same outcome with v_min_f32, which would otherwise drop the NaN.
+// Per-ray traversal state.
 struct RayState {
     float3_ wo, wd, winv;           // world ray (direction sanitised by check_direction), safe_invdir(world d)
     float3_ o, d, inv, ox;          // current-level ray, 1/d, (-o)*inv
-    float tmin, closest_t, cull_t, stmin;  // cull_t / stmin: what the slab tests compare against (see box_tests_dead)
-    bool dead;
+    float tmin, closest_t;
     float hit_u, hit_v;
     uint32_t closest_prim;
     int closest_inst, cur_inst;
@@ -119,9 +113,6 @@ __device__ inline void init_ray(RayState& s, const RcRay& r, bool any_hit, Stack
     s.ox = mk3(-s.o.x * s.inv.x, -s.o.y * s.inv.y, -s.o.z * s.inv.z);
     s.tmin = any_hit ? 0.0f : r.tmin;  // any_hit forces t_min = 0 (:2039)
     s.closest_t = r.tmax;
-    s.dead = box_tests_dead(s.ox, s.tmin);
-    s.cull_t = slab_cull(s.dead, s.closest_t);
-    s.stmin = slab_tmin(s.dead, s.tmin);
     s.hit_u = s.hit_v = 0.0f;
     s.closest_prim = RC_INVALID_NODE;
     s.closest_inst = -1; s.cur_inst = -1;
@@ -135,10 +126,10 @@ __device__ inline void slab(const RayState& s, float mnx, float mny, float mnz, 
                             float& min_t, float& max_t) {
     float fx = mxx * s.inv.x + s.ox.x, fy = mxy * s.inv.y + s.ox.y, fz = mxz * s.inv.z + s.ox.z;
     float nx = mnx * s.inv.x + s.ox.x, ny = mny * s.inv.y + s.ox.y, nz = mnz * s.inv.z + s.ox.z;
-    float tmaxx = fmaxf(fx, nx), tmaxy = fmaxf(fy, ny), tmaxz = fmaxf(fz, nz);
-    float tminx = fminf(fx, nx), tminy = fminf(fy, ny), tminz = fminf(fz, nz);
-    max_t = fminf(fminf(fminf(tmaxx, tmaxy), tmaxz), s.cull_t);
-    min_t = fmaxf(fmaxf(fmaxf(tminx, tminy), tminz), s.stmin);
+    float tmaxx = jl_maxf(fx, nx), tmaxy = jl_maxf(fy, ny), tmaxz = jl_maxf(fz, nz);
+    float tminx = jl_minf(fx, nx), tminy = jl_minf(fy, ny), tminz = jl_minf(fz, nz);
+    max_t = jl_minf(jl_minf(jl_minf(tmaxx, tmaxy), tmaxz), s.closest_t);
+    min_t = jl_maxf(jl_maxf(jl_maxf(tminx, tminy), tminz), s.tmin);
 }
 
 // One iteration of the reference's while loop (:1936-2007).  Returns false when the ray has terminated.
@@ -172,9 +163,6 @@ __device__ inline bool step(RayState& s, const SceneView& a, Stack& st) {
                   m2.x * s.wd.x + m2.y * s.wd.y + m2.z * s.wd.z);
         s.inv = mk3(safe_inv1(s.d.x), safe_inv1(s.d.y), safe_inv1(s.d.z));
         s.ox = mk3(-s.o.x * s.inv.x, -s.o.y * s.inv.y, -s.o.z * s.inv.z);
-        s.dead = box_tests_dead(s.ox, s.tmin);
-        s.cull_t = slab_cull(s.dead, s.closest_t);
-        s.stmin = slab_tmin(s.dead, s.tmin);
         return true;
     } else {
         // bottom-level leaf: fast_intersect_triangle (:1756-1797) on the vertices stored in the node
@@ -191,7 +179,6 @@ __device__ inline bool step(RayState& s, const SceneView& a, Stack& st) {
         bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || (u + v) > 1.0f) && !(t < s.tmin || t > s.closest_t);
         if (hit) {
             s.closest_t = t;
-            s.cull_t = slab_cull(s.dead, t);
             s.closest_inst = s.cur_inst;
             s.closest_prim = nd.d.y;
             s.hit_u = u; s.hit_v = v;
@@ -206,9 +193,6 @@ __device__ inline bool step(RayState& s, const SceneView& a, Stack& st) {
         s.blas_off = a.tlas_off;
         s.o = s.wo; s.d = s.wd; s.inv = s.winv;
         s.ox = mk3(-s.o.x * s.inv.x, -s.o.y * s.inv.y, -s.o.z * s.inv.z);
-        s.dead = box_tests_dead(s.ox, s.tmin);
-        s.cull_t = slab_cull(s.dead, s.closest_t);
-        s.stmin = slab_tmin(s.dead, s.tmin);
     }
     return s.node != RC_INVALID_NODE;
 }
@@ -345,8 +329,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     uint64_t my_ray = 0;
     float3_ wo = mk3(0, 0, 0), wd = mk3(0, 0, 0), winv = mk3(0, 0, 0);
     float3_ o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0), ox = mk3(0, 0, 0);
-    float tmin = 0.f, closest_t = 0.f, cull_t = 0.f, stmin = 0.f, hit_u = 0.f, hit_v = 0.f;  // cull_t / stmin: slab-test bounds (box_tests_dead)
-    bool dead = false;
+    float tmin = 0.f, closest_t = 0.f, hit_u = 0.f, hit_v = 0.f;
     uint32_t closest_prim = RC_INVALID_NODE, cur_off = 0, n_level = 0;
     uint32_t node = RC_INVALID_NODE;  // INVALID + !live = empty lane; INVALID + live = finished, result pending
     int closest_inst = -1, cur_inst = -1, sp = 0;
@@ -381,10 +364,10 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 const v2f nf0z = v2f{nc.x, nc.y} * izz + ozz, nf1z = v2f{nc.z, nc.w} * izz + ozz;
                 const float f0x = f0xy.x, f0y = f0xy.y, f0z = nf0z.y, n0x = n0xy.x, n0y = n0xy.y, n0z = nf0z.x;
                 const float f1x = f1xy.x, f1y = f1xy.y, f1z = nf1z.y, n1x = n1xy.x, n1y = n1xy.y, n1z = nf1z.x;
-                const float t0_max = fminf(fminf(fminf(fmaxf(f0x, n0x), fmaxf(f0y, n0y)), fmaxf(f0z, n0z)), cull_t);
-                const float t0_min = fmaxf(fmaxf(fmaxf(fminf(f0x, n0x), fminf(f0y, n0y)), fminf(f0z, n0z)), stmin);
-                const float t1_max = fminf(fminf(fminf(fmaxf(f1x, n1x), fmaxf(f1y, n1y)), fmaxf(f1z, n1z)), cull_t);
-                const float t1_min = fmaxf(fmaxf(fmaxf(fminf(f1x, n1x), fminf(f1y, n1y)), fminf(f1z, n1z)), stmin);
+                const float t0_max = jl_minf(jl_minf(jl_minf(jl_maxf(f0x, n0x), jl_maxf(f0y, n0y)), jl_maxf(f0z, n0z)), closest_t);
+                const float t0_min = jl_maxf(jl_maxf(jl_maxf(jl_minf(f0x, n0x), jl_minf(f0y, n0y)), jl_minf(f0z, n0z)), tmin);
+                const float t1_max = jl_minf(jl_minf(jl_minf(jl_maxf(f1x, n1x), jl_maxf(f1y, n1y)), jl_maxf(f1z, n1z)), closest_t);
+                const float t1_min = jl_maxf(jl_maxf(jl_maxf(jl_minf(f1x, n1x), jl_minf(f1y, n1y)), jl_minf(f1z, n1z)), tmin);
                 // intersect_internal_node's INVALID-or-child values, kept as predicates (an interior node has two valid children):
                 // traverse0 = h0 ? child0 : INVALID, traverse1 likewise; near first iff t0_min < t1_min && traverse0 valid
                 const bool h0 = t0_min <= t0_max, h1 = t1_min <= t1_max;
@@ -419,7 +402,6 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 closest_prim = hit ? node - n_level + 1u : closest_prim;  // leaf of sorted primitive j sits at n-1+j
                 closest_inst = hit ? cur_inst : closest_inst;
                 closest_t = hit ? t : closest_t;
-                cull_t = hit ? slab_cull(dead, t) : cull_t;
                 hit_u = hit ? u : hit_u;
                 hit_v = hit ? v : hit_v;
                 if (ANY && hit) node = RC_INVALID_NODE;  // :2106-2115
@@ -437,9 +419,6 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 cur_off = tlas_off; n_level = n_instances;
                 o = wo; d = wd; inv = winv;
                 ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-                dead = box_tests_dead(ox, tmin);
-                cull_t = slab_cull(dead, closest_t);
-                stmin = slab_tmin(dead, tmin);
             } else if (is_entry) {
                 float4 m0, m1, m2;
                 u4v m3;
@@ -465,9 +444,6 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
                 inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
                 ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-                dead = box_tests_dead(ox, tmin);
-                cull_t = slab_cull(dead, closest_t);
-                stmin = slab_tmin(dead, tmin);
             }
         }
         // ---- finished lanes: write out; refill when enough lanes are free
@@ -521,9 +497,6 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
                         tmin = ANY ? 0.0f : r.tmin;
                         closest_t = r.tmax;
-                        dead = box_tests_dead(ox, tmin);
-                        cull_t = slab_cull(dead, closest_t);
-                        stmin = slab_tmin(dead, tmin);
                         hit_u = hit_v = 0.0f;
                         closest_prim = RC_INVALID_NODE;
                         closest_inst = -1; cur_inst = -1;

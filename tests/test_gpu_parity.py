@@ -325,7 +325,8 @@ def test_weird_rays_and_scales(rc, oracle):
 def test_nan_and_inf_rays(rc, oracle):
     """Rays with NaN / Inf components.  Under Julia's NaN-propagating min/max a NaN slab component fails every box test of
     that level, while a triangle reached without a box test (single-leaf TLAS / BLAS) is 'hit' with NaN t (all comparisons
-    false).  The kernels reproduce both (box_tests_dead, rc_traverse_core.h)."""
+    false).  The kernels reproduce both: their slab test runs on v_minimum3_f32 / v_maximum3_f32, which propagate
+    NaNs exactly like Julia's min / max (rc_device.h: jl_minf / jl_maxf)."""
     sc = rc.scenes
     xf, _, _ = sc.lattice_transforms(2, 2, 1, 2.0, 9)
     multi = {"blas": [(sc.fan_sphere(10, 6, radius=0.6), None)], "instances": [(1, xf, np.arange(4, dtype=np.uint32))]}
@@ -346,7 +347,14 @@ def test_nan_and_inf_rays(rc, oracle):
     rays["tmax"][2::12] = np.nan
     rays["tmax"][5::12] = np.inf
     rays["tmin"][8::12] = -np.inf
-    for name, cfg in (("multi", multi), ("single", single), ("two", two)):
+    # NaN / Inf inside the geometry: the NaN climbs into every ancestor box (Julia's min / max propagate it) and those boxes fail
+    # every test; the kernels' v_minimum3 / v_maximum3 slab test does the same
+    bad_v = sc.random_triangles(400, 6, lo=-1, hi=1, edge=0.4)
+    bad_v[7, 0] = np.nan
+    bad_v[100, 5] = np.inf
+    bad_v[200, 7] = -np.inf
+    nan_geom = {"blas": [(bad_v, None)], "instances": [(1, xf[:2], np.arange(2, dtype=np.uint32))]}
+    for name, cfg in (("multi", multi), ("single", single), ("two", two), ("nan_geometry", nan_geom)):
         t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
         want_c, want_a = o.trace(rays, nthreads=4), o.trace(rays, mode="any", nthreads=4)
         for kern in (0, 1, 2, 3, 4, 5):
