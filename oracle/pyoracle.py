@@ -122,8 +122,11 @@ class Scene:
         self._h = lib().rco_scene_new()
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().rco_scene_free(self._h)
+        if getattr(self, "_h", None) and _lib is not None:  # at interpreter shutdown the module globals may already be gone
+            try:
+                _lib.rco_scene_free(self._h)
+            except Exception:  # noqa: BLE001
+                pass
             self._h = None
 
     def add_blas(self, verts, meta=None, filter_degenerate=True):
