@@ -219,20 +219,6 @@ __device__ inline RcRay load_ray(const RcRay* rays, uint64_t i) {
 }
 
 
-// Whole-ray traversal for callers that do not interleave rays (drivers).
-template <bool ANY, class Stack>
-__device__ inline void trace_ray(RayState& s, const RcRay& r, const SceneView& a, Stack& st) {
-    init_ray(s, r, ANY, st, a.tlas_off);
-    if (a.n_tlas_nodes != 0)
-        while (step<ANY>(s, a, st)) {}
-}
-
-// 0-based flat primitive index of the accepted hit (valid when s.closest_inst >= 0), :2012-2014
-__device__ inline uint32_t hit_prim_index(const RayState& s, const SceneView& a) {
-    const uint4 m3 = *(reinterpret_cast<const uint4*>(a.inst + s.closest_inst) + 3);
-    return m3.y + s.closest_prim - 1u;
-}
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Ray source / hit sink of the plain trace entry points: RTRay array in, RTHitResult array out (:2010-2023).
