@@ -64,3 +64,25 @@ def test_header_is_plain_c_and_example_links(rc, tmp_path):
     if rc.device_count() == 0:
         r = subprocess.run([str(exe)], capture_output=True, text=True)
         assert r.returncode == 2 and "no GPU" in r.stderr
+
+
+def test_c_struct_layouts_match_the_reference_records(rc, tmp_path):
+    """The wire / export structs are the reference's records byte for byte: RTRay / RTHitResult 32 B (src/rt_transport.jl), BVHNode2 60 B,
+    InstanceDescriptor 108 B, BLASDescriptor 32 B, Triangle{UInt32} 136 B, BVHNode4 120 B, ContactPair 8 B -- checked from C."""
+    src = tmp_path / "sizes.c"
+    src.write_text(r'''
+#include <stddef.h>
+#include <stdio.h>
+#include "raycore_mi355x.h"
+#define CHECK(T, N) _Static_assert(sizeof(T) == N, #T " must be " #N " bytes")
+CHECK(rc_ray, 32); CHECK(rc_hit, 32); CHECK(rc_bvh_node, 60); CHECK(rc_instance_desc, 108); CHECK(rc_blas_desc, 32);
+CHECK(rc_prim, 40); CHECK(rc_triangle, 136); CHECK(rc_bvh4_node, 120); CHECK(rc_contact_pair, 8);
+_Static_assert(offsetof(rc_hit, t) == 4 && offsetof(rc_hit, primitive_id) == 8 && offsetof(rc_hit, bary_u) == 16 && offsetof(rc_hit, instance_id) == 24, "RTHitResult fields");
+_Static_assert(offsetof(rc_instance_desc, transform) == 8 && offsetof(rc_instance_desc, inv_transform) == 56 && offsetof(rc_instance_desc, flags) == 104, "InstanceDescriptor fields");
+_Static_assert(offsetof(rc_triangle, normals) == 36 && offsetof(rc_triangle, tangents) == 72 && offsetof(rc_triangle, uv) == 108 && offsetof(rc_triangle, metadata) == 132, "Triangle fields");
+_Static_assert(offsetof(rc_bvh4_node, aabb) == 16 && offsetof(rc_bvh4_node, parent) == 112 && offsetof(rc_bvh4_node, child_count) == 116, "BVHNode4 fields");
+int main(void) { puts("ok"); return 0; }
+''')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "ok"
