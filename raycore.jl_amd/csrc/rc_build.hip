@@ -312,14 +312,13 @@ __global__ void k_topology(RcNode* nodes, const uint32_t* codes, int n) {
     int child1 = (c1 == span_right) ? (n - 1 + c1) : c1;
     nodes[idx - 1].child0 = (uint32_t)child0;
     nodes[idx - 1].child1 = (uint32_t)child1;
-}
-
-// set_parent_pointers_kernel! (src/instanced-bvh-kernels.jl:159-191); only the parent word is written
-__global__ void k_parents(RcNode* nodes, int n) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (idx >= n) return;
-    nodes[nodes[idx - 1].child0 - 1].parent = (uint32_t)idx;
-    nodes[nodes[idx - 1].child1 - 1].parent = (uint32_t)idx;
+    nodes[idx - 1].pad = 0;
+    // set_parent_pointers_kernel! (src/instanced-bvh-kernels.jl:159-191) folded in: a node's parent word is written exactly once, by
+    // its parent's thread (the root's by its own), so no separate pass and no fill pass are needed -- every other word of every node is
+    // written by this kernel (child words), the leaf kernels (leaf payload) or the refit (both boxes of every internal node).
+    nodes[child0 - 1].parent = (uint32_t)idx;
+    nodes[child1 - 1].parent = (uint32_t)idx;
+    if (idx == 1) nodes[0].parent = RC_INVALID_NODE;
 }
 
 // create_leaf_nodes_kernel! (src/instanced-bvh-kernels.jl:198-226)
@@ -333,6 +332,7 @@ __global__ void k_blas_leaves(RcNode* nodes, const RcPrim* prims, uint32_t n) {
     nd->f[9] = nd->f[10] = nd->f[11] = 0.0f;
     nd->child0 = RC_INVALID_NODE;
     nd->child1 = j;
+    nd->pad = 0;
 }
 
 // Device-coherent 8/16-byte accesses for data exchanged between workgroups inside one launch: sc0 sc1 loads and
@@ -453,6 +453,7 @@ __global__ void k_tlas_leaves(RcNode* nodes, const uint32_t* sorted, const RcIns
     nd->f[6] = nd->f[7] = nd->f[8] = nd->f[9] = nd->f[10] = nd->f[11] = 0.0f;
     nd->child0 = RC_INVALID_NODE;
     nd->child1 = orig;
+    nd->pad = 0;
 }
 
 // Traversal copy of a node array in the packed order of rc_pack_node.
@@ -492,11 +493,8 @@ void reserve_build_scratch(rc_scene* s, uint32_t n) {
 
 // Karras topology + parents for n items with sorted keys in keys_b
 void emit_tree(rc_scene* s, RcNode* nodes, uint32_t n) {
-    hipLaunchKernelGGL(k_fill_nodes, dim3(grid_for(2 * (uint64_t)n - 1)), dim3(kBlock), 0, s->stream, nodes, 2 * n - 1);
-    if (n > 1) {
-        hipLaunchKernelGGL(k_topology, dim3(grid_for(n - 1)), dim3(kBlock), 0, s->stream, nodes, s->keys_b.p, (int)n);
-        hipLaunchKernelGGL(k_parents, dim3(grid_for(n - 1)), dim3(kBlock), 0, s->stream, nodes, (int)n);
-    }
+    if (n > 1) hipLaunchKernelGGL(k_topology, dim3(grid_for(n - 1)), dim3(kBlock), 0, s->stream, nodes, s->keys_b.p, (int)n);
+    else hipLaunchKernelGGL(k_fill_nodes, dim3(1), dim3(kBlock), 0, s->stream, nodes, 1u);  // single leaf: empty node, the leaf kernel fills the payload
 }
 
 void run_refit(rc_scene* s, RcNode* nodes, const RcPrim* prims, uint32_t n, int tlas) {
