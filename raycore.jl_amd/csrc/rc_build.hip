@@ -325,14 +325,17 @@ __global__ void k_topology(RcNode* nodes, const uint32_t* codes, int n) {
 __global__ void k_blas_leaves(RcNode* nodes, const RcPrim* prims, uint32_t n) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (j > n) return;
-    RcNode* nd = &nodes[(n - 1 + j) - 1];
-    const RcPrim& p = prims[j - 1];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) nd->f[k] = p.v[k];
-    nd->f[9] = nd->f[10] = nd->f[11] = 0.0f;
-    nd->child0 = RC_INVALID_NODE;
-    nd->child1 = j;
-    nd->pad = 0;
+    // 16-byte stores instead of one store per word (a wave's 64 leaves are 4 KiB apart word by word); the parent word (14) belongs to
+    // the topology kernel and is left alone
+    const float2* pv = reinterpret_cast<const float2*>(prims + (j - 1));  // RcPrim is 40 bytes: 8-byte aligned
+    const float2 a = pv[0], b = pv[1], c = pv[2], d = pv[3], e = pv[4];   // v[0..9]: nine vertex floats, then the metadata word
+    uint4* q = reinterpret_cast<uint4*>(&nodes[(n - 1 + j) - 1]);
+    q[0] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x), __float_as_uint(b.y));
+    q[1] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(d.x), __float_as_uint(d.y));
+    q[2] = make_uint4(__float_as_uint(e.x), 0u, 0u, 0u);  // f[8], f[9..11] = 0
+    uint32_t* w = reinterpret_cast<uint32_t*>(q + 3);
+    *reinterpret_cast<uint2*>(w) = make_uint2(RC_INVALID_NODE, j);  // child0, child1
+    w[3] = 0u;                                                      // pad
 }
 
 // Device-coherent 8/16-byte accesses for data exchanged between workgroups inside one launch: sc0 sc1 loads and
