@@ -321,6 +321,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     int closest_inst = -1, cur_inst = -1, sp = 0;
     bool live = false;
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0};
+    int thr_eff = a.int_thr;
 
     for (;;) {
         // ---- interior phase: intersect_internal_node (:1807-1832) + push far / descend near / pop (:1946-1960, 1991-1993)
@@ -363,7 +364,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 if (far_ok) st.push(sp, far_c);
                 node = near_ok ? near_c : st.pop(sp);
             }
-            if (n_int < a.int_thr) break;  // too few interior lanes left: serve the waiting ones first
+            if (n_int < thr_eff) break;  // too few interior lanes left: serve the waiting ones first
         }
         // ---- leaf phase: fast_intersect_triangle (:1756-1797) on BLAS leaves, then pop
         {
@@ -437,6 +438,10 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             const bool fin = live && node == RC_INVALID_NODE;
             const int n_free = __popcll(__ballot(fin || !live));
             const bool can_refill = !(exhausted && pool_next == pool_end);
+            if (!can_refill) {  // drain: no more rays to hand out, so the interior loop's exit threshold follows the lanes still alive
+                const int half_live = (64 - n_free) / 2;
+                thr_eff = half_live < a.int_thr ? (half_live > 1 ? half_live : 1) : a.int_thr;
+            }
             if (n_free == 64 && !can_refill && !__ballot(fin)) break;
             if (n_free >= a.refill || n_free == 64 || !can_refill) {
                 if (fin) {
