@@ -112,14 +112,10 @@ __device__ inline void write_leaf4(RcNode4* out, const RcNode& n2, uint32_t pare
     w[30] = w[31] = 0;
 }
 
-// totals[0] = nodes allocated so far (in/out), totals[1] = tasks emitted for the next level (out)
-__global__ void k_collapse_emit(const RcNode* nodes2, const Task4* tasks, uint32_t n_tasks, const Gather4* gathers,
-                                const unsigned long long* offsets, uint32_t base_nodes, RcNode4* nodes4, Task4* next_tasks) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_tasks) return;
-    const Task4 tk = tasks[i];
-    const Gather4 g = gathers[i];
-    const unsigned long long off = offsets[i];
+// One task of the collapse: take node index base_nodes + (off >> 32) + 1, write the interior record and its leaf children, patch the
+// parent's child slot, queue the interior children at next_tasks[(uint32_t)off ...] (next_tasks may point to LDS or global memory).
+__device__ inline void emit_task(const RcNode* nodes2, const Task4 tk, const Gather4& g, unsigned long long off, uint32_t base_nodes,
+                                 RcNode4* nodes4, Task4* next_tasks) {
     const uint32_t current4 = base_nodes + (uint32_t)(off >> 32) + 1u;  // 1-based
     uint32_t next_pos = (uint32_t)off;
     if (tk.parent4 != RC_INVALID_NODE) reinterpret_cast<uint32_t*>(nodes4 + (tk.parent4 - 1))[tk.slot] = current4;  // :415-444
@@ -149,6 +145,48 @@ __global__ void k_collapse_emit(const RcNode* nodes2, const Task4* tasks, uint32
     w[28] = tk.parent4;
     w[29] = g.count;  // child_count, primitive_count 0
     w[30] = w[31] = 0;
+}
+
+__global__ void k_collapse_emit(const RcNode* nodes2, const Task4* tasks, uint32_t n_tasks, const Gather4* gathers,
+                                const unsigned long long* offsets, uint32_t base_nodes, RcNode4* nodes4, Task4* next_tasks) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tasks) return;
+    emit_task(nodes2, tasks[i], gathers[i], offsets[i], base_nodes, nodes4, next_tasks);
+}
+
+// Narrow levels (<= kSmallLevel tasks: the top of the tree and the tails of skinny subtrees) run inside ONE workgroup, level after
+// level, with the task queues in LDS and a block-wide scan -- no launches, no host round trip per level.  state[0] = tasks in `tasks`
+// on entry / tasks left for the wide path on exit (0 = done, else > kSmallLevel and stored in `wide_out`), state[1] = nodes allocated.
+constexpr int kSmallLevel = 1024;
+__global__ __launch_bounds__(kSmallLevel) void k_collapse_small(const RcNode* nodes2, const Task4* tasks, uint32_t* state, RcNode4* nodes4, Task4* wide_out) {
+    typedef hipcub::BlockScan<unsigned long long, kSmallLevel> Scan;
+    __shared__ typename Scan::TempStorage scan_tmp;
+    __shared__ Task4 q[2][kSmallLevel];
+    uint32_t n_tasks = state[0], base_nodes = state[1];
+    if (threadIdx.x < n_tasks) q[0][threadIdx.x] = tasks[threadIdx.x];
+    __syncthreads();
+    int cur = 0;
+    while (n_tasks > 0 && n_tasks <= (uint32_t)kSmallLevel) {
+        const bool mine = threadIdx.x < n_tasks;
+        Task4 tk = Task4{0u, 0u, 0u, 0u};
+        Gather4 g;
+        unsigned long long cnt = 0ull, off = 0ull, total = 0ull;
+        if (mine) {
+            tk = q[cur][threadIdx.x];
+            gather_children(nodes2, tk.bvh2, g);
+            const uint32_t n_leaf = __popc(g.leaf_mask);
+            cnt = ((unsigned long long)(1u + n_leaf) << 32) | (unsigned long long)(g.count - n_leaf);
+        }
+        Scan(scan_tmp).ExclusiveSum(cnt, off, total);
+        const uint32_t next_n = (uint32_t)total;
+        Task4* next_tasks = next_n <= (uint32_t)kSmallLevel ? q[cur ^ 1] : wide_out;
+        if (mine) emit_task(nodes2, tk, g, off, base_nodes, nodes4, next_tasks);
+        base_nodes += (uint32_t)(total >> 32);
+        n_tasks = next_n;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { state[0] = n_tasks; state[1] = base_nodes; }
 }
 
 __global__ void k_collapse_totals(const unsigned long long* counts, const unsigned long long* offsets, uint32_t n_tasks, uint32_t* totals) {
@@ -195,7 +233,7 @@ struct Trace4Args {
     uint32_t* status;
 };
 
-// fast_intersect_bbox4 (:533-554); closest_t = closest t with NaN mapped to -inf (see RayState in rc_traverse_core.h)
+// fast_intersect_bbox4 (:533-554); jl_minf / jl_maxf propagate NaNs like Julia's min / max
 __device__ inline bool slab4(const float3_ inv, const float3_ ox, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                              float tmin, float closest_t, float& t_entry) {
     const float fx = mxx * inv.x + ox.x, fy = mxy * inv.y + ox.y, fz = mxz * inv.z + ox.z;
@@ -383,6 +421,18 @@ void rc_build_blas4(rc_scene* s, Blas& b) {
     RC_HIP(hipMemcpyAsync(cur, &root, sizeof(root), hipMemcpyHostToDevice, st));
     uint32_t n_tasks = 1, base_nodes = 0;
     while (n_tasks > 0) {
+        if (n_tasks <= (uint32_t)kSmallLevel) {
+            const uint32_t st_in[2] = {n_tasks, base_nodes};
+            RC_HIP(hipMemcpyAsync(s->c4_totals.p, st_in, sizeof(st_in), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(kSmallLevel), 0, st, b.nodes.p, cur, s->c4_totals.p, b.nodes4.p, nxt);
+            uint32_t st_out[2];
+            RC_HIP(hipMemcpyAsync(st_out, s->c4_totals.p, sizeof(st_out), hipMemcpyDeviceToHost, st));
+            RC_HIP(hipStreamSynchronize(st));
+            n_tasks = st_out[0];
+            base_nodes = st_out[1];
+            std::swap(cur, nxt);
+            continue;
+        }
         const uint32_t blocks = (n_tasks + 255) / 256;
         hipLaunchKernelGGL(k_collapse_gather, dim3(blocks), dim3(256), 0, st, b.nodes.p, cur, n_tasks, gathers, s->c4_counts.p);
         size_t tb = s->sort_tmp.cap;
