@@ -837,12 +837,12 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "lds_stack") *value = s->opt.lds_stack;
     else if (k == "refill") *value = s->opt.refill;
     else if (k == "tail") *value = s->opt.tail;
-    else if (k.rfind("stat", 0) == 0 && k.size() == 5 && k[4] >= '0' && k[4] <= '7') {
-        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    else if (k.rfind("stat", 0) == 0 && k.size() == 5 && ((k[4] >= '0' && k[4] <= '9') || (k[4] >= 'a' && k[4] <= 'f'))) {
+        unsigned long long st[16] = {0};
         (void)hipSetDevice(s->device);
         (void)hipDeviceSynchronize();
         if (s->counters.p && hipMemcpy(st, rc_counter_slot(s) + 8, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "stats read failed");
-        *value = (int64_t)st[k[4] - '0'];
+        *value = (int64_t)st[k[4] <= '9' ? k[4] - '0' : k[4] - 'a' + 10];
     }
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
     return RC_OK;

@@ -321,6 +321,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     int closest_inst = -1, cur_inst = -1, sp = 0;
     bool live = false;
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0};
+    unsigned long long st_t0 = STATS ? wall_clock64() : 0ull, st_tx = 0ull;
     int thr_eff = a.int_thr;
 
     for (;;) {
@@ -438,6 +439,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             const bool fin = live && node == RC_INVALID_NODE;
             const int n_free = __popcll(__ballot(fin || !live));
             const bool can_refill = !(exhausted && pool_next == pool_end);
+            if (STATS && !can_refill && st_tx == 0) st_tx = wall_clock64();
             if (!can_refill) {  // drain: no more rays to hand out, so the interior loop's exit threshold follows the lanes still alive
                 const int half_live = (64 - n_free) / 2;
                 thr_eff = half_live < a.int_thr ? (half_live > 1 ? half_live : 1) : a.int_thr;
@@ -503,9 +505,19 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
         }
     }
     if (STATS) {
+        const unsigned long long t_end = wall_clock64();
         for (int k = 0; k < 4; ++k) {
-            if (lane == 0) atomicAdd(&a.stats[2 * k], st_iter[k]);
-            atomicAdd(&a.stats[2 * k + 1], st_lane[k]);
+            unsigned long long v = st_lane[k];  // one atomic per wave: 64 same-address atomics per wave would stall the waves still tracing
+            for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+            if (lane == 0) { atomicAdd(&a.stats[2 * k], st_iter[k]); atomicAdd(&a.stats[2 * k + 1], v); }
+        }
+        if (lane == 0) {  // drain timing, 100 MHz ticks: [8] ~first start, [9] ~first wave out of work, [10] last end, [11] sum(end - out of work), [12] sum(end - start), [13] waves
+            atomicMax(&a.stats[8], ~st_t0);
+            atomicMax(&a.stats[9], ~st_tx);
+            atomicMax(&a.stats[10], t_end);
+            atomicAdd(&a.stats[11], t_end - st_tx);
+            atomicAdd(&a.stats[12], t_end - st_t0);
+            atomicAdd(&a.stats[13], 1ull);
         }
     }
 }

@@ -68,7 +68,9 @@ def main():
     wl = {"c2": ("C2 closest", t2, rays2, "closest"), "c3": ("C3 primary", t3, rays3, "closest"),
           "shadow": ("C3 shadow-any", t3, shadow, "any"), "c4": ("C4 bounce", t3, bounce, "closest")}
     wl.update(wl_extra)
-    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 32, "pool": 0, "tail": 1}
+    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 32, "pool": 0, "tail": 1,
+                }
+    first_hits = {}
     for var in args.variants.split(";"):
         opts = dict(defaults)
         for kv in var.split(","):
@@ -82,15 +84,25 @@ def main():
             name, t, rays, mode = wl[w]
             ms, hits = time_trace(t, rays, mode)
             extra = ""
+            if w not in first_hits:
+                first_hits[w] = hits.copy()
+            elif hits.tobytes() != first_hits[w].tobytes():
+                extra = f" !!! {int((hits.view(np.uint8).reshape(len(hits), -1) != first_hits[w].view(np.uint8).reshape(len(hits), -1)).any(axis=1).sum())} HITS DIFFER from the first variant"
             if args.stats and opts["kernel"] in (1, 2, 3):
                 t.set_option("stats", 1)
-                time_trace(t, rays, mode, 1)
+                ms_stats = time_trace(t, rays, mode, 2)[0]
                 v = [t.get_option(f"stat{i}") for i in range(8)]
+                tv = [t.get_option(f"stat{c}") for c in "89abcd"]
                 t.set_option("stats", 0)
                 if opts["kernel"] == 1:
                     extra = f" wave_steps={v[0]} lanes/step={v[1]/max(v[0],1):.1f} max_sp={v[2]}"
                 elif opts["kernel"] == 3:
                     extra = f" | I {v[2]} x{v[3]/max(v[2],1):.1f} | L {v[4]} x{v[5]/max(v[4],1):.1f} | S {v[6]} x{v[7]/max(v[6],1):.1f} | refills {v[0]}"
+                    m64 = (1 << 64) - 1
+                    t0, tx, te = m64 - (tv[0] & m64), m64 - (tv[1] & m64), tv[2]
+                    nw = max(tv[5], 1)
+                    extra += (f" | stats run {ms_stats * 1e3:.0f} us; ticks/100: total {(te - t0) / 100:.0f}, first wave out of work at {(tx - t0) / 100:.0f}, mean wave idle-at-end "
+                              f"{(te - t0 - tv[4] / nw) / 100:.0f}, mean wave drain {tv[3] / nw / 100:.0f}")
                 else:
                     extra = (f" iters={v[0]} live/iter={v[1]/max(v[0],1):.1f} | I {v[2]} x{v[3]/max(v[2],1):.1f} | L {v[4]} x{v[5]/max(v[4],1):.1f}"
                              f" | E {v[6]} x{v[7]/max(v[6],1):.1f}")
