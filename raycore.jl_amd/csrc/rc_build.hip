@@ -10,6 +10,7 @@
 // do not round), the sort is rocPRIM's stable LSD radix sort over the 30 key bits, topology is one thread
 // per internal node, refit is the classic second-arrival walk with agent-scope acq_rel counters.
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -513,12 +514,20 @@ __global__ void k_inst_recs(const RcInstanceDesc* inst, const RcBlasDesc* descs,
     out[i] = r;
 }
 
-// stable sortperm of the 30-bit keys (Base.sortperm / AK.sortperm, src/instanced-bvh.jl:1399, 1533-1540)
-void sort_pairs(rc_scene* s, uint32_t n) {
+// stable sortperm of the 30-bit keys (Base.sortperm / AK.sortperm, src/instanced-bvh.jl:1399, 1533-1540).  rocPRIM's default switches
+// from Onesweep to a merge sort at <= 1 Mi items (block sort + log2(n / 1024) partition/merge launch pairs: 146 us for 1 M keys); both
+// are stable, so the permutation is the same and the switch point is ours to choose (opt.onesweep_min).
+template <size_t MergeLimit>
+static void sort_pairs_cfg(rc_scene* s, uint32_t n) {
+    using Cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, MergeLimit>;
     size_t tmp = 0;
-    RC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vals_b.p, (int)n, 0, 30, s->stream));
+    RC_HIP(rocprim::radix_sort_pairs<Cfg>(nullptr, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vals_b.p, n, 0u, 30u, s->stream));
     s->sort_tmp.reserve(tmp ? tmp : 1);
-    RC_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vals_b.p, (int)n, 0, 30, s->stream));
+    RC_HIP(rocprim::radix_sort_pairs<Cfg>(s->sort_tmp.p, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vals_b.p, n, 0u, 30u, s->stream));
+}
+void sort_pairs(rc_scene* s, uint32_t n) {
+    if ((int64_t)n >= s->opt.onesweep_min) sort_pairs_cfg<4096>(s, n);
+    else sort_pairs_cfg<(size_t)1 << 30>(s, n);
 }
 
 void reserve_build_scratch(rc_scene* s, uint32_t n) {

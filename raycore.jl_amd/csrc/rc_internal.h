@@ -78,6 +78,7 @@ struct TraceOptions {
     int64_t refill = 20;       // persistent kernel: refill when this many lanes of a wave are idle
     int64_t sched_thr = 32;    // kernel 2: lanes that must wait for a leaf/switch batch; kernel 3: interior lanes below which the wave serves the waiting lanes
     int64_t stats = 0;         // dev instrumentation (persistent kernels only)
+    int64_t onesweep_min = 1000000;  // builds: key counts from here up are sorted by Onesweep radix passes, smaller ones by rocPRIM's merge sort (measured: 0.22 vs 0.25 ms at 250 k keys, 0.437 vs 0.425 ms at 1 M)
     int64_t tail = 1;          // phased kernels: claims shrink to remaining / (waves * tail) near the end of a batch (0 = fixed-size claims)
 };
 
