@@ -493,6 +493,67 @@ __global__ void k_tlas_leaves(RcNode* nodes, const uint32_t* sorted, const RcIns
     nd->pad = 0;
 }
 
+// ---- single-BLAS scenes: breadth-first renumbering of the BLAS's top internal nodes in the traversal copy (rc_traverse_core.h,
+// kLdsPlaneNodes).  remap[old - 1] = new index of internal node `old`: the first K nodes of a breadth-first walk (child0 before
+// child1, internal nodes only) get 1..K in that order, the nodes they displace take the vacated indices, everything else stays.
+__global__ void k_iota1(uint32_t* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i + 1u;
+}
+constexpr int kTopBlock = 1024;
+__global__ __launch_bounds__(kTopBlock) void k_top_remap(const RcNode* nodes, uint32_t n_leaves, uint32_t K, uint32_t* remap) {
+    typedef hipcub::BlockScan<uint32_t, kTopBlock> Scan;
+    __shared__ typename Scan::TempStorage tmp;
+    __shared__ uint32_t top[rc::kLdsPlaneNodes], in_top[rc::kLdsPlaneNodes + 1], d_list[rc::kLdsPlaneNodes], v_list[rc::kLdsPlaneNodes];
+    const uint32_t t = threadIdx.x;
+    if (t == 0) top[0] = 1u;
+    if (t <= K) in_top[t] = 0u;
+    __syncthreads();
+    uint32_t begin = 0, end = 1;
+    while (end < K && begin < end) {  // one tree level per round
+        uint32_t c0 = 0, c1 = 0, k0 = 0, k1 = 0;
+        if (t < end - begin) {
+            const RcNode& nd = nodes[top[begin + t] - 1];
+            c0 = nd.child0; c1 = nd.child1;
+            k0 = c0 < n_leaves ? 1u : 0u; k1 = c1 < n_leaves ? 1u : 0u;  // internal nodes are 1..n-1
+        }
+        uint32_t off, total;
+        Scan(tmp).ExclusiveSum(k0 + k1, off, total);
+        if (k0 && end + off < K) top[end + off] = c0;
+        if (k1 && end + off + k0 < K) top[end + off + k0] = c1;
+        begin = end;
+        end = end + total < K ? end + total : K;
+        __syncthreads();
+    }
+    const uint32_t n_top = end;  // == K whenever the tree has K internal nodes (the caller guarantees it)
+    if (t < n_top && top[t] <= n_top) in_top[top[t]] = 1u;
+    __syncthreads();
+    // displaced = indices 1..n_top that are not top nodes (ascending); vacated = top nodes with an index above n_top (walk order)
+    const uint32_t is_d = (t >= 1 && t <= n_top && !in_top[t]) ? 1u : 0u;
+    uint32_t rank, total;
+    Scan(tmp).ExclusiveSum(is_d, rank, total);
+    if (is_d) d_list[rank] = t;
+    __syncthreads();
+    const uint32_t is_v = (t < n_top && top[t] > n_top) ? 1u : 0u;
+    Scan(tmp).ExclusiveSum(is_v, rank, total);
+    if (is_v) v_list[rank] = top[t];
+    __syncthreads();
+    if (t < total) remap[d_list[t] - 1] = v_list[t];
+    if (t < n_top) remap[top[t] - 1] = t + 1u;
+}
+__global__ void k_pack_nodes_remap(const RcNode* src, RcNode* dst, uint32_t n_nodes, uint32_t n_leaves, const uint32_t* remap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    RcNode nd = src[i];
+    uint32_t at = i;
+    if (i + 1u < n_leaves) {
+        if (nd.child0 < n_leaves) nd.child0 = remap[nd.child0 - 1];
+        if (nd.child1 < n_leaves) nd.child1 = remap[nd.child1 - 1];
+        at = remap[i] - 1u;
+    }
+    dst[at] = rc_pack_node(nd);
+}
+
 // Traversal copy of a node array in the packed order of rc_pack_node.
 __global__ void k_pack_nodes(const RcNode* src, RcNode* dst, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -694,8 +755,18 @@ void rc_build_tlas(rc_scene* s) {
     s->flat_nodes.reserve((size_t)tn + 2 * (size_t)n + 1);  // + room for the TLAS copy behind the BLAS nodes
     s->flat_prims.reserve(tp ? tp : 1);
     s->d_descs.reserve(nb ? nb : 1);
+    // One BLAS and a TLAS small enough for the LDS kernel: the BLAS's top internal nodes go to the front of the traversal copy
+    s->blas_top_k = 0;
+    if (nb == 1 && s->opt.blas_top && n > 0 && 2 * n - 1 <= (uint32_t)rc::kTlasLdsNodes && s->blas[0].n_prims >= 2) {
+        const uint32_t n_leaves = s->blas[0].n_prims, n_int = n_leaves - 1, room = (uint32_t)rc::kLdsPlaneNodes - (2 * n - 1);
+        s->blas_top_k = n_int < room ? n_int : room;
+        s->keys_a.reserve(n_int);
+        hipLaunchKernelGGL(k_iota1, dim3(grid_for(n_int)), dim3(kBlock), 0, s->stream, s->keys_a.p, n_int);
+        hipLaunchKernelGGL(k_top_remap, dim3(1), dim3(kTopBlock), 0, s->stream, s->blas[0].nodes.p, n_leaves, s->blas_top_k, s->keys_a.p);
+    }
     for (uint32_t i = 0; i < nb; ++i) {
-        hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes);
+        if (s->blas_top_k) hipLaunchKernelGGL(k_pack_nodes_remap, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes, s->blas[i].n_prims, s->keys_a.p);
+        else hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes);
         RC_HIP(hipMemcpyAsync(s->flat_prims.p + s->descs[i].primitives_offset, s->blas[i].prims.p, sizeof(RcPrim) * s->blas[i].n_prims, hipMemcpyDeviceToDevice, s->stream));
     }
     if (nb) RC_HIP(hipMemcpyAsync(s->d_descs.p, s->descs.data(), sizeof(RcBlasDesc) * nb, hipMemcpyHostToDevice, s->stream));

@@ -825,6 +825,7 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "pool") s->opt.pool = value;
     else if (k == "tail") s->opt.tail = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (k == "onesweep_min") s->opt.onesweep_min = value < 0 ? 0 : value;
+    else if (k == "blas_top") s->opt.blas_top = value != 0;
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
     return RC_OK;
@@ -839,6 +840,8 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "refill") *value = s->opt.refill;
     else if (k == "tail") *value = s->opt.tail;
     else if (k == "onesweep_min") *value = s->opt.onesweep_min;
+    else if (k == "blas_top") *value = s->opt.blas_top;
+    else if (k == "blas_top_k") *value = s->blas_top_k;
     else if (k.rfind("stat", 0) == 0 && k.size() == 5 && ((k[4] >= '0' && k[4] <= '9') || (k[4] >= 'a' && k[4] <= 'f'))) {
         unsigned long long st[16] = {0};
         (void)hipSetDevice(s->device);

@@ -70,6 +70,16 @@ struct HandleRange {
     uint32_t first = 0, count = 0;  // 0-based range in the instance array
 };
 
+namespace rc {
+constexpr int kTlasLdsNodes = 512;    // largest TLAS (nodes) the LDS kernels take
+constexpr int kTlasLdsInst = 256;
+// The planes hold kLdsPlaneNodes entries: the TLAS first, then -- in a scene with a single BLAS -- the BLAS's top `blas_k` internal
+// nodes, which rc_build_tlas renumbers to 1..blas_k in breadth-first order in the traversal copy (a private permutation of internal
+// node indices: visit order, tests and results are untouched, leaves keep their indices).  On C3 the top 65 of 4095 internal nodes
+// take 52 % of the BLAS-level interior visits.
+constexpr int kLdsPlaneNodes = 576;
+}  // namespace rc
+
 struct TraceOptions {
     int64_t kernel = -1;       // -1 = auto, 0 = one-ray-per-lane, 1 = persistent wave-refill, 2 = persistent + voted path scheduling, 3 = persistent + phased (while-while), 4 = 3 with the TLAS + instance records staged in LDS (1024-thread blocks, <= 256 instances), 5 = 3 with the TLAS staged in LDS at 24 waves/CU (2 x 768 threads)
     int64_t blocks_per_cu = 0; // 0 = derive from the LDS stack depth
@@ -79,6 +89,7 @@ struct TraceOptions {
     int64_t sched_thr = 32;    // kernel 2: lanes that must wait for a leaf/switch batch; kernel 3: interior lanes below which the wave serves the waiting lanes
     int64_t stats = 0;         // dev instrumentation (persistent kernels only)
     int64_t onesweep_min = 1000000;  // builds: key counts from here up are sorted by Onesweep radix passes, smaller ones by rocPRIM's merge sort (measured: 0.22 vs 0.25 ms at 250 k keys, 0.437 vs 0.425 ms at 1 M)
+    int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
     int64_t tail = 1;          // phased kernels: claims shrink to remaining / (waves * tail) near the end of a batch (0 = fixed-size claims)
 };
 
@@ -106,6 +117,7 @@ struct rc_scene {
     uint32_t n_static_instances = 0;
     DevBuf<RcNode> flat_nodes;
     uint32_t n_flat_nodes = 0;
+    uint32_t blas_top_k = 0;           // single-BLAS scene: internal nodes 1..blas_top_k of the traversal copy are the tree's top in breadth-first order
     DevBuf<RcPrim> flat_prims;
     uint32_t n_flat_prims = 0;
     DevBuf<RcBlasDesc> d_descs;

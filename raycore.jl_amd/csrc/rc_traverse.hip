@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
 // (28 KiB) + the instance records (16 KiB) = 140 KiB of the CU's 160 KiB LDS.  Used when the scene has <= 256 instances.
 constexpr int kBigBlock = 1024;
 constexpr size_t kBigStackBytes = (size_t)kLdsStack * kBigBlock * 4;
-constexpr size_t kTlasPlaneBytes = (size_t)7 * kTlasLdsNodes * sizeof(float2);
+constexpr size_t kTlasPlaneBytes = (size_t)7 * kLdsPlaneNodes * sizeof(float2);
 constexpr size_t kBigLdsBytes = kBigStackBytes + kTlasPlaneBytes + (size_t)kTlasLdsInst * 64;
 
 // BLOCK threads per workgroup, LDS_N stack entries per lane in LDS, INST_LDS: instance records staged too.
@@ -131,12 +131,16 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     const RcNode* tnodes = a.v.blas_nodes + a.v.tlas_off;
     for (uint32_t i = threadIdx.x; i < a.v.n_tlas_nodes * 7u; i += BLOCK) {
         const uint32_t nd = i / 7u, p = i % 7u;
-        tl[p * kTlasLdsNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
+        tl[p * kLdsPlaneNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
+    }
+    for (uint32_t i = threadIdx.x; i < a.blas_k * 7u; i += BLOCK) {  // single-BLAS scene: its top internal nodes sit first in the traversal copy
+        const uint32_t nd = i / 7u, p = i % 7u;
+        tl[p * kLdsPlaneNodes + a.lds_blas_base + nd] = reinterpret_cast<const float2*>(a.v.blas_nodes + nd)[p];
     }
     if (INST_LDS)
         for (uint32_t i = threadIdx.x; i < a.v.n_inst * 4u; i += BLOCK) il[i] = reinterpret_cast<const float4*>(a.v.inst)[i];
     __syncthreads();
-    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div};
+    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base};
     phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, INST_LDS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, tl, il);
 }
 constexpr int kMidBlock = 768, kMidStack = 16;
@@ -504,6 +508,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.sched_thr = (int)s->opt.sched_thr;
     a.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
     a.tail_div = (uint32_t)((total_threads / 64) * (uint64_t)s->opt.tail);
+    if (s->opt.kernel == 5 && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = s->n_tlas_nodes; }
     RC_HIP(hipEventRecord(s->ev0, stream));
     if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
     s->opt.kernel = saved_kernel;

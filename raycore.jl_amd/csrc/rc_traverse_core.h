@@ -38,6 +38,7 @@ struct TraceArgs {
     int sched_thr;                     // scheduled kernel: run a leaf/entry batch once this many lanes wait for it
     unsigned long long* stats;         // optional instrumentation (dev builds), else nullptr
     uint32_t tail_div = 0;             // phased kernels: see PersistArgs
+    uint32_t blas_k = 0, lds_blas_base = 0;
 };
 
 // Address-space-qualified pointers keep the two halves of the stack on their own instruction paths
@@ -286,14 +287,15 @@ struct PersistArgs {
     int int_thr;                       // leave the interior loop when fewer lanes than this have an interior node pending
     unsigned long long* stats;
     uint32_t tail_div = 0;             // guided self-scheduling: a claim takes min(pool, remaining / tail_div) items (0 = always `pool`)
+    uint32_t blas_k = 0;               // TLAS_LDS kernels: BLAS nodes 1..blas_k are staged in the planes at entry lds_blas_base + node - 1
+    uint32_t lds_blas_base = 0;
 };
 
 // TLAS_LDS: the block has staged the whole top level in LDS before the call (see k_trace_phased_lds): `tl` holds the packed
 // TLAS nodes as seven float2 planes of kTlasLdsNodes entries (dword pairs 0-1, 2-3, ... 12-13 of each node; a plane read is
 // one ds_read_b64 with lane addresses 8 bytes apart per node), `il` the instance records (4 x float4 each).  TLAS-level
 // visits and instance entries then never touch the vector-memory path, which is what bounds the kernel.
-constexpr int kTlasLdsNodes = 512;
-constexpr int kTlasLdsInst = 256;
+// kTlasLdsNodes, kTlasLdsInst, kLdsPlaneNodes: rc_internal.h (the TLAS build needs them too)
 
 template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS>
 __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
@@ -334,10 +336,10 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             if (is_int) {
                 float4 na, nb, nc;
                 u2v ch;
-                if (TLAS_LDS && cur_inst < 0) {
-                    const float2* q = tl + (node - 1u);
-                    const float2 p0 = q[0], p1 = q[kTlasLdsNodes], p2 = q[2 * kTlasLdsNodes], p3 = q[3 * kTlasLdsNodes],
-                                 p4 = q[4 * kTlasLdsNodes], p5 = q[5 * kTlasLdsNodes], p6 = q[6 * kTlasLdsNodes];
+                if (TLAS_LDS && (cur_inst < 0 || node <= a.blas_k)) {
+                    const float2* q = tl + ((node - 1u) + (cur_inst < 0 ? 0u : a.lds_blas_base));
+                    const float2 p0 = q[0], p1 = q[kLdsPlaneNodes], p2 = q[2 * kLdsPlaneNodes], p3 = q[3 * kLdsPlaneNodes],
+                                 p4 = q[4 * kLdsPlaneNodes], p5 = q[5 * kLdsPlaneNodes], p6 = q[6 * kLdsPlaneNodes];
                     na = make_float4(p0.x, p0.y, p1.x, p1.y); nb = make_float4(p2.x, p2.y, p3.x, p3.y); nc = make_float4(p4.x, p4.y, p5.x, p5.y);
                     ch = u2v{__float_as_uint(p6.x), __float_as_uint(p6.y)};
                 } else {
@@ -410,7 +412,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             } else if (is_entry) {
                 float4 m0, m1, m2;
                 u4v m3;
-                if (TLAS_LDS) cur_inst = (int)__float_as_uint(tl[6 * kTlasLdsNodes + (node - 1u)].y);  // child1
+                if (TLAS_LDS) cur_inst = (int)__float_as_uint(tl[6 * kLdsPlaneNodes + (node - 1u)].y);  // child1
                 else cur_inst = (int)__builtin_amdgcn_raw_buffer_load_b32(nrs1, (cur_off + node) << 6, 52, 0);
                 if (INST_LDS) {
                     const float4* q = il + 4 * cur_inst;

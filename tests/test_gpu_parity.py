@@ -253,6 +253,39 @@ def test_trace_parity_c3_and_shadow(rc, oracle, kernel):
     assert_hits_equal(t.trace(bounce), o.trace(bounce, nthreads=8), "C4 bounce")
 
 
+@pytest.mark.parametrize("n_tris,n_inst", [(2, 1), (3, 4), (40, 1), (700, 1), (5000, 3), (5000, 200), (20000, 256)])
+def test_blas_top_renumbering(rc, oracle, n_tris, n_inst):
+    """Single-BLAS scenes: the traversal copy renumbers the BLAS's top internal nodes breadth-first (kernel 5 reads them from LDS).
+    Every kernel walks that copy, so all of them must still agree with the oracle bit for bit; the exported arrays keep the
+    reference numbering; a second BLAS switches the renumbering off."""
+    sc = rc.scenes
+    verts = sc.random_triangles(n_tris, 31 + n_tris, lo=-0.5, hi=0.5, edge=0.3 if n_tris < 100 else 0.08)
+    xf, _, _ = sc.lattice_transforms(8, 8, 4, 1.1, 5)
+    cfg = {"blas": [(verts, None)], "instances": [(1, xf[:n_inst], np.arange(n_inst, dtype=np.uint32))]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    n_int = len(o.blas_prims) - 1
+    assert t.get_option("blas_top_k") == min(n_int, 576 - (2 * n_inst - 1))
+    assert t.adapt().all_blas_nodes.tobytes() == o.blas_nodes.tobytes()
+    wb = o.world_bound
+    rays = random_rays(rc, 150_000, n_tris, wb[:3], wb[3:])
+    want, want_any = o.trace(rays, nthreads=8), o.trace(rays, mode="any", nthreads=8)
+    assert want["hit"].any()
+    for kernel, top in ((5, 1), (5, 0), (0, 1), (1, 1), (3, 1), (4, 1)):
+        t.set_option("kernel", kernel)
+        t.set_option("blas_top", top)
+        assert_hits_equal(t.trace(rays), want, f"kernel {kernel} blas_top {top} closest")
+        assert_hits_equal(t.trace(rays, mode="any"), want_any, f"kernel {kernel} blas_top {top} any")
+    t.set_option("blas_top", 1)
+    t.set_option("kernel", 5)
+    h2 = t.push_instances(t.add_geometry(sc.fan_sphere(12, 7)))  # a second BLAS: plain copy again
+    t.sync()
+    assert t.get_option("blas_top_k") == 0
+    o.add_instance(o.add_blas(sc.fan_sphere(12, 7)))
+    o.build()
+    assert_hits_equal(t.trace(rays), o.trace(rays, nthreads=8), "two BLASes")
+    t.free()
+
+
 def test_trace_edge_cases(rc, oracle):
     """Axis-parallel rays, -0 directions, rays in the plane of a triangle (det == 0 => NaN-t 'hit',
     SURVEY.md Appendix A), duplicate instances (exact t ties: the later visit wins), t_max culling."""
