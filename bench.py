@@ -335,7 +335,7 @@ def main():
                          # the scene is L1/L2 resident (see traffic), so the physical ceiling is the 64-byte gather rate of the vector-memory / LDS
                          # paths, not HBM: 64 B per node or instance-record visit against the 11.7 TB/s measured by tools/td_probe.hip
                          "cache_gather": {"achieved_GBs": round((node_f + inst_f) * 64.0 * n / (launch_ms * 1e-3) / 1e9, 1), "vector_memory_ceiling_GBs": 11700.0,
-                                          "note": "the default kernel reads the TLAS half of the visits from LDS, which is how it can pass the vector-memory-only gather ceiling"}},
+                                          "note": "the default kernel reads the TLAS half of the visits, and the top of the single BLAS, from LDS, which is how it can pass the vector-memory-only gather ceiling"}},
             "cpu_baseline": cpu_baseline,
             "extras": extras,
         }
