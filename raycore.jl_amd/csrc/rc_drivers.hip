@@ -78,6 +78,16 @@ __global__ __launch_bounds__(kBlock, 6) void k_illumination(SceneView v, Persist
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     phased_trace<false, kLdsStack, false>(v, p, lds_stack, GridSource{g, ray_begin}, HistogramSink{v.inst, v.prims, v.n_prims, counts});
 }
+// Small top level (<= kTlasLdsNodes nodes): the shape of trace kernel 5 -- two 768-thread workgroups per CU, TLAS (and a single BLAS's
+// top nodes) in LDS planes.
+__global__ __launch_bounds__(kMidBlock, 6) void k_illumination_lds(SceneView v, PersistArgs p, GridParams g, uint64_t ray_begin, float* counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
+    stage_node_planes<kMidBlock>(tl, v, p.blas_k, p.lds_blas_base);
+    __syncthreads();
+    phased_trace<false, kMidStack, false, GridSource, HistogramSink, kMidBlock, true, false>(v, p, reinterpret_cast<uint32_t*>(smem), GridSource{g, ray_begin},
+                                                                                             HistogramSink{v.inst, v.prims, v.n_prims, counts}, tl, nullptr);
+}
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------------
 __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -207,6 +217,17 @@ __global__ __launch_bounds__(kBlock, 6) void k_view_factors(SceneView v, Persist
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     phased_trace<false, kLdsStack, false>(v, p, lds_stack, ViewFactorSource{v.prims, k0, k1, src_begin, ray_begin, n_ray},
                                           ViewFactorSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags});
+}
+__global__ __launch_bounds__(kMidBlock, 6) void k_view_factors_lds(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin,
+                                                                    uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
+                                                                    uint64_t col_stride, uint32_t row_offset, uint32_t flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
+    stage_node_planes<kMidBlock>(tl, v, p.blas_k, p.lds_blas_base);
+    __syncthreads();
+    phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorSink, kMidBlock, true, false>(
+        v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, k0, k1, src_begin, ray_begin, n_ray},
+        ViewFactorSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags}, tl, nullptr);
 }
 
 __global__ void k_view_factor_rays(SceneView v, uint32_t k0, uint32_t k1, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* out) {
@@ -360,11 +381,21 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
     if (ray_end <= ray_begin) return;
     check_buffer_range(s);
     GridParams g = grid_params(s, viewdir, grid);
-    uint32_t blocks = rc_persistent_blocks(s, ray_end - ray_begin);
+    const bool lds = rc_lds_driver_ok(s);
+    const uint32_t bs = lds ? (uint32_t)kMidBlock : (uint32_t)kBlock;
+    uint32_t blocks = lds ? rc_lds_driver_blocks(s, ray_end - ray_begin) : rc_persistent_blocks(s, ray_end - ray_begin);
     rc_prepare_launch(s, stream);
-    SceneView v = rc_scene_view(s, blocks * kBlock);
-    PersistArgs p = rc_persist_args(s, ray_end - ray_begin, blocks * kBlock);
+    SceneView v = rc_scene_view(s, blocks * bs);
+    PersistArgs p = rc_persist_args(s, ray_end - ray_begin, blocks * bs);
     RC_HIP(hipEventRecord(s->ev0, stream));
+    if (lds) {
+        rc_lds_driver_args(s, p);
+        if (!s->lds_attr_set[4]) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_illumination_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
+            s->lds_attr_set[4] = true;
+        }
+        hipLaunchKernelGGL(k_illumination_lds, dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, v, p, g, ray_begin, d_counts);
+    } else
     hipLaunchKernelGGL(k_illumination, dim3(blocks), dim3(kBlock), 0, stream, v, p, g, ray_begin, d_counts);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
@@ -378,11 +409,22 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     if (src_begin >= src_end || ray_begin >= ray_end) return;
     check_buffer_range(s);
     uint64_t total = (uint64_t)(src_end - src_begin) * (ray_end - ray_begin);
-    uint32_t blocks = rc_persistent_blocks(s, total);
+    const bool lds = rc_lds_driver_ok(s);
+    const uint32_t bs = lds ? (uint32_t)kMidBlock : (uint32_t)kBlock;
+    uint32_t blocks = lds ? rc_lds_driver_blocks(s, total) : rc_persistent_blocks(s, total);
     rc_prepare_launch(s, stream);
-    SceneView v = rc_scene_view(s, blocks * kBlock);
-    PersistArgs p = rc_persist_args(s, total, blocks * kBlock);
+    SceneView v = rc_scene_view(s, blocks * bs);
+    PersistArgs p = rc_persist_args(s, total, blocks * bs);
     RC_HIP(hipEventRecord(s->ev0, stream));
+    if (lds) {
+        rc_lds_driver_args(s, p);
+        if (!s->lds_attr_set[5]) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_view_factors_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
+            s->lds_attr_set[5] = true;
+        }
+        hipLaunchKernelGGL(k_view_factors_lds, dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, v, p, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
+                           ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags);
+    } else
     hipLaunchKernelGGL(k_view_factors, dim3(blocks), dim3(kBlock), 0, stream, v, p, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
                        ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags);
     RC_HIP(hipEventRecord(s->ev1, stream));

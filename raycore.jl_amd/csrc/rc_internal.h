@@ -155,7 +155,7 @@ struct rc_scene {
     DevBuf<uint32_t> collide_counts;  // collide_instances' per-leaf counts / prefix sums (the reference's `cache`)
     DevBuf<uint2> contact_stage;
 
-    bool lds_attr_set[4] = {false, false, false, false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any)
+    bool lds_attr_set[6] = {false, false, false, false, false, false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any), illumination, view factors
 
     TraceOptions opt;
 };

@@ -115,7 +115,6 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
 // (28 KiB) + the instance records (16 KiB) = 140 KiB of the CU's 160 KiB LDS.  Used when the scene has <= 256 instances.
 constexpr int kBigBlock = 1024;
 constexpr size_t kBigStackBytes = (size_t)kLdsStack * kBigBlock * 4;
-constexpr size_t kTlasPlaneBytes = (size_t)7 * kLdsPlaneNodes * sizeof(float2);
 constexpr size_t kBigLdsBytes = kBigStackBytes + kTlasPlaneBytes + (size_t)kTlasLdsInst * 64;
 
 // BLOCK threads per workgroup, LDS_N stack entries per lane in LDS, INST_LDS: instance records staged too.
@@ -128,23 +127,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem);
     float2* tl = reinterpret_cast<float2*>(smem + stack_bytes);
     float4* il = reinterpret_cast<float4*>(smem + stack_bytes + kTlasPlaneBytes);
-    const RcNode* tnodes = a.v.blas_nodes + a.v.tlas_off;
-    for (uint32_t i = threadIdx.x; i < a.v.n_tlas_nodes * 7u; i += BLOCK) {
-        const uint32_t nd = i / 7u, p = i % 7u;
-        tl[p * kLdsPlaneNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
-    }
-    for (uint32_t i = threadIdx.x; i < a.blas_k * 7u; i += BLOCK) {  // single-BLAS scene: its top internal nodes sit first in the traversal copy
-        const uint32_t nd = i / 7u, p = i % 7u;
-        tl[p * kLdsPlaneNodes + a.lds_blas_base + nd] = reinterpret_cast<const float2*>(a.v.blas_nodes + nd)[p];
-    }
+    stage_node_planes<BLOCK>(tl, a.v, a.blas_k, a.lds_blas_base);
     if (INST_LDS)
         for (uint32_t i = threadIdx.x; i < a.v.n_inst * 4u; i += BLOCK) il[i] = reinterpret_cast<const float4*>(a.v.inst)[i];
     __syncthreads();
     PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base};
     phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, INST_LDS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, tl, il);
 }
-constexpr int kMidBlock = 768, kMidStack = 16;
-constexpr size_t kMidLdsBytes = (size_t)kMidStack * kMidBlock * 4 + kTlasPlaneBytes;
 
 // ---- kernel 2: persistent waves + per-wave path scheduling --------------------------------------------
 // Kernel 1 runs the reference's three-way loop body as written, so a wave executes the interior-node,
@@ -422,6 +411,17 @@ rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_th
     p.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
     p.tail_div = (uint32_t)((total_threads / 64) * (uint64_t)s->opt.tail);
     return p;
+}
+
+// The drivers' LDS variants (768-thread workgroups, node planes) apply under the same conditions as trace kernel 5.
+bool rc_lds_driver_ok(rc_scene* s) {
+    return s->opt.kernel != 3 && s->n_tlas_nodes > 0 && s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes && (uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u < (1ull << 32);
+}
+uint32_t rc_lds_driver_blocks(rc_scene* s, uint64_t n_items) {
+    return (uint32_t)std::min<uint64_t>((n_items + kMidBlock - 1) / kMidBlock, (uint64_t)s->n_cus * 2);
+}
+void rc_lds_driver_args(rc_scene* s, rc::PersistArgs& p) {
+    if (s->opt.blas_top) { p.blas_k = s->blas_top_k; p.lds_blas_base = s->n_tlas_nodes; }
 }
 
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items) {

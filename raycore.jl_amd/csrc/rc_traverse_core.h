@@ -297,6 +297,25 @@ struct PersistArgs {
 // visits and instance entries then never touch the vector-memory path, which is what bounds the kernel.
 // kTlasLdsNodes, kTlasLdsInst, kLdsPlaneNodes: rc_internal.h (the TLAS build needs them too)
 
+// Shape of the two-workgroups-per-CU LDS kernels (trace kernel 5 and the LDS variants of the drivers): 768 threads, 16-entry LDS lane
+// stacks (48 KiB) + the node planes (31.5 KiB) = 79.5 KiB per workgroup.
+constexpr int kMidBlock = 768, kMidStack = 16;
+constexpr size_t kTlasPlaneBytes = (size_t)7 * kLdsPlaneNodes * sizeof(float2);
+constexpr size_t kMidLdsBytes = (size_t)kMidStack * kMidBlock * 4 + kTlasPlaneBytes;
+// Fill the planes: TLAS nodes at entries 0.., then (single-BLAS scenes) BLAS nodes 1..blas_k of the traversal copy at lds_blas_base...
+template <int BLOCK>
+__device__ inline void stage_node_planes(float2* tl, const SceneView& v, uint32_t blas_k, uint32_t lds_blas_base) {
+    const RcNode* tnodes = v.blas_nodes + v.tlas_off;
+    for (uint32_t i = threadIdx.x; i < v.n_tlas_nodes * 7u; i += BLOCK) {
+        const uint32_t nd = i / 7u, p = i % 7u;
+        tl[p * kLdsPlaneNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
+    }
+    for (uint32_t i = threadIdx.x; i < blas_k * 7u; i += BLOCK) {  // single-BLAS scene: its top internal nodes sit first in the traversal copy
+        const uint32_t nd = i / 7u, p = i % 7u;
+        tl[p * kLdsPlaneNodes + lds_blas_base + nd] = reinterpret_cast<const float2*>(v.blas_nodes + nd)[p];
+    }
+}
+
 template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS>
 __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
                                     const float2* tl = nullptr, const float4* il = nullptr) {
@@ -529,3 +548,6 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads);  // rc_traverse.hip
 rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads);
+bool rc_lds_driver_ok(rc_scene* s);
+uint32_t rc_lds_driver_blocks(rc_scene* s, uint64_t n_items);
+void rc_lds_driver_args(rc_scene* s, rc::PersistArgs& p);

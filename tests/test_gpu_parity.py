@@ -501,6 +501,9 @@ def test_ray_grid_and_illumination_parity(rc, oracle):
         assert rays.tobytes() == o.ray_grid(cfg["viewdir"], grid).tobytes()
         got, want = rc.get_illumination(t, cfg["viewdir"], grid), o.get_illumination(cfg["viewdir"], grid, nthreads=8)
         assert got.dtype == np.float32 and np.array_equal(got, want)
+        t.set_option("kernel", 3)  # the 256-thread driver kernel without LDS node planes (what large top levels get)
+        assert np.array_equal(rc.get_illumination(t, cfg["viewdir"], grid), want)
+        t.set_option("kernel", -1)
         h = t.trace(rays)
         metas = t.adapt().all_blas_prims["meta"][h["primitive_id"][h["hit"] == 1]]
         assert got.sum() == np.count_nonzero(metas <= len(got))  # metadata outside 1..N is dropped (src/kernels.jl:123)
@@ -558,6 +561,9 @@ def test_view_factors_parity(rc, oracle):
     want = o.view_factors(256, seed=1234, nthreads=8)
     assert got.shape == (n, n) and got.dtype == np.uint32
     assert np.array_equal(got, want)
+    t.set_option("kernel", 3)  # the 256-thread driver kernel without LDS node planes
+    assert np.array_equal(rc.view_factors(t, rays_per_triangle=256, seed=1234), want)
+    t.set_option("kernel", -1)
     assert got.sum() > 0 and np.all(np.diag(got) == 0)
     assert np.all(got.sum(axis=1) <= 256)
     # sharding independence: two half-jobs accumulate to the whole (Philox keyed by (src, ray))
