@@ -760,12 +760,12 @@ void rc_build_tlas(rc_scene* s) {
     if (nb == 1 && s->opt.blas_top && n > 0 && 2 * n - 1 <= (uint32_t)rc::kTlasLdsNodes && s->blas[0].n_prims >= 2) {
         const uint32_t n_leaves = s->blas[0].n_prims, n_int = n_leaves - 1, room = (uint32_t)rc::kLdsPlaneNodes - (2 * n - 1);
         s->blas_top_k = n_int < room ? n_int : room;
-        s->keys_a.reserve(n_int);
-        hipLaunchKernelGGL(k_iota1, dim3(grid_for(n_int)), dim3(kBlock), 0, s->stream, s->keys_a.p, n_int);
-        hipLaunchKernelGGL(k_top_remap, dim3(1), dim3(kTopBlock), 0, s->stream, s->blas[0].nodes.p, n_leaves, s->blas_top_k, s->keys_a.p);
+        s->top_remap.reserve(n_int);
+        hipLaunchKernelGGL(k_iota1, dim3(grid_for(n_int)), dim3(kBlock), 0, s->stream, s->top_remap.p, n_int);
+        hipLaunchKernelGGL(k_top_remap, dim3(1), dim3(kTopBlock), 0, s->stream, s->blas[0].nodes.p, n_leaves, s->blas_top_k, s->top_remap.p);
     }
     for (uint32_t i = 0; i < nb; ++i) {
-        if (s->blas_top_k) hipLaunchKernelGGL(k_pack_nodes_remap, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes, s->blas[i].n_prims, s->keys_a.p);
+        if (s->blas_top_k) hipLaunchKernelGGL(k_pack_nodes_remap, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes, s->blas[i].n_prims, s->top_remap.p);
         else hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes);
         RC_HIP(hipMemcpyAsync(s->flat_prims.p + s->descs[i].primitives_offset, s->blas[i].prims.p, sizeof(RcPrim) * s->blas[i].n_prims, hipMemcpyDeviceToDevice, s->stream));
     }

@@ -117,6 +117,7 @@ struct rc_scene {
     uint32_t n_static_instances = 0;
     DevBuf<RcNode> flat_nodes;
     uint32_t n_flat_nodes = 0;
+    DevBuf<uint32_t> top_remap;        // old -> new internal node index of that renumbering (scratch of rc_build_tlas)
     uint32_t blas_top_k = 0;           // single-BLAS scene: internal nodes 1..blas_top_k of the traversal copy are the tree's top in breadth-first order
     DevBuf<RcPrim> flat_prims;
     uint32_t n_flat_prims = 0;
