@@ -758,7 +758,7 @@ void rc_build_tlas(rc_scene* s) {
     // One BLAS and a TLAS small enough for the LDS kernel: the BLAS's top internal nodes go to the front of the traversal copy
     s->blas_top_k = 0;
     if (nb == 1 && s->opt.blas_top && n > 0 && 2 * n - 1 <= (uint32_t)rc::kTlasLdsNodes && s->blas[0].n_prims >= 2) {
-        const uint32_t n_leaves = s->blas[0].n_prims, n_int = n_leaves - 1, room = (uint32_t)rc::kLdsPlaneNodes - (2 * n - 1);
+        const uint32_t n_leaves = s->blas[0].n_prims, n_int = n_leaves - 1, room = (uint32_t)rc::kLdsPlaneNodes - (n - 1);  // the planes hold the TLAS's n - 1 interior nodes first
         s->blas_top_k = n_int < room ? n_int : room;
         s->top_remap.reserve(n_int);
         hipLaunchKernelGGL(k_iota1, dim3(grid_for(n_int)), dim3(kBlock), 0, s->stream, s->top_remap.p, n_int);

@@ -82,11 +82,11 @@ __global__ __launch_bounds__(kBlock, 6) void k_illumination(SceneView v, Persist
 // top nodes) in LDS planes.
 __global__ __launch_bounds__(kMidBlock, 6) void k_illumination_lds(SceneView v, PersistArgs p, GridParams g, uint64_t ray_begin, float* counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2* tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
-    stage_node_planes<kMidBlock>(tl, v, p.blas_k, p.lds_blas_base);
+    const LdsTop top(smem + (size_t)kMidStack * kMidBlock * 4);
+    stage_lds_top<kMidBlock>(top, v, p.blas_k, p.lds_blas_base);
     __syncthreads();
-    phased_trace<false, kMidStack, false, GridSource, HistogramSink, kMidBlock, true, false>(v, p, reinterpret_cast<uint32_t*>(smem), GridSource{g, ray_begin},
-                                                                                             HistogramSink{v.inst, v.prims, v.n_prims, counts}, tl, nullptr);
+    phased_trace<false, kMidStack, false, GridSource, HistogramSink, kMidBlock, true, true>(v, p, reinterpret_cast<uint32_t*>(smem), GridSource{g, ray_begin},
+                                                                                            HistogramSink{v.inst, v.prims, v.n_prims, counts}, top);
 }
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------------
@@ -222,12 +222,12 @@ __global__ __launch_bounds__(kMidBlock, 6) void k_view_factors_lds(SceneView v, 
                                                                     uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
                                                                     uint64_t col_stride, uint32_t row_offset, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2* tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
-    stage_node_planes<kMidBlock>(tl, v, p.blas_k, p.lds_blas_base);
+    const LdsTop top(smem + (size_t)kMidStack * kMidBlock * 4);
+    stage_lds_top<kMidBlock>(top, v, p.blas_k, p.lds_blas_base);
     __syncthreads();
-    phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorSink, kMidBlock, true, false>(
+    phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorSink, kMidBlock, true, true>(
         v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, k0, k1, src_begin, ray_begin, n_ray},
-        ViewFactorSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags}, tl, nullptr);
+        ViewFactorSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags}, top);
 }
 
 __global__ void k_view_factor_rays(SceneView v, uint32_t k0, uint32_t k1, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* out) {

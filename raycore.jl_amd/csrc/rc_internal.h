@@ -71,13 +71,16 @@ struct HandleRange {
 };
 
 namespace rc {
-constexpr int kTlasLdsNodes = 512;    // largest TLAS (nodes) the LDS kernels take
+constexpr int kTlasLdsNodes = 511;    // largest TLAS (nodes) the LDS kernels take: kTlasLdsInst instances
 constexpr int kTlasLdsInst = 256;
-// The planes hold kLdsPlaneNodes entries: the TLAS first, then -- in a scene with a single BLAS -- the BLAS's top `blas_k` internal
-// nodes, which rc_build_tlas renumbers to 1..blas_k in breadth-first order in the traversal copy (a private permutation of internal
-// node indices: visit order, tests and results are untouched, leaves keep their indices).  On C3 the top 65 of 4095 internal nodes
-// take 52 % of the BLAS-level interior visits.
-constexpr int kLdsPlaneNodes = 576;
+// What those kernels keep in LDS behind the lane stacks (rc_traverse_core.h, stage_lds_top):
+//  * node planes, kLdsPlaneNodes entries of seven float2 each: the TLAS's interior nodes 1..n-1 (its leaves are never fetched as
+//    nodes -- their boxes were tested in the parent), then, in a scene with a single BLAS, that BLAS's top `blas_k` internal nodes,
+//    which rc_build_tlas renumbers to 1..blas_k in breadth-first order in the traversal copy (a private permutation of internal
+//    node indices: visit order, tests and results are untouched, leaves keep their indices);
+//  * the TLAS leaf -> instance index table (kTlasLdsInst words);
+//  * the instance records as seven float2 planes of kTlasLdsInst entries (inverse transform, nodes offset, leaf count).
+constexpr int kLdsPlaneNodes = 310;
 }  // namespace rc
 
 struct TraceOptions {

@@ -110,29 +110,23 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
     }
 }
 
-// ---- kernel 4: kernel 3 with the whole top level staged in LDS ----------------------------------------------------
-// One 1024-thread workgroup per CU (16 waves): 96 KiB of lane stacks + the packed TLAS nodes as seven float2 planes
-// (28 KiB) + the instance records (16 KiB) = 140 KiB of the CU's 160 KiB LDS.  Used when the scene has <= 256 instances.
+// ---- kernels 4 / 5: kernel 3 with the top level staged in LDS (LdsTop, rc_traverse_core.h) -------------------------------
+// kernel 4 = <1024, 24>: one 1024-thread workgroup per CU (16 waves), 96 KiB of lane stacks; kernel 5 = <768, 16>: two workgroups per
+// CU keep the 24 waves per CU of kernel 3 (the shallower LDS stack costs < 2 %, measured).  Used when the scene has <= 256 instances.
 constexpr int kBigBlock = 1024;
 constexpr size_t kBigStackBytes = (size_t)kLdsStack * kBigBlock * 4;
-constexpr size_t kBigLdsBytes = kBigStackBytes + kTlasPlaneBytes + (size_t)kTlasLdsInst * 64;
+constexpr size_t kBigLdsBytes = kBigStackBytes + kLdsTopBytes;
 
-// BLOCK threads per workgroup, LDS_N stack entries per lane in LDS, INST_LDS: instance records staged too.
-// kernel 4 = <1024, 24, true> (one workgroup per CU); kernel 5 = <768, 16, false>: two workgroups per CU keep the 24 waves
-// per CU of kernel 3 (the shallower LDS stack costs < 2 %, measured) while the TLAS still comes from LDS.
-template <bool ANY, int BLOCK, int LDS_N, bool INST_LDS, int MINW>
+template <bool ANY, int BLOCK, int LDS_N, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr size_t stack_bytes = (size_t)LDS_N * BLOCK * 4;
     uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem);
-    float2* tl = reinterpret_cast<float2*>(smem + stack_bytes);
-    float4* il = reinterpret_cast<float4*>(smem + stack_bytes + kTlasPlaneBytes);
-    stage_node_planes<BLOCK>(tl, a.v, a.blas_k, a.lds_blas_base);
-    if (INST_LDS)
-        for (uint32_t i = threadIdx.x; i < a.v.n_inst * 4u; i += BLOCK) il[i] = reinterpret_cast<const float4*>(a.v.inst)[i];
+    const LdsTop top(smem + stack_bytes);
+    if (a.v.n_tlas_nodes) stage_lds_top<BLOCK>(top, a.v, a.blas_k, a.lds_blas_base);
     __syncthreads();
     PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base};
-    phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, INST_LDS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, tl, il);
+    phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
 // ---- kernel 2: persistent waves + per-wave path scheduling --------------------------------------------
@@ -421,7 +415,7 @@ uint32_t rc_lds_driver_blocks(rc_scene* s, uint64_t n_items) {
     return (uint32_t)std::min<uint64_t>((n_items + kMidBlock - 1) / kMidBlock, (uint64_t)s->n_cus * 2);
 }
 void rc_lds_driver_args(rc_scene* s, rc::PersistArgs& p) {
-    if (s->opt.blas_top) { p.blas_k = s->blas_top_k; p.lds_blas_base = s->n_tlas_nodes; }
+    if (s->opt.blas_top) { p.blas_k = s->blas_top_k; p.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
 }
 
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items) {
@@ -439,17 +433,17 @@ static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hip
     if (s->opt.kernel == 4) {
         bool& attr_set = s->lds_attr_set[ANY ? 1 : 0];  // per scene = per device: the attribute belongs to the function on one device
         if (!attr_set) {
-            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kBigBlock, kLdsStack, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes));
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kBigBlock, kLdsStack, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_trace_phased_lds<ANY, kBigBlock, kLdsStack, true, 4>), dim3(blocks), dim3(kBigBlock), kBigLdsBytes, stream, a);
+        hipLaunchKernelGGL((k_trace_phased_lds<ANY, kBigBlock, kLdsStack, 4>), dim3(blocks), dim3(kBigBlock), kBigLdsBytes, stream, a);
     } else if (s->opt.kernel == 5) {
         bool& attr_set = s->lds_attr_set[2 + (ANY ? 1 : 0)];
         if (!attr_set) {
-            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, false, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, false, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
+        hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
     } else if (s->opt.kernel == 3) {
         if (stats) hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else if (lds == 16) hipLaunchKernelGGL((k_trace_phased<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
@@ -508,7 +502,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.sched_thr = (int)s->opt.sched_thr;
     a.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
     a.tail_div = (uint32_t)((total_threads / 64) * (uint64_t)s->opt.tail);
-    if (s->opt.kernel == 5 && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = s->n_tlas_nodes; }
+    if ((s->opt.kernel == 5 || s->opt.kernel == 4) && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
     RC_HIP(hipEventRecord(s->ev0, stream));
     if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
     s->opt.kernel = saved_kernel;

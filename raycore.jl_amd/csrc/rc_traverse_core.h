@@ -291,34 +291,58 @@ struct PersistArgs {
     uint32_t lds_blas_base = 0;
 };
 
-// TLAS_LDS: the block has staged the whole top level in LDS before the call (see k_trace_phased_lds): `tl` holds the packed
-// TLAS nodes as seven float2 planes of kTlasLdsNodes entries (dword pairs 0-1, 2-3, ... 12-13 of each node; a plane read is
-// one ds_read_b64 with lane addresses 8 bytes apart per node), `il` the instance records (4 x float4 each).  TLAS-level
-// visits and instance entries then never touch the vector-memory path, which is what bounds the kernel.
+// TLAS_LDS / INST_LDS: the block has staged the top level in LDS before the call (LdsTop below; layout and sizes in rc_internal.h):
+// packed nodes as seven float2 planes (dword pairs 0-1, 2-3, ... 12-13 of each node; a plane read is one ds_read_b64 with lane
+// addresses 8 bytes apart per node), the TLAS leaf -> instance table, and the instance records as float2 planes.  TLAS-level visits
+// and instance entries then never touch the vector-memory path, which is what bounds the kernel.
 // kTlasLdsNodes, kTlasLdsInst, kLdsPlaneNodes: rc_internal.h (the TLAS build needs them too)
 
 // Shape of the two-workgroups-per-CU LDS kernels (trace kernel 5 and the LDS variants of the drivers): 768 threads, 16-entry LDS lane
-// stacks (48 KiB) + the node planes (31.5 KiB) = 79.5 KiB per workgroup.
+// stacks (48 KiB) + node planes (17 KiB) + leaf table (1 KiB) + instance planes (14 KiB) = 79.95 KiB per workgroup.
 constexpr int kMidBlock = 768, kMidStack = 16;
-constexpr size_t kTlasPlaneBytes = (size_t)7 * kLdsPlaneNodes * sizeof(float2);
-constexpr size_t kMidLdsBytes = (size_t)kMidStack * kMidBlock * 4 + kTlasPlaneBytes;
-// Fill the planes: TLAS nodes at entries 0.., then (single-BLAS scenes) BLAS nodes 1..blas_k of the traversal copy at lds_blas_base...
+constexpr size_t kNodePlaneBytes = (size_t)7 * kLdsPlaneNodes * sizeof(float2);
+constexpr size_t kLeafTableBytes = (size_t)kTlasLdsInst * sizeof(uint32_t);
+constexpr size_t kInstPlaneBytes = (size_t)7 * kTlasLdsInst * sizeof(float2);
+constexpr size_t kLdsTopBytes = kNodePlaneBytes + kLeafTableBytes + kInstPlaneBytes;
+constexpr size_t kMidLdsBytes = (size_t)kMidStack * kMidBlock * 4 + kLdsTopBytes;
+struct LdsTop {
+    float2* tl;    // node planes: plane p of entry e at tl[p * kLdsPlaneNodes + e]
+    uint32_t* lt;  // lt[j] = instance index of TLAS leaf n - 1 + j + 1 (node index n + j)
+    float2* il;    // instance planes: plane p of instance i at il[p * kTlasLdsInst + i]; planes 0-5 = inverse transform, 6 = (nodes offset, leaf count)
+    __device__ inline explicit LdsTop(unsigned char* base)
+        : tl(reinterpret_cast<float2*>(base)), lt(reinterpret_cast<uint32_t*>(base + kNodePlaneBytes)),
+          il(reinterpret_cast<float2*>(base + kNodePlaneBytes + kLeafTableBytes)) {}
+    __device__ inline LdsTop() : tl(nullptr), lt(nullptr), il(nullptr) {}
+};
+// Fill it (all threads of the workgroup; caller synchronises).  n_inst <= kTlasLdsInst, blas_k <= kLdsPlaneNodes - (n_inst - 1).
 template <int BLOCK>
-__device__ inline void stage_node_planes(float2* tl, const SceneView& v, uint32_t blas_k, uint32_t lds_blas_base) {
+__device__ inline void stage_lds_top(const LdsTop& t, const SceneView& v, uint32_t blas_k, uint32_t lds_blas_base) {
     const RcNode* tnodes = v.blas_nodes + v.tlas_off;
-    for (uint32_t i = threadIdx.x; i < v.n_tlas_nodes * 7u; i += BLOCK) {
+    const uint32_t n_inst = (v.n_tlas_nodes + 1u) >> 1;
+    for (uint32_t i = threadIdx.x; i < (n_inst - 1u) * 7u; i += BLOCK) {  // TLAS interior nodes 1..n-1
         const uint32_t nd = i / 7u, p = i % 7u;
-        tl[p * kLdsPlaneNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
+        t.tl[p * kLdsPlaneNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
     }
     for (uint32_t i = threadIdx.x; i < blas_k * 7u; i += BLOCK) {  // single-BLAS scene: its top internal nodes sit first in the traversal copy
         const uint32_t nd = i / 7u, p = i % 7u;
-        tl[p * kLdsPlaneNodes + lds_blas_base + nd] = reinterpret_cast<const float2*>(v.blas_nodes + nd)[p];
+        t.tl[p * kLdsPlaneNodes + lds_blas_base + nd] = reinterpret_cast<const float2*>(v.blas_nodes + nd)[p];
+    }
+    for (uint32_t j = threadIdx.x; j < n_inst; j += BLOCK)  // child1 word (dword 13) of leaf node n + j
+        t.lt[j] = reinterpret_cast<const uint32_t*>(tnodes + (n_inst - 1u + j))[13];
+    for (uint32_t i = threadIdx.x; i < v.n_inst * 7u; i += BLOCK) {
+        const uint32_t in = i / 7u, p = i % 7u;
+        const uint32_t* rec = reinterpret_cast<const uint32_t*>(v.inst + in);
+        const uint32_t a = p < 6u ? rec[2u * p] : rec[12], b = p < 6u ? rec[2u * p + 1u] : rec[15];
+        t.il[p * kTlasLdsInst + in] = make_float2(__uint_as_float(a), __uint_as_float(b));
     }
 }
 
 template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS>
 __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
-                                    const float2* tl = nullptr, const float4* il = nullptr) {
+                                    const LdsTop top = LdsTop()) {
+    const float2* const tl = top.tl;
+    const uint32_t* const lt = top.lt;
+    const float2* const il = top.il;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
     LaneStackT<LDS_N, BLOCK> st(lds_stack + threadIdx.x, av.overflow + gtid, av.total_threads, av.status);
     const int lane = threadIdx.x & 63;
@@ -431,13 +455,14 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             } else if (is_entry) {
                 float4 m0, m1, m2;
                 u4v m3;
-                if (TLAS_LDS) cur_inst = (int)__float_as_uint(tl[6 * kLdsPlaneNodes + (node - 1u)].y);  // child1
+                if (TLAS_LDS) cur_inst = (int)lt[node - n_level];  // leaf of sorted instance j is node n - 1 + j; its child1 word
                 else cur_inst = (int)__builtin_amdgcn_raw_buffer_load_b32(nrs1, (cur_off + node) << 6, 52, 0);
                 if (INST_LDS) {
-                    const float4* q = il + 4 * cur_inst;
-                    m0 = q[0]; m1 = q[1]; m2 = q[2];
-                    const float4 w = q[3];
-                    m3 = u4v{__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
+                    const float2* q = il + cur_inst;
+                    const float2 p0 = q[0], p1 = q[kTlasLdsInst], p2 = q[2 * kTlasLdsInst], p3 = q[3 * kTlasLdsInst],
+                                 p4 = q[4 * kTlasLdsInst], p5 = q[5 * kTlasLdsInst], p6 = q[6 * kTlasLdsInst];
+                    m0 = make_float4(p0.x, p0.y, p1.x, p1.y); m1 = make_float4(p2.x, p2.y, p3.x, p3.y); m2 = make_float4(p4.x, p4.y, p5.x, p5.y);
+                    m3 = u4v{__float_as_uint(p6.x), 0u, 0u, __float_as_uint(p6.y)};  // nodes offset, leaf count (the other two words are the sink's)
                 } else {
                     const uint32_t ioff = (uint32_t)cur_inst << 6;
                     m0 = buf_f4(irs, ioff); m1 = buf_f4(irs, ioff, 16); m2 = buf_f4(irs, ioff, 32);

@@ -264,7 +264,7 @@ def test_blas_top_renumbering(rc, oracle, n_tris, n_inst):
     cfg = {"blas": [(verts, None)], "instances": [(1, xf[:n_inst], np.arange(n_inst, dtype=np.uint32))]}
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
     n_int = len(o.blas_prims) - 1
-    assert t.get_option("blas_top_k") == min(n_int, 576 - (2 * n_inst - 1))
+    assert t.get_option("blas_top_k") == min(n_int, 310 - (n_inst - 1))
     assert t.adapt().all_blas_nodes.tobytes() == o.blas_nodes.tobytes()
     wb = o.world_bound
     rays = random_rays(rc, 150_000, n_tris, wb[:3], wb[3:])
