@@ -274,9 +274,6 @@ def main():
         if rank == 0:
             extras["view_factors_c5"] = vf
 
-    if not args.no_extras and args.backend == "nccl":
-        guarded_extra("view_factors", extra_view_factors)
-
     node_f, inst_f = C3_NODE_FETCHES_PER_RAY, C3_INST_ENTRIES_PER_RAY
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -328,23 +325,23 @@ def main():
             "config": {"workload": "C3: TLAS of 256 rotated/scaled instances of one 4096-triangle BLAS (1 048 576 triangles), "
                                    f"{n} pinhole primary rays per GPU per step, closest_hit",
                        "triangles": int(n_tris), "rays_per_step_per_gpu": n, "hit_fraction": round(hit_frac, 4),
-                       "kernel": {-1: "auto (phased persistent, TLAS in LDS)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased", 4: "phased + TLAS/instances in LDS", 5: "phased + TLAS in LDS"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
+                       "kernel": {-1: "auto (phased persistent, top level in LDS)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased", 4: "phased + top level in LDS, 1024-thread workgroups", 5: "phased + top level in LDS"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": {-1: "k_trace_phased_lds<false, 768, 16, false, 6>", 5: "k_trace_phased_lds<false, 768, 16, false, 6>", 3: "k_trace_phased<false, 24, 6, false>"}.get(t.get_option("kernel"), f"kernel option {t.get_option('kernel')}"), "avg_launch_ms": round(launch_ms, 4),
+                         "traffic": traffic, "kernel": {-1: "k_trace_phased_lds<false, 768, 16, 6>", 5: "k_trace_phased_lds<false, 768, 16, 6>", 3: "k_trace_phased<false, 24, 6, false>"}.get(t.get_option("kernel"), f"kernel option {t.get_option('kernel')}"), "avg_launch_ms": round(launch_ms, 4),
                          "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3),
                          # the scene is L1/L2 resident (see traffic), so the physical ceiling is the 64-byte gather rate of the vector-memory / LDS
                          # paths, not HBM: 64 B per node or instance-record visit against the 11.7 TB/s measured by tools/td_probe.hip
                          "cache_gather": {"achieved_GBs": round((node_f + inst_f) * 64.0 * n / (launch_ms * 1e-3) / 1e9, 1), "vector_memory_ceiling_GBs": 11700.0,
-                                          "note": "the default kernel reads the TLAS half of the visits, and the top of the single BLAS, from LDS, which is how it can pass the vector-memory-only gather ceiling"}},
+                                          "note": "the default kernel reads the TLAS half of the visits, the instance records and the top of the single BLAS from LDS, which is how it can pass the vector-memory-only gather ceiling"}},
             "cpu_baseline": cpu_baseline,
             "extras": extras,
         }
     else:
         out = None
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if out is not None:
+
+    def emit():
+        if out is None:
+            return
         # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit, AFTER the JSON line
         try:
             import ctypes
@@ -353,6 +350,28 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
+
+    if not args.no_extras and args.backend == "nccl":
+        # The view-factor extra is the only measurement with collectives in it.  It runs last, with the headline result already
+        # assembled, under a watchdog: if a rank fails inside a collective the others would wait for ever, and a hung extra must not
+        # cost the headline line -- every rank gives up together, rank 0 prints what it has.
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(300.0):
+                extras["view_factors_error"] = "timed out after 300 s (a rank left the collective sequence?)"
+                emit()
+                os._exit(0)
+
+        if world > 1:
+            threading.Thread(target=watchdog, daemon=True).start()
+        guarded_extra("view_factors", extra_view_factors)
+        finished.set()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    emit()
 
 
 if __name__ == "__main__":
