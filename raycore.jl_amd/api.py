@@ -363,10 +363,16 @@ class TLAS:
         check(lib().rc_get_option(self._h, name.encode(), C.byref(v)))
         return v.value
 
-    def trace(self, rays, mode="closest"):
-        """Batch closest_hit / any_hit: RAY_DT array in, HIT_DT array out (RTRay/RTHitResult, src/rt_transport.jl)."""
+    def trace(self, rays, mode="closest", out=None):
+        """Batch closest_hit / any_hit: RAY_DT array in, HIT_DT array out (RTRay/RTHitResult, src/rt_transport.jl).  `out` reuses a
+        HIT_DT array of the same length (a render loop saves the page faults of a fresh 32 B/ray array on every call)."""
         rays = _as_rays(rays)
-        hits = np.zeros(len(rays), dtype=HIT_DT)
+        if out is None:
+            hits = np.empty(len(rays), dtype=HIT_DT)  # every record is written by the library
+        else:
+            if out.dtype != HIT_DT or len(out) != len(rays) or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a contiguous HIT_DT array with one record per ray")
+            hits = out
         fn = lib().rc_trace_closest if mode == "closest" else lib().rc_trace_any
         check(fn(self._h, ptr(rays), ptr(hits), len(rays)))
         return hits

@@ -4,9 +4,12 @@
 // transforms_dirty flags, delete + compaction, sync! as the sole owner of the adapted (device) form.
 // All compute happens in the HIP kernels of rc_build.hip / rc_traverse.hip / rc_drivers.hip; there is no
 // CPU fallback -- without a device every entry point that needs one fails with RC_ERR_NO_DEVICE.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
+#include <sys/mman.h>
 
 #include "../../include/raycore_mi355x.h"
 #include "rc_internal.h"
@@ -520,6 +523,99 @@ int rc_export_prims(rc_scene* s, rc_prim* out, uint32_t capacity, uint32_t* coun
     });
 }
 
+// A freshly allocated output array has no pages yet; faulting them in one by one from inside the transfer threads (which contend for
+// the process's memory-map lock) is several times slower than asking the kernel for the whole range up front.
+static void populate_pages(void* p, size_t bytes) {
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23  // Linux 5.14+
+#endif
+    const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p) & ~(page - 1), b = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
+    (void)madvise(reinterpret_cast<void*>(a), b - a, MADV_POPULATE_WRITE);  // best effort: older kernels return EINVAL and the copies fault the pages in
+}
+
+// Host-buffer batches of three million rays or more (below that the chunking costs more than the overlap gains): upload, trace and download run as a three-stage pipeline over 512 Ki-ray chunks
+// (16 MiB each way), each transfer direction on its own host thread and non-blocking stream, so the two directions of the link and
+// the kernel overlap: a 4 M-ray batch takes about one direction's transfer time (2.4 ms at 56 GB/s) plus one chunk's latency instead
+// of upload + kernel + download back to back.  The chunks are traced by the same kernels, so the results do not change.
+static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
+    constexpr uint64_t kChunk = 1ull << 19;
+    const uint64_t n_chunks = (n + kChunk - 1) / kChunk;
+    s->ray_stage.reserve(n);
+    s->hit_stage.reserve(n);
+    populate_pages(hits, sizeof(RcHit) * n);
+    std::vector<hipEvent_t> ev_begin(n_chunks), ev_end(n_chunks);
+    std::vector<uint32_t*> status_words(n_chunks);
+    for (uint64_t c = 0; c < n_chunks; ++c) { RC_HIP(hipEventCreate(&ev_begin[c])); RC_HIP(hipEventCreate(&ev_end[c])); }
+    std::atomic<uint64_t> uploaded{0}, launched{0};
+    std::atomic<int> copy_error{0};
+    std::atomic<bool> abort_all{false};
+    auto span = [&](uint64_t c, uint64_t& off, uint64_t& cnt) { off = c * kChunk; cnt = std::min<uint64_t>(kChunk, n - off); };
+    std::thread up([&] {
+        hipStream_t st = nullptr;
+        hipError_t e = hipSetDevice(s->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (uint64_t c = 0; c < n_chunks && e == hipSuccess && !abort_all.load(); ++c) {
+            uint64_t off, cnt; span(c, off, cnt);
+            e = hipMemcpyAsync(s->ray_stage.p + off, reinterpret_cast<const RcRay*>(rays) + off, sizeof(RcRay) * cnt, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess) uploaded.store(c + 1, std::memory_order_release);
+        }
+        if (e != hipSuccess) { copy_error.store((int)e); abort_all.store(true); }
+        if (st) (void)hipStreamDestroy(st);
+    });
+    std::thread down([&] {
+        hipStream_t st = nullptr;
+        hipError_t e = hipSetDevice(s->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (uint64_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+            while (launched.load(std::memory_order_acquire) <= c && !abort_all.load()) std::this_thread::yield();
+            if (launched.load(std::memory_order_acquire) <= c) break;  // aborted before this chunk was launched
+            uint64_t off, cnt; span(c, off, cnt);
+            e = hipEventSynchronize(ev_end[c]);
+            if (e == hipSuccess) e = hipMemcpyAsync(reinterpret_cast<RcHit*>(hits) + off, s->hit_stage.p + off, sizeof(RcHit) * cnt, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+        if (e != hipSuccess) { copy_error.store((int)e); abort_all.store(true); }
+        if (st) (void)hipStreamDestroy(st);
+    });
+    std::string launch_error;
+    int launch_code = 0;
+    try {
+        for (uint64_t c = 0; c < n_chunks; ++c) {
+            while (uploaded.load(std::memory_order_acquire) <= c && !abort_all.load()) std::this_thread::yield();
+            if (abort_all.load()) break;
+            uint64_t off, cnt; span(c, off, cnt);
+            RC_HIP(hipEventRecord(ev_begin[c], s->stream));
+            rc_launch_trace(s, s->ray_stage.p + off, s->hit_stage.p + off, cnt, any, s->stream);
+            status_words[c] = rc_counter_slot(s) + 4;
+            RC_HIP(hipEventRecord(ev_end[c], s->stream));
+            launched.store(c + 1, std::memory_order_release);
+        }
+    } catch (const RcError& e) {
+        launch_error = e.what(); launch_code = e.code; abort_all.store(true);
+    }
+    up.join();
+    down.join();
+    (void)hipStreamSynchronize(s->stream);
+    float total_ms = 0.f;
+    uint32_t overflow = 0;
+    const uint64_t done = launched.load();
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        if (c < done) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev_begin[c], ev_end[c]) == hipSuccess) total_ms += ms;
+            uint32_t st = 0;
+            if (hipMemcpy(&st, status_words[c], 4, hipMemcpyDeviceToHost) == hipSuccess) overflow |= st;
+        }
+        (void)hipEventDestroy(ev_begin[c]); (void)hipEventDestroy(ev_end[c]);
+    }
+    s->last_ms = total_ms;  // the chunks' kernel time, transfers excluded (as for the single-launch path)
+    s->pipelined_ms = total_ms; s->pipelined_seq = s->launch_seq;
+    if (launch_code) throw RcError(launch_code, launch_error);
+    if (copy_error.load()) throw RcError(RC_ERR_HIP, std::string("host-buffer transfer failed: ") + hipGetErrorString((hipError_t)copy_error.load()));
+    if (overflow) throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels)");
+}
+
 static int trace_host(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
     return guarded([&] {
@@ -527,8 +623,10 @@ static int trace_host(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n,
         require_synced(s);
         if (n == 0) return;
         if (!rays || !hits) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
+        if (n >= 3 * (1ull << 20) && s->opt.host_pipeline) { trace_host_pipelined(s, rays, hits, n, any); return; }
         s->ray_stage.reserve(n);
         s->hit_stage.reserve(n);
+        if (n >= (1ull << 16)) populate_pages(hits, sizeof(RcHit) * n);
         RC_HIP(hipMemcpyAsync(s->ray_stage.p, rays, sizeof(RcRay) * n, hipMemcpyHostToDevice, s->stream));
         rc_launch_trace(s, s->ray_stage.p, s->hit_stage.p, n, any, s->stream);
         RC_HIP(hipMemcpyAsync(hits, s->hit_stage.p, sizeof(RcHit) * n, hipMemcpyDeviceToHost, s->stream));
@@ -826,6 +924,7 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "tail") s->opt.tail = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (k == "onesweep_min") s->opt.onesweep_min = value < 0 ? 0 : value;
     else if (k == "blas_top") s->opt.blas_top = value != 0;
+    else if (k == "host_pipeline") s->opt.host_pipeline = value != 0;
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
     return RC_OK;
@@ -841,6 +940,7 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "tail") *value = s->opt.tail;
     else if (k == "onesweep_min") *value = s->opt.onesweep_min;
     else if (k == "blas_top") *value = s->opt.blas_top;
+    else if (k == "host_pipeline") *value = s->opt.host_pipeline;
     else if (k == "blas_top_k") *value = s->blas_top_k;
     else if (k.rfind("stat", 0) == 0 && k.size() == 5 && ((k[4] >= '0' && k[4] <= '9') || (k[4] >= 'a' && k[4] <= 'f'))) {
         unsigned long long st[16] = {0};
@@ -947,6 +1047,7 @@ int rc_last_kernel_ms(rc_scene* s, float* ms) {
     if (!s || !ms) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {
         use_device(s);
+        if (s->pipelined_seq == s->launch_seq && s->launch_seq != 0) { *ms = s->pipelined_ms; return; }  // last call was a chunked host-buffer trace
         RC_HIP(hipEventSynchronize(s->ev1));
         RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
         *ms = s->last_ms;

@@ -93,6 +93,7 @@ struct TraceOptions {
     int64_t stats = 0;         // dev instrumentation (persistent kernels only)
     int64_t onesweep_min = 1000000;  // builds: key counts from here up are sorted by Onesweep radix passes, smaller ones by rocPRIM's merge sort (measured: 0.22 vs 0.25 ms at 250 k keys, 0.437 vs 0.425 ms at 1 M)
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
+    int64_t host_pipeline = 1; // host-buffer trace calls of >= 1 Mi rays overlap upload / trace / download in chunks
     int64_t tail = 1;          // phased kernels: claims shrink to remaining / (waves * tail) near the end of a batch (0 = fixed-size claims)
 };
 
@@ -102,6 +103,8 @@ struct rc_scene {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
+    float pipelined_ms = 0.f;          // kernel time of the last chunked host-buffer trace, valid while pipelined_seq == launch_seq
+    uint64_t pipelined_seq = 0;
 
     // mutable TLAS state (src/instanced-bvh.jl:261-310)
     std::vector<Blas> blas;

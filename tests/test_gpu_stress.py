@@ -275,3 +275,37 @@ def test_overlapping_launches_on_two_streams(rc):
     for k in (0, 1):
         got = d_hits[k].cpu().numpy().view(rc.HIT_DT)
         assert got.tobytes() == sets[k][1].tobytes(), f"stream {k}"
+
+
+def test_large_host_batches_are_chunked_and_identical(rc):
+    """Host-buffer trace calls of >= 3 Mi rays run as an upload / trace / download pipeline over 512 Ki-ray chunks (rc_capi.hip);
+    the chunked result, the single-launch result and the device-buffer result must be the same bytes, with and without `out=`."""
+    import torch
+    sc = rc.scenes
+    cfg = sc.config_c3()
+    t = rc.TLAS(0)
+    for verts, meta in cfg["blas"]:
+        t.add_geometry(verts, meta)
+    for b, xf, ids in cfg["instances"]:
+        t.push_instances(b, xf, ids)
+    t.sync()
+    rays = sc.c3_primary_rays(cfg, 1800, 1800)  # 3.24 M rays: seven chunks, the last one partial
+    assert len(rays) >= 3 * (1 << 20) and len(rays) % (1 << 19) != 0
+    for mode in ("closest", "any"):
+        t.set_option("host_pipeline", 1)
+        chunked = t.trace(rays, mode=mode)
+        assert t.last_kernel_ms() > 0
+        reuse = np.full(len(rays), 0xAB, dtype=np.uint8).repeat(32).view(rc.HIT_DT)
+        assert t.trace(rays, mode=mode, out=reuse) is reuse
+        t.set_option("host_pipeline", 0)
+        single = t.trace(rays, mode=mode)
+        d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+        d_hits = torch.empty(len(rays) * 32, dtype=torch.uint8, device="cuda")
+        t.trace_device(d_rays.data_ptr(), d_hits.data_ptr(), len(rays), mode=mode)
+        torch.cuda.synchronize()
+        dev = d_hits.cpu().numpy().view(rc.HIT_DT)
+        assert chunked.tobytes() == single.tobytes() == dev.tobytes() == reuse.tobytes(), mode
+        assert 0 < int(chunked["hit"].sum()) < len(rays)
+    with pytest.raises(ValueError):
+        t.trace(rays, out=np.zeros(5, dtype=rc.HIT_DT))
+    t.free()
