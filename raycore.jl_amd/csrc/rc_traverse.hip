@@ -12,7 +12,8 @@
 // with a global spill area for the rare deep path, persistent waves that refill finished lanes from a global ray
 // counter (ballot + mbcnt prefix sums), and phase-structured execution so a wave only issues the block its lanes
 // actually need.  Kernel variants (rc_set_option "kernel"): 0 simple, 1 persistent, 2 voted scheduling, 3 phased
-// (core in rc_traverse_core.h), 4 / 5 phased with the TLAS staged in LDS (5 = default when the TLAS fits).  All return identical results.
+// (core in rc_traverse_core.h), 4 / 5 phased with the top level -- TLAS interior nodes, instance records, a single BLAS's top nodes --
+// staged in LDS (5 = default when the scene has <= 256 instances).  All return identical results.
 #include <algorithm>
 
 #include "rc_traverse_core.h"
