@@ -504,7 +504,7 @@ constexpr int kTopBlock = 1024;
 __global__ __launch_bounds__(kTopBlock) void k_top_remap(const RcNode* nodes, uint32_t n_leaves, uint32_t K, uint32_t* remap) {
     typedef hipcub::BlockScan<uint32_t, kTopBlock> Scan;
     __shared__ typename Scan::TempStorage tmp;
-    __shared__ uint32_t top[rc::kLdsPlaneNodes], in_top[rc::kLdsPlaneNodes + 1], d_list[rc::kLdsPlaneNodes], v_list[rc::kLdsPlaneNodes];
+    __shared__ uint32_t top[rc::kPartialPlaneNodes], in_top[rc::kPartialPlaneNodes + 1], d_list[rc::kPartialPlaneNodes], v_list[rc::kPartialPlaneNodes];  // K <= kPartialPlaneNodes
     const uint32_t t = threadIdx.x;
     if (t == 0) top[0] = 1u;
     if (t <= K) in_top[t] = 0u;
@@ -738,6 +738,13 @@ void rc_build_blas(rc_scene* s, uint32_t n, Blas& out, bool keep_face_map) {
 }
 
 // rebuild_bvh! minus compaction (src/instanced-bvh.jl:968-992): build_tlas_topology (:1485-1594) +
+// The TLAS part of the traversal copy (behind the BLAS nodes), renumbered when the scene keeps the TLAS's top in LDS (tlas_top_k).
+static void pack_tlas(rc_scene* s) {
+    const uint32_t n = (s->n_tlas_nodes + 1) / 2;
+    if (s->tlas_top_k) hipLaunchKernelGGL(k_pack_nodes_remap, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes, n, s->tlas_remap.p);
+    else hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes);
+}
+
 // build_flat_blas_arrays! (:470-517) + the traversal instance records.
 void rc_build_tlas(rc_scene* s) {
     const uint32_t n = (uint32_t)s->instances.size();
@@ -755,10 +762,29 @@ void rc_build_tlas(rc_scene* s) {
     s->flat_nodes.reserve((size_t)tn + 2 * (size_t)n + 1);  // + room for the TLAS copy behind the BLAS nodes
     s->flat_prims.reserve(tp ? tp : 1);
     s->d_descs.reserve(nb ? nb : 1);
-    // One BLAS and a TLAS small enough for the LDS kernel: the BLAS's top internal nodes go to the front of the traversal copy
+    // LDS residency plan of the traversal copy (rc_internal.h).  Up to kTlasLdsInst instances: the whole top level fits (kernel 5) and a
+    // single BLAS gets the remaining node-plane entries for its top.  More instances: the planes hold the breadth-first top of the TLAS
+    // (renumbered below, after the TLAS is built) and, for a single BLAS, of the BLAS -- half each when both want more (kernel 6).
     s->blas_top_k = 0;
-    if (nb == 1 && s->opt.blas_top && n > 0 && 2 * n - 1 <= (uint32_t)rc::kTlasLdsNodes && s->blas[0].n_prims >= 2) {
-        const uint32_t n_leaves = s->blas[0].n_prims, n_int = n_leaves - 1, room = (uint32_t)rc::kLdsPlaneNodes - (n - 1);  // the planes hold the TLAS's n - 1 interior nodes first
+    s->tlas_top_k = 0;
+    const bool full_lds = n > 0 && 2 * n - 1 <= (uint32_t)rc::kTlasLdsNodes;
+    const bool small_enough = (uint64_t)tn + 2ull * n < (1ull << 26);  // the LDS kernels address nodes with 32-bit byte offsets
+    uint32_t blas_room = 0;
+    if (s->opt.blas_top && n > 0 && small_enough) {
+        if (full_lds) blas_room = (uint32_t)rc::kLdsPlaneNodes - (n - 1);
+        else {
+            const uint32_t P = (uint32_t)rc::kPartialPlaneNodes, t_int = n - 1, b_int = (nb == 1 && s->blas[0].n_prims >= 2) ? s->blas[0].n_prims - 1 : 0;
+            uint32_t tk = t_int < P ? t_int : P, bk = b_int < P ? b_int : P;
+            if (tk + bk > P) {  // both want more than half: split evenly, hand a short side's slack to the other
+                const uint32_t half = P / 2;
+                if (tk <= half) bk = P - tk; else if (bk <= half) tk = P - bk; else { tk = P - half; bk = half; }
+            }
+            s->tlas_top_k = tk;
+            blas_room = bk;
+        }
+    }
+    if (nb == 1 && blas_room > 0 && s->blas[0].n_prims >= 2) {
+        const uint32_t n_leaves = s->blas[0].n_prims, n_int = n_leaves - 1, room = blas_room;
         s->blas_top_k = n_int < room ? n_int : room;
         s->top_remap.reserve(n_int);
         hipLaunchKernelGGL(k_iota1, dim3(grid_for(n_int)), dim3(kBlock), 0, s->stream, s->top_remap.p, n_int);
@@ -796,7 +822,12 @@ void rc_build_tlas(rc_scene* s) {
     // n == 1 (:1553-1570): the single leaf holds the scene AABB == the instance's world AABB (same min/max set)
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->vals_b.p, s->d_instances.p, s->d_descs.p, n);
     run_refit(s, s->tlas_nodes.p, nullptr, n, 1, s->tlas_ranges);
-    hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes);
+    if (s->tlas_top_k) {  // the renumbering depends on the topology only: computed here, reused by every refit
+        s->tlas_remap.reserve(n - 1);
+        hipLaunchKernelGGL(k_iota1, dim3(grid_for(n - 1)), dim3(kBlock), 0, s->stream, s->tlas_remap.p, n - 1);
+        hipLaunchKernelGGL(k_top_remap, dim3(1), dim3(kTopBlock), 0, s->stream, s->tlas_nodes.p, n, s->tlas_top_k, s->tlas_remap.p);
+    }
+    pack_tlas(s);
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, s->tlas_nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));
     RC_HIP(hipStreamSynchronize(s->stream));
@@ -820,7 +851,7 @@ void rc_refit_tlas(rc_scene* s, bool from_device, bool recompute_inverse) {
     hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p);
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, (const uint32_t*)nullptr, s->d_instances.p, s->d_descs.p, n);
     run_refit(s, s->tlas_nodes.p, nullptr, n, 1, s->tlas_ranges);
-    hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes);
+    pack_tlas(s);
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, s->tlas_nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));
     RC_HIP(hipStreamSynchronize(s->stream));

@@ -942,6 +942,7 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "blas_top") *value = s->opt.blas_top;
     else if (k == "host_pipeline") *value = s->opt.host_pipeline;
     else if (k == "blas_top_k") *value = s->blas_top_k;
+    else if (k == "tlas_top_k") *value = s->tlas_top_k;
     else if (k.rfind("stat", 0) == 0 && k.size() == 5 && ((k[4] >= '0' && k[4] <= '9') || (k[4] >= 'a' && k[4] <= 'f'))) {
         unsigned long long st[16] = {0};
         (void)hipSetDevice(s->device);

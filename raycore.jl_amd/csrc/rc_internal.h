@@ -81,6 +81,7 @@ constexpr int kTlasLdsInst = 256;
 //  * the TLAS leaf -> instance index table (kTlasLdsInst words);
 //  * the instance records as seven float2 planes of kTlasLdsInst entries (inverse transform, nodes offset, leaf count).
 constexpr int kLdsPlaneNodes = 310;
+constexpr int kPartialPlaneNodes = 585;  // node planes of the PARTIAL_LDS kernel (no leaf table, no instance planes): 32 760 bytes
 }  // namespace rc
 
 struct TraceOptions {
@@ -123,6 +124,8 @@ struct rc_scene {
     uint32_t n_static_instances = 0;
     DevBuf<RcNode> flat_nodes;
     uint32_t n_flat_nodes = 0;
+    DevBuf<uint32_t> tlas_remap;       // same for the TLAS's internal nodes (top levels too large for the full LDS kernels), kept for refits
+    uint32_t tlas_top_k = 0;
     DevBuf<uint32_t> top_remap;        // old -> new internal node index of that renumbering (scratch of rc_build_tlas)
     uint32_t blas_top_k = 0;           // single-BLAS scene: internal nodes 1..blas_top_k of the traversal copy are the tree's top in breadth-first order
     DevBuf<RcPrim> flat_prims;
@@ -162,7 +165,7 @@ struct rc_scene {
     DevBuf<uint32_t> collide_counts;  // collide_instances' per-leaf counts / prefix sums (the reference's `cache`)
     DevBuf<uint2> contact_stage;
 
-    bool lds_attr_set[6] = {false, false, false, false, false, false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any), illumination, view factors
+    bool lds_attr_set[8] = {false, false, false, false, false, false, false, false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any), illumination, view factors
 
     TraceOptions opt;
 };

@@ -130,6 +130,20 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
+// ---- kernel 6: kernel 5's shape for top levels that do not fit (more than 256 instances): only the breadth-first tops of the TLAS and
+// of a single BLAS are staged (PARTIAL_LDS, rc_traverse_core.h); TLAS leaves and instance records come from memory as in kernel 3.
+template <bool ANY>
+__global__ __launch_bounds__(kMidBlock, 6) void k_trace_phased_partial(TraceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem);
+    LdsTop top;
+    top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
+    stage_partial_top<kMidBlock>(top.tl, a.v, a.tlas_k, a.blas_k, a.lds_blas_base);
+    __syncthreads();
+    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base, a.tlas_k};
+    phased_trace<ANY, kMidStack, false, ArraySource, HitWriter, kMidBlock, false, false, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
+}
+
 // ---- kernel 2: persistent waves + per-wave path scheduling --------------------------------------------
 // Kernel 1 runs the reference's three-way loop body as written, so a wave executes the interior-node,
 // triangle, instance-entry and hit-write blocks whenever ANY of its lanes needs them.  Measured on C3
@@ -445,6 +459,13 @@ static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hip
             attr_set = true;
         }
         hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
+    } else if (s->opt.kernel == 6) {
+        bool& attr_set = s->lds_attr_set[6 + (ANY ? 1 : 0)];
+        if (!attr_set) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_partial<ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartialLdsBytes));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_trace_phased_partial<ANY>), dim3(blocks), dim3(kMidBlock), kPartialLdsBytes, stream, a);
     } else if (s->opt.kernel == 3) {
         if (stats) hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else if (lds == 16) hipLaunchKernelGGL((k_trace_phased<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
@@ -479,15 +500,16 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     uint32_t total_threads = blocks * kBlock;
     const int64_t saved_kernel = s->opt.kernel;
     if (saved_kernel < 0)  // auto: tiny batches gain nothing from refilling; a TLAS that fits the LDS planes (<= 256 instances) is read from there
-        s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 3);
+        s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 6);
     if (s->opt.kernel == 4 && (s->n_tlas_nodes > (uint32_t)kTlasLdsNodes || s->n_static_instances > (uint32_t)kTlasLdsInst)) s->opt.kernel = 3;
     if (s->opt.kernel == 5 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes) s->opt.kernel = 3;
+    if (s->opt.kernel == 6 && s->tlas_top_k + s->blas_top_k == 0) s->opt.kernel = 3;  // nothing to stage
     if (s->opt.kernel >= 3 && (uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32)) s->opt.kernel = 1;  // buffer offsets are 32-bit
     if (s->opt.kernel == 4) {  // one 1024-thread workgroup per CU
         blocks = (uint32_t)std::min<uint64_t>((n + kBigBlock - 1) / kBigBlock, (uint64_t)s->n_cus);
         total_threads = blocks * kBigBlock;
     }
-    if (s->opt.kernel == 5) {  // two 768-thread workgroups per CU
+    if (s->opt.kernel == 5 || s->opt.kernel == 6) {  // two 768-thread workgroups per CU
         blocks = (uint32_t)std::min<uint64_t>((n + kMidBlock - 1) / kMidBlock, (uint64_t)s->n_cus * 2);
         total_threads = blocks * kMidBlock;
     }
@@ -504,6 +526,9 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
     a.tail_div = (uint32_t)((total_threads / 64) * (uint64_t)s->opt.tail);
     if ((s->opt.kernel == 5 || s->opt.kernel == 4) && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
+    if (s->opt.kernel == 6) {  // a plan made for the full-LDS kernels (<= 256 instances) has no TLAS renumbering: tlas_k = 0, its blas_k still fits
+        a.tlas_k = s->tlas_top_k; a.blas_k = s->opt.blas_top ? s->blas_top_k : 0; a.lds_blas_base = s->tlas_top_k;
+    }
     RC_HIP(hipEventRecord(s->ev0, stream));
     if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
     s->opt.kernel = saved_kernel;

@@ -38,7 +38,7 @@ struct TraceArgs {
     int sched_thr;                     // scheduled kernel: run a leaf/entry batch once this many lanes wait for it
     unsigned long long* stats;         // optional instrumentation (dev builds), else nullptr
     uint32_t tail_div = 0;             // phased kernels: see PersistArgs
-    uint32_t blas_k = 0, lds_blas_base = 0;
+    uint32_t blas_k = 0, lds_blas_base = 0, tlas_k = 0;
 };
 
 // Address-space-qualified pointers keep the two halves of the stack on their own instruction paths
@@ -289,6 +289,7 @@ struct PersistArgs {
     uint32_t tail_div = 0;             // guided self-scheduling: a claim takes min(pool, remaining / tail_div) items (0 = always `pool`)
     uint32_t blas_k = 0;               // TLAS_LDS kernels: BLAS nodes 1..blas_k are staged in the planes at entry lds_blas_base + node - 1
     uint32_t lds_blas_base = 0;
+    uint32_t tlas_k = 0;               // PARTIAL_LDS kernels: TLAS nodes 1..tlas_k are staged at entry node - 1 (the rest comes from memory)
 };
 
 // TLAS_LDS / INST_LDS: the block has staged the top level in LDS before the call (LdsTop below; layout and sizes in rc_internal.h):
@@ -337,7 +338,25 @@ __device__ inline void stage_lds_top(const LdsTop& t, const SceneView& v, uint32
     }
 }
 
-template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS>
+// PARTIAL_LDS (top levels too large for TLAS_LDS): the planes (kPartialPlaneNodes entries) hold only the breadth-first top of the TLAS
+// -- rc_build_tlas renumbers the TLAS's internal nodes in the traversal copy the way it does for a single BLAS -- and of a single BLAS;
+// TLAS leaves, instance records and everything below the tops are read from memory as in the plain kernel.
+constexpr size_t kPartialPlaneBytes = (size_t)7 * kPartialPlaneNodes * sizeof(float2);
+constexpr size_t kPartialLdsBytes = (size_t)kMidStack * kMidBlock * 4 + kPartialPlaneBytes;
+template <int BLOCK>
+__device__ inline void stage_partial_top(float2* tl, const SceneView& v, uint32_t tlas_k, uint32_t blas_k, uint32_t lds_blas_base) {
+    const RcNode* tnodes = v.blas_nodes + v.tlas_off;
+    for (uint32_t i = threadIdx.x; i < tlas_k * 7u; i += BLOCK) {
+        const uint32_t nd = i / 7u, p = i % 7u;
+        tl[p * kPartialPlaneNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
+    }
+    for (uint32_t i = threadIdx.x; i < blas_k * 7u; i += BLOCK) {
+        const uint32_t nd = i / 7u, p = i % 7u;
+        tl[p * kPartialPlaneNodes + lds_blas_base + nd] = reinterpret_cast<const float2*>(v.blas_nodes + nd)[p];
+    }
+}
+
+template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS, bool PARTIAL_LDS = false>
 __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
                                     const LdsTop top = LdsTop()) {
     const float2* const tl = top.tl;
@@ -379,10 +398,10 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             if (is_int) {
                 float4 na, nb, nc;
                 u2v ch;
-                if (TLAS_LDS && (cur_inst < 0 || node <= a.blas_k)) {
+                constexpr int PS = PARTIAL_LDS ? kPartialPlaneNodes : kLdsPlaneNodes;  // plane stride
+                if ((TLAS_LDS && (cur_inst < 0 || node <= a.blas_k)) || (PARTIAL_LDS && node <= (cur_inst < 0 ? a.tlas_k : a.blas_k))) {
                     const float2* q = tl + ((node - 1u) + (cur_inst < 0 ? 0u : a.lds_blas_base));
-                    const float2 p0 = q[0], p1 = q[kLdsPlaneNodes], p2 = q[2 * kLdsPlaneNodes], p3 = q[3 * kLdsPlaneNodes],
-                                 p4 = q[4 * kLdsPlaneNodes], p5 = q[5 * kLdsPlaneNodes], p6 = q[6 * kLdsPlaneNodes];
+                    const float2 p0 = q[0], p1 = q[PS], p2 = q[2 * PS], p3 = q[3 * PS], p4 = q[4 * PS], p5 = q[5 * PS], p6 = q[6 * PS];
                     na = make_float4(p0.x, p0.y, p1.x, p1.y); nb = make_float4(p2.x, p2.y, p3.x, p3.y); nc = make_float4(p4.x, p4.y, p5.x, p5.y);
                     ch = u2v{__float_as_uint(p6.x), __float_as_uint(p6.y)};
                 } else {

@@ -77,7 +77,7 @@ def test_random_hostile_scenes(rc, oracle, seed):
     rays["tmin"][::7] = g.uniform(-1, 1, len(rays["tmin"][::7]))
     rays["tmax"][::5] = g.uniform(0, 8, len(rays["tmax"][::5]))
     want_c, want_a = o.trace(rays, nthreads=4), o.trace(rays, mode="any", nthreads=4)
-    for kern in (0, 1, 2, 3, 4, 5):
+    for kern in (0, 1, 2, 3, 4, 5, 6):
         t.set_option("kernel", kern)
         assert_hits_equal(t.trace(rays), want_c, f"seed {seed} closest k{kern}")
         assert_hits_equal(t.trace(rays, mode="any"), want_a, f"seed {seed} any k{kern}")

@@ -270,7 +270,7 @@ def test_blas_top_renumbering(rc, oracle, n_tris, n_inst):
     rays = random_rays(rc, 150_000, n_tris, wb[:3], wb[3:])
     want, want_any = o.trace(rays, nthreads=8), o.trace(rays, mode="any", nthreads=8)
     assert want["hit"].any()
-    for kernel, top in ((5, 1), (5, 0), (0, 1), (1, 1), (3, 1), (4, 1)):
+    for kernel, top in ((5, 1), (5, 0), (0, 1), (1, 1), (3, 1), (4, 1), (6, 1), (6, 0)):
         t.set_option("kernel", kernel)
         t.set_option("blas_top", top)
         assert_hits_equal(t.trace(rays), want, f"kernel {kernel} blas_top {top} closest")
@@ -283,6 +283,71 @@ def test_blas_top_renumbering(rc, oracle, n_tris, n_inst):
     o.add_instance(o.add_blas(sc.fan_sphere(12, 7)))
     o.build()
     assert_hits_equal(t.trace(rays), o.trace(rays, nthreads=8), "two BLASes")
+    t.free()
+
+
+@pytest.mark.parametrize("n_tris,n_inst,n_blas", [(3000, 300, 1), (40, 700, 1), (5000, 1500, 1), (800, 600, 3), (2, 257, 1)])
+def test_large_top_level_partial_lds(rc, oracle, n_tris, n_inst, n_blas):
+    """More than 256 instances: the traversal copy's TLAS (and a single BLAS) is renumbered so that the breadth-first top sits in
+    front and kernel 6 stages those nodes in LDS; transforms change through refits (the renumbering must survive them) and through a
+    rebuild.  Every kernel must agree with the oracle on that copy; the exported arrays keep the reference numbering."""
+    sc = rc.scenes
+    g = np.random.default_rng(n_inst)
+    blas = [(sc.random_triangles(n_tris, 7 + b, lo=-0.5, hi=0.5, edge=0.3 if n_tris < 100 else 0.1), None) for b in range(n_blas)]
+    xf = np.tile(sc.IDENTITY3x4, (n_inst, 1)).astype(np.float32)
+    xf[:, [3, 7, 11]] = g.uniform(-6, 6, size=(n_inst, 3))
+    per = n_inst // n_blas
+    inst = [(b + 1, xf[b * per:(b + 1) * per if b < n_blas - 1 else n_inst], np.arange(b * per, (b + 1) * per if b < n_blas - 1 else n_inst, dtype=np.uint32)) for b in range(n_blas)]
+    cfg = {"blas": blas, "instances": inst}
+    t = rc.TLAS(0)
+    bids = [t.add_geometry(v, m) for v, m in cfg["blas"]]
+    handles = [t.push_instances(b, x, i) for b, x, i in cfg["instances"]]
+    t.sync()
+    o = build_oracle(oracle, cfg)
+    n_int_tlas = n_inst - 1
+    n_int_blas = len(o.blas_prims) - 1 if n_blas == 1 else 0
+    tk, bk = t.get_option("tlas_top_k"), t.get_option("blas_top_k")
+    assert 0 < tk <= min(n_int_tlas, 585) and bk <= min(n_int_blas, 585) and tk + bk <= 585
+    assert tk + bk == min(585, n_int_tlas + n_int_blas)
+    st = t.adapt()
+    assert st.nodes.tobytes() == o.tlas_nodes.tobytes() and st.all_blas_nodes.tobytes() == o.blas_nodes.tobytes()
+    wb = o.world_bound
+    rays = random_rays(rc, 120_000, n_inst, wb[:3], wb[3:])
+
+    def check_all(what):
+        want, want_any = o.trace(rays, nthreads=8), o.trace(rays, mode="any", nthreads=8)
+        assert want["hit"].any()
+        for kernel in (6, 3, 0, 1, 5):  # 5 falls back to 3 here (too many instances)
+            t.set_option("kernel", kernel)
+            assert_hits_equal(t.trace(rays), want, f"{what} kernel {kernel} closest")
+            assert_hits_equal(t.trace(rays, mode="any"), want_any, f"{what} kernel {kernel} any")
+        t.set_option("kernel", -1)
+
+    check_all("built")
+    xf2 = xf.copy()
+    xf2[:, [3, 7, 11]] += g.uniform(-1, 1, size=(n_inst, 3)).astype(np.float32)
+    for (b, x, i), h in zip(cfg["instances"], handles):
+        lo = int(i[0])
+        t.update_transforms(h, xf2[lo:lo + len(i)])
+    t.sync()
+    assert t.last_sync_action == "refit" and t.get_option("tlas_top_k") == tk
+    o2 = oracle.Scene()
+    for v, m in cfg["blas"]:
+        o2.add_blas(v, m)
+    for (b, x, i) in cfg["instances"]:
+        for k, idx in enumerate(i):
+            o2.add_instance(b, xf2[int(idx)], int(idx))
+    o2.build()
+    # a refit keeps the topology of the first build: compare against the oracle only through the rays (the refitted tree is a valid
+    # BVH of the moved instances, and every kernel walks the same one)
+    t.set_option("kernel", 3)
+    ref = t.trace(rays)
+    for kernel in (6, 0, 1):
+        t.set_option("kernel", kernel)
+        assert_hits_equal(t.trace(rays), ref, f"refit kernel {kernel}")
+    t.set_option("kernel", -1)
+    brute = o2.trace(rays, nthreads=8)
+    assert np.array_equal(ref["hit"], brute["hit"]) and np.array_equal(ref["t"][ref["hit"] == 1], brute["t"][brute["hit"] == 1])
     t.free()
 
 
