@@ -22,7 +22,7 @@ work = [("C3 primary closest", t3, o3, rays, "closest"), ("C3 shadow any", t3, o
         ("C4 bounce any", t3, o3, bounce, "any"), ("C2 closest", t2, o2, rays2, "closest"), ("C2 any", t2, o2, rays2, "any")]
 for name, t, o, r, mode in work:
     t0 = time.time(); w = o.trace(r, mode=mode, nthreads=nt); dt = time.time() - t0
-    for k in (0, 1, 2, 3, 4, 5):
+    for k in (0, 1, 2, 3, 4, 5, 6):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(r, mode=mode), w, f"{name} kernel {k}")
-    print(f"{name}: {len(r)} rays x 6 kernels identical (oracle {dt:.1f} s, hit fraction {w['hit'].mean():.3f})", flush=True)
+    print(f"{name}: {len(r)} rays x 7 kernels identical (oracle {dt:.1f} s, hit fraction {w['hit'].mean():.3f})", flush=True)
