@@ -372,9 +372,25 @@ constexpr int kRefitBlock = 1024;
 __global__ __launch_bounds__(kRefitBlock) void k_refit(RcNode* nodes, const RcPrim* prims, uint32_t* flags, const uint2* ranges, uint32_t n, int tlas) {
     __shared__ uint32_t l_flags[kRefitBlock];
     __shared__ float l_box[kRefitBlock][2][6];
-    l_flags[threadIdx.x] = 0u;
-    __syncthreads();
+    // Topology of the window's own internal nodes (indices base+1 .. base+kRefitBlock), fetched once with every thread's loads in
+    // flight together: the walk below then takes each in-window step from LDS instead of paying a dependent global load per level.
+    // l_c0 = child0 with bit 31 set when the node's leaf range lies inside the window (=> only this workgroup ever visits it).
+    __shared__ uint32_t l_parent[kRefitBlock], l_c0[kRefitBlock];
     const uint32_t base = blockIdx.x * kRefitBlock;  // this workgroup's leaves are sorted positions base+1 .. base+kRefitBlock
+    l_flags[threadIdx.x] = 0u;
+    {
+        const uint32_t idx = base + threadIdx.x + 1;  // 1-based internal node index
+        uint32_t par = RC_INVALID_NODE, c0 = 0u;
+        if (idx < n) {
+            const RcNode& nd = nodes[idx - 1];
+            const uint2 rg = ranges[idx - 1];
+            par = nd.parent;
+            c0 = nd.child0 | ((rg.x > base && rg.y <= base + kRefitBlock) ? 0x80000000u : 0u);
+        }
+        l_parent[threadIdx.x] = par;
+        l_c0[threadIdx.x] = c0;
+    }
+    __syncthreads();
     const uint32_t j = base + threadIdx.x + 1;
     if (j > n) return;
     uint32_t cur = n - 1 + j;
@@ -388,11 +404,13 @@ __global__ __launch_bounds__(kRefitBlock) void k_refit(RcNode* nodes, const RcPr
     uint32_t parent = nodes[cur - 1].parent;
     while (parent != RC_INVALID_NODE) {
         RcNode* nd = &nodes[parent - 1];
-        const bool first_slot = nd->child0 == cur;  // topology was written by earlier launches
-        const uint2 rg = ranges[parent - 1];
-        if (rg.x > base && rg.y <= base + kRefitBlock) {
+        const uint32_t li = parent - 1u - base;  // < kRefitBlock iff the node's index is in the window
+        const uint32_t c0w = li < (uint32_t)kRefitBlock ? l_c0[li] : 0u;
+        uint32_t next_parent;
+        if (c0w >> 31) {
             // ---- inside the window: LDS protocol
-            const uint32_t li = parent - 1u - base;
+            const bool first_slot = (c0w & 0x7FFFFFFFu) == cur;
+            next_parent = l_parent[li];
             float* mine = l_box[li][first_slot ? 0 : 1];
             mine[0] = mn.x; mine[1] = mn.y; mine[2] = mn.z; mine[3] = mx.x; mine[4] = mx.y; mine[5] = mx.z;
             const uint32_t old = __hip_atomic_fetch_add(&l_flags[li], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -409,6 +427,8 @@ __global__ __launch_bounds__(kRefitBlock) void k_refit(RcNode* nodes, const RcPr
             mx = first_slot ? max3v(mx, smx) : max3v(smx, mx);
         } else {
             // ---- spans windows: device-scope protocol
+            const bool first_slot = nd->child0 == cur;  // topology was written by earlier launches
+            next_parent = nd->parent;
             float* mine = nd->f + (first_slot ? 0 : 6);
             const float* sib = nd->f + (first_slot ? 6 : 0);
             if (first_slot) { store_coherent(mine, f4v{mn.x, mn.y, mn.z, mx.x}); store_coherent(mine + 4, f2v{mx.y, mx.z}); }
@@ -423,7 +443,7 @@ __global__ __launch_bounds__(kRefitBlock) void k_refit(RcNode* nodes, const RcPr
             mx = first_slot ? max3v(mx, smx) : max3v(smx, mx);
         }
         cur = parent;
-        parent = nd->parent;
+        parent = next_parent;
     }
 }
 
