@@ -164,6 +164,22 @@ def main():
         t2.sync()
         extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(t2, rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"]), "closest", reps=5)
         t2.free()
+        # Top levels beyond the 256 instances the full LDS kernel takes (kernel 6: TLAS / BLAS tops in LDS, the rest from memory):
+        # the C3 BLAS on bigger lattices, same 4 M-ray pinhole camera
+        big = {}
+        for lattice in ((10, 10, 5), (20, 20, 12)):
+            cfgb = sc.config_c3(lattice=lattice)
+            tb = rc.TLAS(local_rank)
+            for verts, meta in cfgb["blas"]:
+                tb.add_geometry(verts, meta)
+            for b, xf, ids in cfgb["instances"]:
+                tb.push_instances(b, xf, ids)
+            tb.sync()
+            big[str(int(np.prod(lattice)))] = {"triangles": tb.n_primitives() * tb.n_instances(),
+                                               "mrays_s": timed(tb, sc.c3_primary_rays(cfgb, args.res, args.res), "closest"),
+                                               "tlas_top_k": tb.get_option("tlas_top_k"), "blas_top_k": tb.get_option("blas_top_k")}
+            tb.free()
+        extras["c3_blas_more_instances_closest"] = big
         # The reference's own published traversal benchmark shape (benchmarks/implicitbvh_comparison.md:37-39): random geometry in one
         # BLAS, 1 M rays closest_hit -- 8.99 / 11.08 / 15.41 ms for 250 k / 1 M / 4 M triangles on an RX 7900 XTX (ray distribution
         # unstated there; here the coherent 1000 x 1000 grid of get_illumination).
