@@ -538,7 +538,8 @@ static void populate_pages(void* p, size_t bytes) {
 // the kernel overlap: a 4 M-ray batch takes about one direction's transfer time (2.4 ms at 56 GB/s) plus one chunk's latency instead
 // of upload + kernel + download back to back.  The chunks are traced by the same kernels, so the results do not change.
 static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
-    constexpr uint64_t kChunk = 1ull << 19;
+    // at most 48 chunks: every chunk's launch keeps its own counter / status slot (64 rotate) until the statuses are read below
+    const uint64_t kChunk = std::max<uint64_t>(1ull << 19, ((n + 47) / 48 + 63) & ~63ull);
     const uint64_t n_chunks = (n + kChunk - 1) / kChunk;
     s->ray_stage.reserve(n);
     s->hit_stage.reserve(n);
