@@ -285,7 +285,7 @@ __device__ inline int delta(int i1, int i2, const uint32_t* codes, int n) {
 
 // emit_topology_kernel! (src/instanced-bvh-kernels.jl:119-152) = find_span_for_node + find_split_in_span
 // (src/instanced-bvh.jl:1232-1290)
-__global__ void k_topology(RcNode* nodes, const uint32_t* codes, int n, uint2* ranges) {
+__global__ void k_topology(RcNode* nodes, const uint32_t* codes, int n, uint4* meta) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (idx >= n) return;
     int d_left = delta(idx, idx - 1, codes, n);
@@ -314,7 +314,16 @@ __global__ void k_topology(RcNode* nodes, const uint32_t* codes, int n, uint2* r
     nodes[idx - 1].child0 = (uint32_t)child0;
     nodes[idx - 1].child1 = (uint32_t)child1;
     nodes[idx - 1].pad = 0;
-    ranges[idx - 1] = make_uint2((uint32_t)span_left, (uint32_t)span_right);  // sorted-leaf range of this node, for the refit
+    // Compact copy of the topology for the refit (16 bytes per internal node: sorted-leaf range, child0, parent; 4 per leaf: parent), so
+    // that it reads 20 MB per million leaves instead of one word each out of 2 x 64 MB of node records.
+    uint32_t* mw = reinterpret_cast<uint32_t*>(meta);
+    uint32_t* leaf_parent = mw + 4 * (size_t)(n - 1);
+    mw[4 * (size_t)(idx - 1) + 0] = (uint32_t)span_left;
+    mw[4 * (size_t)(idx - 1) + 1] = (uint32_t)span_right;
+    mw[4 * (size_t)(idx - 1) + 2] = (uint32_t)child0;
+    if (child0 < n) mw[4 * (size_t)(child0 - 1) + 3] = (uint32_t)idx; else leaf_parent[child0 - n] = (uint32_t)idx;
+    if (child1 < n) mw[4 * (size_t)(child1 - 1) + 3] = (uint32_t)idx; else leaf_parent[child1 - n] = (uint32_t)idx;
+    if (idx == 1) mw[3] = RC_INVALID_NODE;
     // set_parent_pointers_kernel! (src/instanced-bvh-kernels.jl:159-191) folded in: a node's parent word is written exactly once, by
     // its parent's thread (the root's by its own), so no separate pass and no fill pass are needed -- every other word of every node is
     // written by this kernel (child words), the leaf kernels (leaf payload) or the refit (both boxes of every internal node).
@@ -369,7 +378,7 @@ __device__ inline f2v load2_coherent(const float* p) {
 // slots, and the second arrival writes the finished node with plain stores.  Only the few nodes that span windows (about
 // 2 log2(window) per workgroup) go through device-scope atomics and write-through stores.  Measured on 4 M triangles: 0.79 ms -> see DESIGN.
 constexpr int kRefitBlock = 1024;
-__global__ __launch_bounds__(kRefitBlock) void k_refit(RcNode* nodes, const RcPrim* prims, uint32_t* flags, const uint2* ranges, uint32_t n, int tlas) {
+__global__ __launch_bounds__(kRefitBlock) void k_refit(RcNode* nodes, const RcPrim* prims, uint32_t* flags, const uint4* meta, uint32_t n, int tlas) {
     __shared__ uint32_t l_flags[kRefitBlock];
     __shared__ float l_box[kRefitBlock][2][6];
     // Topology of the window's own internal nodes (indices base+1 .. base+kRefitBlock), fetched once with every thread's loads in
@@ -382,10 +391,9 @@ __global__ __launch_bounds__(kRefitBlock) void k_refit(RcNode* nodes, const RcPr
         const uint32_t idx = base + threadIdx.x + 1;  // 1-based internal node index
         uint32_t par = RC_INVALID_NODE, c0 = 0u;
         if (idx < n) {
-            const RcNode& nd = nodes[idx - 1];
-            const uint2 rg = ranges[idx - 1];
-            par = nd.parent;
-            c0 = nd.child0 | ((rg.x > base && rg.y <= base + kRefitBlock) ? 0x80000000u : 0u);
+            const uint4 m = meta[idx - 1];  // range, child0, parent
+            par = m.w;
+            c0 = m.z | ((m.x > base && m.y <= base + kRefitBlock) ? 0x80000000u : 0u);
         }
         l_parent[threadIdx.x] = par;
         l_c0[threadIdx.x] = c0;
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(kRefitBlock) void k_refit(RcNode* nodes, const RcPr
     } else {
         tri_bounds(prims[j - 1], mn, mx);   // get_node_aabb of a BLAS leaf (:1149-1158)
     }
-    uint32_t parent = nodes[cur - 1].parent;
+    uint32_t parent = reinterpret_cast<const uint32_t*>(meta + (n - 1))[j - 1];  // the leaf's parent
     while (parent != RC_INVALID_NODE) {
         RcNode* nd = &nodes[parent - 1];
         const uint32_t li = parent - 1u - base;  // < kRefitBlock iff the node's index is in the window
@@ -427,8 +435,9 @@ __global__ __launch_bounds__(kRefitBlock) void k_refit(RcNode* nodes, const RcPr
             mx = first_slot ? max3v(mx, smx) : max3v(smx, mx);
         } else {
             // ---- spans windows: device-scope protocol
-            const bool first_slot = nd->child0 == cur;  // topology was written by earlier launches
-            next_parent = nd->parent;
+            const uint4 m = meta[parent - 1];  // topology was written by earlier launches
+            const bool first_slot = m.z == cur;
+            next_parent = m.w;
             float* mine = nd->f + (first_slot ? 0 : 6);
             const float* sib = nd->f + (first_slot ? 6 : 0);
             if (first_slot) { store_coherent(mine, f4v{mn.x, mn.y, mn.z, mx.x}); store_coherent(mine + 4, f2v{mx.y, mx.z}); }
@@ -618,13 +627,13 @@ void reserve_build_scratch(rc_scene* s, uint32_t n) {
 }
 
 // Karras topology + parents for n items with sorted keys in keys_b
-void emit_tree(rc_scene* s, RcNode* nodes, uint32_t n, DevBuf<uint2>& ranges) {
-    ranges.reserve(n > 1 ? n - 1 : 1);
+void emit_tree(rc_scene* s, RcNode* nodes, uint32_t n, DevBuf<uint4>& ranges) {
+    ranges.reserve(n > 1 ? (size_t)(n - 1) + (n + 3) / 4 : 1);  // one record per internal node, then the leaves' parent words
     if (n > 1) hipLaunchKernelGGL(k_topology, dim3(grid_for(n - 1)), dim3(kBlock), 0, s->stream, nodes, s->keys_b.p, (int)n, ranges.p);
     else hipLaunchKernelGGL(k_fill_nodes, dim3(1), dim3(kBlock), 0, s->stream, nodes, 1u);  // single leaf: empty node, the leaf kernel fills the payload
 }
 
-void run_refit(rc_scene* s, RcNode* nodes, const RcPrim* prims, uint32_t n, int tlas, const DevBuf<uint2>& ranges) {
+void run_refit(rc_scene* s, RcNode* nodes, const RcPrim* prims, uint32_t n, int tlas, const DevBuf<uint4>& ranges) {
     if (n < 2) return;
     RC_HIP(hipMemsetAsync(s->flags.p, 0, sizeof(uint32_t) * (n - 1), s->stream));
     hipLaunchKernelGGL(k_refit, dim3((n + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, s->stream, nodes, prims, s->flags.p, ranges.p, n, tlas);

@@ -140,8 +140,8 @@ struct rc_scene {
     DevBuf<uint32_t> keys_a, keys_b, vals_a, vals_b, flags, scene_enc, bounds_partials;
     DevBuf<unsigned char> sort_tmp;
     DevBuf<float> aabb_tmp;
-    DevBuf<uint2> range_tmp;    // sorted-leaf range of every internal node of the BLAS being built (k_topology -> k_refit)
-    DevBuf<uint2> tlas_ranges;  // same for the TLAS; kept, because refit_tlas! reuses the topology
+    DevBuf<uint4> range_tmp;    // compact topology of the BLAS being built (k_topology -> k_refit): per internal node its sorted-leaf range, child0, parent; then one parent word per leaf
+    DevBuf<uint4> tlas_ranges;  // same for the TLAS; kept, because refit_tlas! reuses the topology
     DevBuf<RcPrim> prim_tmp;
     // global spill areas of the traversal stacks: one per stream that has launched on this scene (launches on one stream are
     // ordered and share theirs; launches on different streams may overlap and must not), at most kMaxOverflowRegions
