@@ -283,7 +283,11 @@ def main():
             else:
                 counted = int(m.sum(dtype=torch.int64).item()) if rank == 0 else 0
             if rank == 0:
-                vf[mode] = {"seconds": round(vdt, 4), "Mrays_s": round(n5 * rpt / vdt / 1e6, 1), "counted": counted}
+                # seconds = end to end on the slowest rank, INCLUDING the allocation and zero fill of this rank's block of the matrix
+                # (10 GB at N = 1, fresh from the driver each time because the cache is emptied between modes) and any gather / reduce;
+                # kernel_ms = rank 0's trace kernel alone
+                vf[mode] = {"seconds": round(vdt, 4), "Mrays_s": round(n5 * rpt / vdt / 1e6, 1), "counted": counted,
+                            "kernel_ms_rank0": round(t5.last_kernel_ms(), 3)}
             del m
             torch.cuda.empty_cache()
         t5.free()
