@@ -144,6 +144,32 @@ def test_scene_save_load_roundtrip(rc, oracle, tmp_path):
         rc.TLAS.load(tmp_path / "junk.rcs")
 
 
+def test_scene_save_load_keeps_the_lds_plan(rc, tmp_path):
+    """A loaded scene rebuilds its traversal copy: the single-BLAS / large-top-level renumbering (kernels 5 / 6) is planned again and
+    every kernel of the loaded scene agrees with the original."""
+    sc = rc.scenes
+    for n_inst in (40, 400):
+        g = np.random.default_rng(n_inst)
+        xf = np.tile(sc.IDENTITY3x4, (n_inst, 1)).astype(np.float32)
+        xf[:, [3, 7, 11]] = g.uniform(-5, 5, size=(n_inst, 3))
+        t = rc.TLAS()
+        t.push(sc.random_triangles(3000, 21, lo=-0.5, hi=0.5, edge=0.1), xf)
+        t.sync()
+        path = tmp_path / f"scene{n_inst}.rcs"
+        t.save(path)
+        u = rc.TLAS.load(path)
+        u.sync()
+        assert (u.get_option("tlas_top_k"), u.get_option("blas_top_k")) == (t.get_option("tlas_top_k"), t.get_option("blas_top_k"))
+        assert u.get_option("blas_top_k") > 0 and (u.get_option("tlas_top_k") > 0) == (n_inst > 256)
+        rays = sc.make_rays(g.uniform(-7, 7, (60000, 3)), sc.normalize(g.normal(size=(60000, 3))))
+        ref = t.trace(rays)
+        assert ref["hit"].any()
+        for kernel in (0, 3, 5, 6):
+            u.set_option("kernel", kernel)
+            assert_hits_equal(u.trace(rays), ref, f"{n_inst} instances, loaded scene, kernel {kernel}")
+        t.free(); u.free()
+
+
 def test_update_mesh_replaces_geometry(rc, oracle):
     v, f, nrm, uv = grid_mesh(8, seed=10)
     v2, f2, nrm2, uv2 = grid_mesh(5, seed=11)
