@@ -90,7 +90,7 @@ struct TraceOptions {
     int64_t lds_stack = 24;    // per-lane stack entries kept in LDS: 12, 16, 24 or 32
     int64_t pool = 0;          // persistent kernels: ray indices per atomic claim (0 = auto 64..512)
     int64_t refill = 20;       // persistent kernel: refill when this many lanes of a wave are idle
-    int64_t sched_thr = 32;    // kernel 2: lanes that must wait for a leaf/switch batch; kernel 3: interior lanes below which the wave serves the waiting lanes
+    int64_t sched_thr = 36;    // kernel 2: lanes that must wait for a leaf/switch batch; kernel 3: interior lanes below which the wave serves the waiting lanes
     int64_t stats = 0;         // dev instrumentation (persistent kernels only)
     int64_t onesweep_min = 1000000;  // builds: key counts from here up are sorted by Onesweep radix passes, smaller ones by rocPRIM's merge sort (measured: 0.22 vs 0.25 ms at 250 k keys, 0.437 vs 0.425 ms at 1 M)
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
