@@ -462,10 +462,10 @@ int rc_wait(rc_scene* s) {
         // asynchronous launches (the *_device entry points) cannot report a traversal-stack overflow themselves: their status words
         // (one per launch slot) are collected here
         if (s->counters.p) {
-            std::vector<uint32_t> words(64 * 64);
+            std::vector<uint32_t> words((size_t)kCounterSlots * kCounterSlotWords);
             RC_HIP(hipMemcpy(words.data(), s->counters.p, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
             bool overflow = false;
-            for (int slot = 0; slot < 64; ++slot) overflow |= words[slot * 64 + 4] != 0;
+            for (int slot = 0; slot < kCounterSlots; ++slot) overflow |= words[(size_t)slot * kCounterSlotWords + 4] != 0;
             if (overflow) {
                 RC_HIP(hipMemset(s->counters.p, 0, words.size() * sizeof(uint32_t)));
                 throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow in an earlier asynchronous launch (tree deeper than 128 levels)");
@@ -925,6 +925,7 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "tail") s->opt.tail = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (k == "onesweep_min") s->opt.onesweep_min = value < 0 ? 0 : value;
     else if (k == "blas_top") s->opt.blas_top = value != 0;
+    else if (k == "claim_shards") { int64_t p2 = 1; while (p2 * 2 <= value && p2 * 2 <= kClaimShards) p2 *= 2; s->opt.claim_shards = p2; }  // a power of two
     else if (k == "host_pipeline") s->opt.host_pipeline = value != 0;
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
@@ -941,6 +942,15 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "tail") *value = s->opt.tail;
     else if (k == "onesweep_min") *value = s->opt.onesweep_min;
     else if (k == "blas_top") *value = s->opt.blas_top;
+    else if (k == "claims") {  // dev: claim atomics issued by the last phased launch (successful + failed)
+        uint32_t w[kCounterSlotUsedWords];
+        (void)hipSetDevice(s->device);
+        (void)hipDeviceSynchronize();
+        if (s->counters.p && hipMemcpy(w, rc_counter_slot(s), sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "counter read failed");
+        int64_t t = 0;
+        for (int sh = 0; sh < kClaimShards; ++sh) t += w[kShardBase + sh * kShardStrideWords];
+        *value = t;
+    }
     else if (k == "host_pipeline") *value = s->opt.host_pipeline;
     else if (k == "blas_top_k") *value = s->blas_top_k;
     else if (k == "tlas_top_k") *value = s->tlas_top_k;

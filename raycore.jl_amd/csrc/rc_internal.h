@@ -95,6 +95,7 @@ struct TraceOptions {
     int64_t onesweep_min = 1000000;  // builds: key counts from here up are sorted by Onesweep radix passes, smaller ones by rocPRIM's merge sort (measured: 0.22 vs 0.25 ms at 250 k keys, 0.437 vs 0.425 ms at 1 M)
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
     int64_t host_pipeline = 1; // host-buffer trace calls of >= 1 Mi rays overlap upload / trace / download in chunks
+    int64_t claim_shards = 16; // phased kernels: chunk counters in use (a power of two <= kClaimShards)
     int64_t tail = 1;          // phased kernels: claims shrink to remaining / (waves * tail) near the end of a batch (0 = fixed-size claims)
 };
 
@@ -208,7 +209,14 @@ void rc_launch_compact_hits(rc_scene* s, const RcHit* d_hits, uint64_t n, uint32
 // rc_traverse.hip helpers shared with rc_drivers.hip
 namespace rc { struct SceneView; }
 void rc_prepare_launch(rc_scene* s, hipStream_t stream);
-inline uint32_t* rc_counter_slot(rc_scene* s) { return s->counters.p + (s->launch_seq % 64) * 64; }  // slot of the most recent launch
+// One slot of counter / status words per launch, rotated over kCounterSlots: words [0..1] the work counter of the kernels that claim
+// ray indices from a single counter, [4] the stack-overflow status, [8..] dev statistics, and from word kShardBase on the chunk
+// counters of the phased kernels, kClaimShards of them kShardStrideWords apart.  A returning atomic on ONE address costs 12.6 ns on
+// MI355X however many waves issue it (tools/atomic_probe.hip): 6144 waves claiming their first rays wait up to 77 us, and the
+// 32 768 claims of a 4 M-ray launch keep a single counter busy for 0.41 ms.  Sixteen counters 256 bytes apart run at 0.9 ns per claim.
+constexpr int kCounterSlots = 64, kCounterSlotWords = 2048, kCounterSlotUsedWords = 1088;
+constexpr int kClaimShards = 16, kShardBase = 64, kShardStrideWords = 64;
+inline uint32_t* rc_counter_slot(rc_scene* s) { return s->counters.p + (size_t)(s->launch_seq % kCounterSlots) * kCounterSlotWords; }  // slot of the most recent launch
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items);
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream);
 void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float* d_points, float* d_normals, hipStream_t stream);

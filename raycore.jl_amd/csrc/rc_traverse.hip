@@ -126,7 +126,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     const LdsTop top(smem + stack_bytes);
     if (a.v.n_tlas_nodes) stage_lds_top<BLOCK>(top, a.v, a.blas_k, a.lds_blas_base);
     __syncthreads();
-    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base};
+    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base, 0u, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
     phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kMidBlock, 6) void k_trace_phased_partial(TraceArgs
     top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
     stage_partial_top<kMidBlock>(top.tl, a.v, a.tlas_k, a.blas_k, a.lds_blas_base);
     __syncthreads();
-    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base, a.tlas_k};
+    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base, a.tlas_k, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
     phased_trace<ANY, kMidStack, false, ArraySource, HitWriter, kMidBlock, false, false, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
 template <bool ANY, int LDS_N, int MINW, bool STATS>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
     __shared__ uint32_t lds_stack[LDS_N * kBlock];
-    PersistArgs p{a.n_rays, a.work_counter, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div};
+    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, 0u, 0u, 0u, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
     phased_trace<ANY, LDS_N, STATS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits});
 }
 
@@ -396,9 +396,12 @@ void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
     }
     // one 256-byte slot of counter / status words per launch, rotated over 64 slots, so launches of one scene that
     // are in flight on different streams never share a work counter
-    s->counters.reserve(64 * 64);
+    if (!s->counters.p) {
+        s->counters.reserve((size_t)kCounterSlots * kCounterSlotWords);
+        RC_HIP(hipMemsetAsync(s->counters.p, 0, sizeof(uint32_t) * (size_t)kCounterSlots * kCounterSlotWords, stream));
+    }
     s->launch_seq += 1;
-    RC_HIP(hipMemsetAsync(rc_counter_slot(s), 0, 64 * sizeof(uint32_t), stream));
+    RC_HIP(hipMemsetAsync(rc_counter_slot(s), 0, kCounterSlotUsedWords * sizeof(uint32_t), stream));
 }
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
@@ -413,12 +416,14 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
 rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads) {
     rc::PersistArgs p;
     p.n_items = n_items;
-    p.work_counter = reinterpret_cast<unsigned long long*>(rc_counter_slot(s));
+    p.work_counter = rc_counter_slot(s) + kShardBase;  // chunk counters (phased_trace)
     p.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
     p.refill = (int)s->opt.refill;
     p.int_thr = (int)s->opt.sched_thr;
     p.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
     p.tail_div = (uint32_t)((total_threads / 64) * (uint64_t)s->opt.tail);
+    p.n_shards = (uint32_t)s->opt.claim_shards;
+    p.n_chunks = (uint32_t)((n_items + p.pool - 1) / p.pool);
     return p;
 }
 
@@ -504,7 +509,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     if (s->opt.kernel == 4 && (s->n_tlas_nodes > (uint32_t)kTlasLdsNodes || s->n_static_instances > (uint32_t)kTlasLdsInst)) s->opt.kernel = 3;
     if (s->opt.kernel == 5 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes) s->opt.kernel = 3;
     if (s->opt.kernel == 6 && s->tlas_top_k + s->blas_top_k == 0) s->opt.kernel = 3;  // nothing to stage
-    if (s->opt.kernel >= 3 && (uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32)) s->opt.kernel = 1;  // buffer offsets are 32-bit
+    if (s->opt.kernel >= 3 && ((uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32) || n >= (1ull << 38))) s->opt.kernel = 1;  // buffer offsets and chunk ids are 32-bit
     if (s->opt.kernel == 4) {  // one 1024-thread workgroup per CU
         blocks = (uint32_t)std::min<uint64_t>((n + kBigBlock - 1) / kBigBlock, (uint64_t)s->n_cus);
         total_threads = blocks * kBigBlock;
@@ -518,6 +523,8 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.v = rc_scene_view(s, total_threads);
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
     a.work_counter = reinterpret_cast<unsigned long long*>(rc_counter_slot(s));
+    a.chunk_counters = rc_counter_slot(s) + kShardBase;
+    a.n_shards = (uint32_t)s->opt.claim_shards;
     a.refill = (int)s->opt.refill;
     {
         a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail

@@ -32,13 +32,14 @@ struct TraceArgs {
     const RcRay* rays;
     RcHit* hits;
     uint64_t n_rays;
-    unsigned long long* work_counter;  // persistent kernel: next unclaimed ray index
+    unsigned long long* work_counter;  // persistent kernels 1 / 2: next unclaimed ray index
+    uint32_t* chunk_counters;          // phased kernels: the sharded chunk counters (PersistArgs::work_counter)
     int refill;                        // persistent kernel: refill when this many lanes are idle
     uint32_t pool;                     // persistent kernels: ray indices claimed per atomic
     int sched_thr;                     // scheduled kernel: run a leaf/entry batch once this many lanes wait for it
     unsigned long long* stats;         // optional instrumentation (dev builds), else nullptr
     uint32_t tail_div = 0;             // phased kernels: see PersistArgs
-    uint32_t blas_k = 0, lds_blas_base = 0, tlas_k = 0;
+    uint32_t blas_k = 0, lds_blas_base = 0, tlas_k = 0, n_shards = kClaimShards;
 };
 
 // Address-space-qualified pointers keep the two halves of the stack on their own instruction paths
@@ -281,7 +282,7 @@ __device__ inline float2 buf_f2(__amdgpu_buffer_rsrc_t r, uint32_t off, int soff
 // keeps it, inst = 0-based instance, -1 on a miss).
 struct PersistArgs {
     uint64_t n_items;                  // work items = rays
-    unsigned long long* work_counter;  // next unclaimed item
+    uint32_t* work_counter;            // kClaimShards chunk counters, kShardStrideWords apart: shard s hands out chunks s, s + kClaimShards, ... of `pool` items
     uint32_t pool;                     // items claimed per atomic
     int refill;                        // refill when this many lanes are free
     int int_thr;                       // leave the interior loop when fewer lanes than this have an interior node pending
@@ -290,6 +291,8 @@ struct PersistArgs {
     uint32_t blas_k = 0;               // TLAS_LDS kernels: BLAS nodes 1..blas_k are staged in the planes at entry lds_blas_base + node - 1
     uint32_t lds_blas_base = 0;
     uint32_t tlas_k = 0;               // PARTIAL_LDS kernels: TLAS nodes 1..tlas_k are staged at entry node - 1 (the rest comes from memory)
+    uint32_t n_shards = kClaimShards;  // chunk counters in use, a power of two (1 = a single counter, for A/B measurement)
+    uint32_t n_chunks = 0;             // ceil(n_items / pool), < 2^32
 };
 
 // TLAS_LDS / INST_LDS: the block has staged the top level in LDS before the call (LdsTop below; layout and sizes in rc_internal.h):
@@ -374,7 +377,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     // the node array addressed by 1-based node index: the base sits one record before element 0 (never dereferenced: index 0 is not a node)
     const __amdgpu_buffer_rsrc_t nrs1 = make_rsrc(reinterpret_cast<const char*>(av.blas_nodes) - 64, (av.n_nodes_total + 1u) * 64u);
     const __amdgpu_buffer_rsrc_t irs = make_rsrc(av.inst, av.n_inst * 64u);
-    unsigned long long pool_next = 0, pool_end = 0, seen = 0;
+    unsigned long long pool_next = 0, pool_end = 0;
     bool exhausted = false;
     uint64_t my_ray = 0;
     float3_ wo = mk3(0, 0, 0), wd = mk3(0, 0, 0), winv = mk3(0, 0, 0);
@@ -522,25 +525,21 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                     if (nf == 0) break;
                     if (pool_next == pool_end) {
                         if (exhausted) break;
-                        // Large claims keep a wave on neighbouring rays (coherent fetches); towards the end of the batch they would leave
-                        // some waves with a full slice while others have nothing, so the claim shrinks with what is left (guided
-                        // self-scheduling on the counter value this wave saw last).
-                        unsigned long long chunk = a.pool;
-                        if (a.tail_div) {
-                            unsigned long long c = ((a.n_items > seen ? a.n_items - seen : 0ull) / a.tail_div) & ~15ull;
-                            if (c < 16) c = 16;
-                            if (c < chunk) chunk = c;
-                        }
-                        unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(a.work_counter, chunk);
-                        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-                        unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-                        base = ((unsigned long long)hi << 32) | lo;
-                        if (base >= a.n_items) { exhausted = true; break; }
-                        pool_next = base;
-                        pool_end = base + chunk;
-                        seen = pool_end;
-                        if (pool_end >= a.n_items) { pool_end = a.n_items; exhausted = true; }
+                        // A claim is one chunk of `pool` consecutive items (large claims keep a wave on neighbouring rays: coherent
+                        // fetches).  The chunks are dealt out by n_shards counters -- shard s owns chunks s, s + n_shards, ... -- because
+                        // returning atomics on ONE address serialise at 12.6 ns each however many waves issue them.  A wave stays with
+                        // the shard it started on: the shards own the same number of interleaved chunks (+-1) and each is drained by
+                        // 1/n_shards of the waves, so they run dry together, and probing other counters at the end costs more (every
+                        // probe of a contended line queues behind the claims) than the few chunks' worth of imbalance it could recover.
+                        const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6) & (a.n_shards - 1u);  // wave-uniform (keeps the claim in scalar registers); n_shards is a power of two, neighbouring waves use different counters
+                        const uint32_t n_chunks = a.n_chunks;
+                        uint32_t c = 0;
+                        if (lane == 0) c = atomicAdd(a.work_counter + my_shard * kShardStrideWords, 1u);
+                        const uint32_t chunk_id = __builtin_amdgcn_readfirstlane(c) * a.n_shards + my_shard;
+                        if (chunk_id >= n_chunks) { exhausted = true; break; }
+                        pool_next = (unsigned long long)chunk_id * a.pool;
+                        pool_end = pool_next + a.pool;
+                        if (pool_end > a.n_items) pool_end = a.n_items;
                     }
                     const unsigned long long left = pool_end - pool_next;
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),

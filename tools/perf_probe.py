@@ -68,7 +68,7 @@ def main():
     wl = {"c2": ("C2 closest", t2, rays2, "closest"), "c3": ("C3 primary", t3, rays3, "closest"),
           "shadow": ("C3 shadow-any", t3, shadow, "any"), "c4": ("C4 bounce", t3, bounce, "closest")}
     wl.update(wl_extra)
-    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 36, "pool": 0, "tail": 1,
+    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 36, "pool": 0, "tail": 1, "claim_shards": 16,
                 }
     first_hits = {}
     for var in args.variants.split(";"):
@@ -106,6 +106,7 @@ def main():
                 else:
                     extra = (f" iters={v[0]} live/iter={v[1]/max(v[0],1):.1f} | I {v[2]} x{v[3]/max(v[2],1):.1f} | L {v[4]} x{v[5]/max(v[4],1):.1f}"
                              f" | E {v[6]} x{v[7]/max(v[6],1):.1f}")
+            extra += f" claims={t.get_option('claims')}"
             print(f"[{var:40s}] {name:14s} n={len(rays):9d} {ms:9.3f} ms  {len(rays)/ms/1e3:9.1f} Mrays/s  hit={hits['hit'].mean():.3f}{extra}", flush=True)
 
 
