@@ -166,7 +166,7 @@ int rc_trace_any_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, u
 
 /* Kernel selection for the trace entry points (tuning / A-B measurement).  The default is the tuned
  * kernel; every variant returns identical results.  Names: "kernel" (-1 auto, 0..6),
- * "blocks_per_cu", "lds_stack", "refill", "sched_thr", "pool", "tail" (scheduling knobs of the
+ * "blocks_per_cu", "lds_stack", "refill", "sched_thr", "pool", "claim_shards" (scheduling knobs of the
  * persistent kernels), "blas_top" (1 = a scene with a single BLAS keeps that BLAS's top internal
  * nodes in LDS; takes effect at the next structural rc_sync), "onesweep_min" (key count from which
  * the builds sort with Onesweep radix passes instead of a merge sort), "stats" (dev counters).

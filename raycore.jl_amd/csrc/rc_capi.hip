@@ -922,7 +922,6 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "refill") s->opt.refill = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (k == "stats") s->opt.stats = value;
     else if (k == "pool") s->opt.pool = value;
-    else if (k == "tail") s->opt.tail = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (k == "onesweep_min") s->opt.onesweep_min = value < 0 ? 0 : value;
     else if (k == "blas_top") s->opt.blas_top = value != 0;
     else if (k == "claim_shards") { int64_t p2 = 1; while (p2 * 2 <= value && p2 * 2 <= kClaimShards) p2 *= 2; s->opt.claim_shards = p2; }  // a power of two
@@ -939,7 +938,6 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "n_cus") *value = s->n_cus;
     else if (k == "lds_stack") *value = s->opt.lds_stack;
     else if (k == "refill") *value = s->opt.refill;
-    else if (k == "tail") *value = s->opt.tail;
     else if (k == "onesweep_min") *value = s->opt.onesweep_min;
     else if (k == "blas_top") *value = s->opt.blas_top;
     else if (k == "claims") {  // dev: claim atomics issued by the last phased launch (successful + failed)

@@ -96,7 +96,6 @@ struct TraceOptions {
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
     int64_t host_pipeline = 1; // host-buffer trace calls of >= 1 Mi rays overlap upload / trace / download in chunks
     int64_t claim_shards = 16; // phased kernels: chunk counters in use (a power of two <= kClaimShards)
-    int64_t tail = 1;          // phased kernels: claims shrink to remaining / (waves * tail) near the end of a batch (0 = fixed-size claims)
 };
 
 struct rc_scene {

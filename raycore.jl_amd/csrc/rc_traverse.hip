@@ -126,7 +126,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     const LdsTop top(smem + stack_bytes);
     if (a.v.n_tlas_nodes) stage_lds_top<BLOCK>(top, a.v, a.blas_k, a.lds_blas_base);
     __syncthreads();
-    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base, 0u, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
+    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, 0u, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
     phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kMidBlock, 6) void k_trace_phased_partial(TraceArgs
     top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
     stage_partial_top<kMidBlock>(top.tl, a.v, a.tlas_k, a.blas_k, a.lds_blas_base);
     __syncthreads();
-    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, a.blas_k, a.lds_blas_base, a.tlas_k, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
+    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, a.tlas_k, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
     phased_trace<ANY, kMidStack, false, ArraySource, HitWriter, kMidBlock, false, false, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
 template <bool ANY, int LDS_N, int MINW, bool STATS>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
     __shared__ uint32_t lds_stack[LDS_N * kBlock];
-    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.tail_div, 0u, 0u, 0u, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
+    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, 0u, 0u, 0u, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
     phased_trace<ANY, LDS_N, STATS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits});
 }
 
@@ -421,7 +421,6 @@ rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_th
     p.refill = (int)s->opt.refill;
     p.int_thr = (int)s->opt.sched_thr;
     p.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
-    p.tail_div = (uint32_t)((total_threads / 64) * (uint64_t)s->opt.tail);
     p.n_shards = (uint32_t)s->opt.claim_shards;
     p.n_chunks = (uint32_t)((n_items + p.pool - 1) / p.pool);
     return p;
@@ -531,7 +530,6 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     }
     a.sched_thr = (int)s->opt.sched_thr;
     a.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
-    a.tail_div = (uint32_t)((total_threads / 64) * (uint64_t)s->opt.tail);
     if ((s->opt.kernel == 5 || s->opt.kernel == 4) && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
     if (s->opt.kernel == 6) {  // a plan made for the full-LDS kernels (<= 256 instances) has no TLAS renumbering: tlas_k = 0, its blas_k still fits
         a.tlas_k = s->tlas_top_k; a.blas_k = s->opt.blas_top ? s->blas_top_k : 0; a.lds_blas_base = s->tlas_top_k;

@@ -38,7 +38,6 @@ struct TraceArgs {
     uint32_t pool;                     // persistent kernels: ray indices claimed per atomic
     int sched_thr;                     // scheduled kernel: run a leaf/entry batch once this many lanes wait for it
     unsigned long long* stats;         // optional instrumentation (dev builds), else nullptr
-    uint32_t tail_div = 0;             // phased kernels: see PersistArgs
     uint32_t blas_k = 0, lds_blas_base = 0, tlas_k = 0, n_shards = kClaimShards;
 };
 
@@ -287,7 +286,6 @@ struct PersistArgs {
     int refill;                        // refill when this many lanes are free
     int int_thr;                       // leave the interior loop when fewer lanes than this have an interior node pending
     unsigned long long* stats;
-    uint32_t tail_div = 0;             // guided self-scheduling: a claim takes min(pool, remaining / tail_div) items (0 = always `pool`)
     uint32_t blas_k = 0;               // TLAS_LDS kernels: BLAS nodes 1..blas_k are staged in the planes at entry lds_blas_base + node - 1
     uint32_t lds_blas_base = 0;
     uint32_t tlas_k = 0;               // PARTIAL_LDS kernels: TLAS nodes 1..tlas_k are staged at entry node - 1 (the rest comes from memory)
