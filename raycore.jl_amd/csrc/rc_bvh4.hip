@@ -225,7 +225,8 @@ struct Trace4Args {
     const RcRay* rays;
     RcHit* hits;
     uint64_t n_rays;
-    unsigned long long* work_counter;
+    uint32_t* chunk_counters;  // kClaimShards counters, kShardStrideWords apart (rc_internal.h)
+    uint32_t n_chunks;
     uint32_t pool;
     int refill, int_thr;
     uint32_t* overflow;
@@ -356,15 +357,15 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                     if (nf == 0) break;
                     if (pool_next == pool_end) {
                         if (exhausted) break;
-                        unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)a.pool);
-                        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-                        unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-                        base = ((unsigned long long)hi << 32) | lo;
-                        if (base >= a.n_rays) { exhausted = true; break; }
-                        pool_next = base;
-                        pool_end = base + a.pool;
-                        if (pool_end >= a.n_rays) { pool_end = a.n_rays; exhausted = true; }
+                        // sharded chunk counters, as in phased_trace (rc_traverse_core.h): one counter serialises every claim at 12.6 ns
+                        const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6) & (kClaimShards - 1u);
+                        uint32_t c = 0;
+                        if (lane == 0) c = atomicAdd(a.chunk_counters + my_shard * kShardStrideWords, 1u);
+                        const uint32_t chunk_id = __builtin_amdgcn_readfirstlane(c) * kClaimShards + my_shard;
+                        if (chunk_id >= a.n_chunks) { exhausted = true; break; }
+                        pool_next = (unsigned long long)chunk_id * a.pool;
+                        pool_end = pool_next + a.pool;
+                        if (pool_end > a.n_rays) pool_end = a.n_rays;
                     }
                     const unsigned long long left = pool_end - pool_next;
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_mask, 0u));
@@ -470,8 +471,11 @@ void rc_launch_trace4(rc_scene* s, const Blas& b, const RcRay* d_rays, RcHit* d_
     Trace4Args a;
     a.nodes = b.nodes4.p; a.n_nodes = b.n_nodes4; a.root_word = b.root_word4; a.n_prims = b.n_prims;
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
-    a.work_counter = reinterpret_cast<unsigned long long*>(rc_counter_slot(s));
-    a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
+    a.chunk_counters = rc_counter_slot(s) + kShardBase;
+    a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);
+    a.n_chunks = (uint32_t)((n + a.pool - 1) / a.pool);
+    if (n >= (1ull << 38)) throw RcError(1, "ray batches of 2^38 rays or more are not supported by the BVH4 kernels");
+     // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
     a.refill = (int)s->opt.refill;
     a.int_thr = (int)s->opt.sched_thr;
     a.overflow = s->cur_overflow; a.total_threads = total_threads;
