@@ -504,7 +504,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     uint32_t total_threads = blocks * kBlock;
     const int64_t saved_kernel = s->opt.kernel;
     if (saved_kernel < 0)  // auto: tiny batches gain nothing from refilling; a TLAS that fits the LDS planes (<= 256 instances) is read from there
-        s->opt.kernel = (n < (uint64_t)total_threads * 2) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 6);
+        s->opt.kernel = (n < (uint64_t)total_threads * 5 / 4) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 6);  // measured crossover (tools/small_batch_probe.py): ~1.2 rays per resident lane
     if (s->opt.kernel == 4 && (s->n_tlas_nodes > (uint32_t)kTlasLdsNodes || s->n_static_instances > (uint32_t)kTlasLdsInst)) s->opt.kernel = 3;
     if (s->opt.kernel == 5 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes) s->opt.kernel = 3;
     if (s->opt.kernel == 6 && s->tlas_top_k + s->blas_top_k == 0) s->opt.kernel = 3;  // nothing to stage
