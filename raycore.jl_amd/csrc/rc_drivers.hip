@@ -62,16 +62,42 @@ struct GridSource {
     uint64_t first;
     __device__ inline RcRay operator()(uint64_t i) const { return grid_ray(g, first + i); }
 };
+// Counting into an accumulator array from inside a wave.  An atomic on ONE address costs ~12.7 ns on this chip whether or not it
+// returns a value and however many lanes issue it (tools/atomic_probe.hip), so a driver whose rays mostly land on a few large
+// triangles (a ground plane under get_illumination: 10^5 hits on one counter = milliseconds) would be bound by that one word.
+// The lanes that finish together first combine equal targets: up to four rounds of "the first pending lane's target, everyone
+// with the same target, one atomic of the group's size"; whatever is still pending (the common case of all-different targets, where
+// the rounds cost a few dozen instructions per write-out) adds its own 1.  Called by the active (finishing, counted) lanes only.
+template <class T>
+__device__ inline void wave_count(T* acc, unsigned long long index, bool counted) {
+    bool pending = counted;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const unsigned long long act = __ballot(pending);
+        if (!act) return;
+        const int leader = __ffsll((long long)act) - 1;
+        const unsigned lo = __shfl((unsigned)index, leader), hi = __shfl((unsigned)(index >> 32), leader);
+        const bool same = pending && index == (((unsigned long long)hi << 32) | lo);
+        const unsigned long long grp = __ballot(same);
+        if ((int)(threadIdx.x & 63u) == leader) atomicAdd(acc + index, (T)__popcll(grp));
+        pending = pending && !same;
+    }
+    if (pending) atomicAdd(acc + index, (T)1);
+}
+
 struct HistogramSink {
     const RcInstRec* inst;
     const RcPrim* prims;
     uint32_t n_prims;
     float* counts;
     __device__ inline void operator()(uint64_t, bool hit, float, float, float, uint32_t prim, int instance) const {
-        if (!hit) return;
-        const uint4 m3 = *(reinterpret_cast<const uint4*>(inst + instance) + 3);
-        const uint32_t meta = prims[m3.y + prim - 1u].meta;
-        if (meta >= 1 && meta <= n_prims) atomicAdd(&counts[meta - 1], 1.0f);
+        uint32_t meta = 0;
+        if (hit) {
+            const uint4 m3 = *(reinterpret_cast<const uint4*>(inst + instance) + 3);
+            meta = prims[m3.y + prim - 1u].meta;
+        }
+        const bool counted = hit && meta >= 1 && meta <= n_prims;  // metadata outside 1..N is dropped (src/kernels.jl:123)
+        wave_count(counts, counted ? (unsigned long long)(meta - 1) : 0ull, counted);  // f32 counts: exact below 2^24 per triangle, like the reference's
     }
 };
 __global__ __launch_bounds__(kBlock, 6) void k_illumination(SceneView v, PersistArgs p, GridParams g, uint64_t ray_begin, float* counts) {
@@ -203,12 +229,16 @@ struct ViewFactorSink {
     uint64_t row_stride, col_stride;
     uint32_t row_offset, flags;
     __device__ inline void operator()(uint64_t w, bool hit, float, float, float, uint32_t prim, int instance) const {
-        if (!hit) return;
-        const uint32_t src = src_begin + (uint32_t)(w / n_ray);
-        const uint4 m3 = *(reinterpret_cast<const uint4*>(inst + instance) + 3);
-        const uint32_t hit_meta = prims[m3.y + prim - 1u].meta, src_meta = prims[src].meta;
-        if (hit_meta != src_meta && src_meta >= 1 && src_meta <= n_prims && hit_meta >= 1 && hit_meta <= n_prims)
-            atomicAdd(&matrix[(uint64_t)(((flags & 1u) ? src : src_meta - 1) - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride], 1u);
+        bool counted = false;
+        unsigned long long index = 0;
+        if (hit) {
+            const uint32_t src = src_begin + (uint32_t)(w / n_ray);
+            const uint4 m3 = *(reinterpret_cast<const uint4*>(inst + instance) + 3);
+            const uint32_t hit_meta = prims[m3.y + prim - 1u].meta, src_meta = prims[src].meta;
+            counted = hit_meta != src_meta && src_meta >= 1 && src_meta <= n_prims && hit_meta >= 1 && hit_meta <= n_prims;
+            if (counted) index = (uint64_t)(((flags & 1u) ? src : src_meta - 1) - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride;
+        }
+        wave_count(matrix, index, counted);
     }
 };
 __global__ __launch_bounds__(kBlock, 6) void k_view_factors(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin,

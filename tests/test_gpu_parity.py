@@ -574,6 +574,21 @@ def test_ray_grid_and_illumination_parity(rc, oracle):
         assert got.sum() == np.count_nonzero(metas <= len(got))  # metadata outside 1..N is dropped (src/kernels.jl:123)
 
 
+def test_illumination_hot_counters(rc, oracle):
+    """Most rays land on two large triangles: the histogram's wave-level aggregation (equal targets among the lanes that finish
+    together become one atomic) must still give the reference's counts exactly."""
+    sc = rc.scenes
+    ground = np.array([[-50, -50, 0, 50, -50, 0, 50, 50, 0], [-50, -50, 0, 50, 50, 0, -50, 50, 0]], dtype=np.float32)
+    verts = np.concatenate([ground, sc.fan_sphere(24, 13, centre=(0, 0, 3), radius=2.0)]).astype(np.float32)
+    cfg = {"blas": [(verts, np.arange(1, len(verts) + 1, dtype=np.uint32))], "instances": [(1, sc.IDENTITY3x4[None], np.zeros(1, np.uint32))]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    got, want = rc.get_illumination(t, [0.05, 0.02, -1.0], 400), o.get_illumination([0.05, 0.02, -1.0], 400, nthreads=8)
+    assert np.array_equal(got, want) and got[:2].sum() > 0.5 * got.sum() > 0
+    t.set_option("kernel", 3)
+    assert np.array_equal(rc.get_illumination(t, [0.05, 0.02, -1.0], 400), want)
+    t.free()
+
+
 def test_hits_from_grid_and_centroid(rc, oracle):  # src/kernels.jl:58-72, 106-110
     cfg = rc.scenes.config_c1()
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)

@@ -11,6 +11,10 @@ __global__ void k32(unsigned int* c, int reps, int shards, int stride_words, uns
     }
     if (acc == 0xdeadbeefull) sink[0] = acc;
 }
+__global__ void k_noret(float* c, int per_lane, int n_addr) {  // every lane: non-returning float atomics, addresses spread over n_addr words
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int r = 0; r < per_lane; ++r) atomicAdd(c + ((t * 2654435761u + r) % (unsigned)n_addr), 1.0f);
+}
 __global__ void k(unsigned long long* c, int reps, int shards, int stride_words, unsigned long long* sink) {
     const int lane = threadIdx.x & 63;
     unsigned long long acc = 0;
@@ -36,6 +40,17 @@ int main() {
             float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
         }
         printf("6144 waves x %d atomics, %d counter(s) %d B apart: %.1f us  (%.1f ns per atomic)\n", reps, shards, stride * 8, best * 1e3, best * 1e6 / (6144.0 * reps));
+    }
+    for (int n_addr : {1, 16, 1024, 1 << 20}) {
+        float best = 1e9;
+        for (int it = 0; it < 3; ++it) {
+            hipMemset(c, 0, 1 << 20);
+            hipEventRecord(a);
+            hipLaunchKernelGGL(k_noret, dim3(4096), dim3(256), 0, 0, (float*)c, 1, n_addr > (1 << 18) ? (1 << 18) : n_addr);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+        }
+        printf("1 Mi non-returning f32 atomics over %d address(es): %.1f us (%.2f ns each)\n", n_addr, best * 1e3, best * 1e6 / (4096.0 * 256));
     }
     for (int shards : {1, 16}) {
         float best = 1e9;
