@@ -66,8 +66,8 @@ struct GridSource {
 // returns a value and however many lanes issue it (tools/atomic_probe.hip), so a driver whose rays mostly land on a few large
 // triangles (a ground plane under get_illumination: 10^5 hits on one counter = milliseconds) would be bound by that one word.
 // The lanes that finish together first combine equal targets: up to four rounds of "the first pending lane's target, everyone
-// with the same target, one atomic of the group's size"; whatever is still pending (the common case of all-different targets, where
-// the rounds cost a few dozen instructions per write-out) adds its own 1.  Called by the active (finishing, counted) lanes only.
+// with the same target, one atomic of the group's size", stopping at the first group of one (the common case of all-different
+// targets then costs a single round); whatever is still pending adds its own 1.  Called by the active (finishing, counted) lanes only.
 template <class T>
 __device__ inline void wave_count(T* acc, unsigned long long index, bool counted) {
     bool pending = counted;
@@ -81,6 +81,7 @@ __device__ inline void wave_count(T* acc, unsigned long long index, bool counted
         const unsigned long long grp = __ballot(same);
         if ((int)(threadIdx.x & 63u) == leader) atomicAdd(acc + index, (T)__popcll(grp));
         pending = pending && !same;
+        if (__popcll(grp) == 1) break;  // a group of one: the targets are probably all different, stop looking for duplicates
     }
     if (pending) atomicAdd(acc + index, (T)1);
 }
