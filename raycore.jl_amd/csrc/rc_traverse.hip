@@ -75,15 +75,15 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
                 if (n_idle == 0) break;
                 if (pool_next == pool_end) {
                     if (exhausted) break;
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)a.pool);
-                    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-                    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-                    base = ((unsigned long long)hi << 32) | lo;
-                    if (base >= a.n_rays) { exhausted = true; break; }
-                    pool_next = base;
-                    pool_end = base + a.pool;
-                    if (pool_end >= a.n_rays) { pool_end = a.n_rays; exhausted = true; }
+                    // one chunk of a.pool rays from this wave's shard of the interleaved chunk counters (see phased_trace)
+                    const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6) & (a.n_shards - 1u);
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(a.chunk_counters + my_shard * kShardStrideWords, 1u);
+                    const uint32_t chunk_id = __builtin_amdgcn_readfirstlane(c) * a.n_shards + my_shard;
+                    if (chunk_id >= (uint32_t)((a.n_rays + a.pool - 1) / a.pool)) { exhausted = true; break; }
+                    pool_next = (unsigned long long)chunk_id * a.pool;
+                    pool_end = pool_next + a.pool;
+                    if (pool_end > a.n_rays) pool_end = a.n_rays;
                 }
                 const unsigned long long left = pool_end - pool_next;
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
@@ -227,15 +227,15 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                 if (n_free == 0) break;
                 if (pool_next == pool_end) {
                     if (exhausted) break;
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)a.pool);
-                    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-                    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-                    base = ((unsigned long long)hi << 32) | lo;
-                    if (base >= a.n_rays) { exhausted = true; break; }
-                    pool_next = base;
-                    pool_end = base + a.pool;
-                    if (pool_end >= a.n_rays) { pool_end = a.n_rays; exhausted = true; }
+                    // one chunk of a.pool rays from this wave's shard of the interleaved chunk counters (see phased_trace)
+                    const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6) & (a.n_shards - 1u);
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(a.chunk_counters + my_shard * kShardStrideWords, 1u);
+                    const uint32_t chunk_id = __builtin_amdgcn_readfirstlane(c) * a.n_shards + my_shard;
+                    if (chunk_id >= (uint32_t)((a.n_rays + a.pool - 1) / a.pool)) { exhausted = true; break; }
+                    pool_next = (unsigned long long)chunk_id * a.pool;
+                    pool_end = pool_next + a.pool;
+                    if (pool_end > a.n_rays) pool_end = a.n_rays;
                 }
                 const unsigned long long left = pool_end - pool_next;
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
@@ -521,7 +521,6 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     TraceArgs a;
     a.v = rc_scene_view(s, total_threads);
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
-    a.work_counter = reinterpret_cast<unsigned long long*>(rc_counter_slot(s));
     a.chunk_counters = rc_counter_slot(s) + kShardBase;
     a.n_shards = (uint32_t)s->opt.claim_shards;
     a.refill = (int)s->opt.refill;

@@ -32,8 +32,7 @@ struct TraceArgs {
     const RcRay* rays;
     RcHit* hits;
     uint64_t n_rays;
-    unsigned long long* work_counter;  // persistent kernels 1 / 2: next unclaimed ray index
-    uint32_t* chunk_counters;          // phased kernels: the sharded chunk counters (PersistArgs::work_counter)
+    uint32_t* chunk_counters;          // persistent kernels: the sharded chunk counters (PersistArgs::work_counter; rc_internal.h)
     int refill;                        // persistent kernel: refill when this many lanes are idle
     uint32_t pool;                     // persistent kernels: ray indices claimed per atomic
     int sched_thr;                     // scheduled kernel: run a leaf/entry batch once this many lanes wait for it
