@@ -462,12 +462,12 @@ int rc_wait(rc_scene* s) {
         // asynchronous launches (the *_device entry points) cannot report a traversal-stack overflow themselves: their status words
         // (one per launch slot) are collected here
         if (s->counters.p) {
-            std::vector<uint32_t> words((size_t)kCounterSlots * kCounterSlotWords);
-            RC_HIP(hipMemcpy(words.data(), s->counters.p, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            uint32_t status[kCounterSlots];  // word 4 of every slot, gathered with one strided copy
+            RC_HIP(hipMemcpy2D(status, sizeof(uint32_t), s->counters.p + 4, (size_t)kCounterSlotWords * sizeof(uint32_t), sizeof(uint32_t), kCounterSlots, hipMemcpyDeviceToHost));
             bool overflow = false;
-            for (int slot = 0; slot < kCounterSlots; ++slot) overflow |= words[(size_t)slot * kCounterSlotWords + 4] != 0;
+            for (int slot = 0; slot < kCounterSlots; ++slot) overflow |= status[slot] != 0;
             if (overflow) {
-                RC_HIP(hipMemset(s->counters.p, 0, words.size() * sizeof(uint32_t)));
+                RC_HIP(hipMemset(s->counters.p, 0, (size_t)kCounterSlots * kCounterSlotWords * sizeof(uint32_t)));
                 throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow in an earlier asynchronous launch (tree deeper than 128 levels)");
             }
         }
