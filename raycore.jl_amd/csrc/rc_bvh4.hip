@@ -361,7 +361,8 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                         const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6) & (kClaimShards - 1u);
                         uint32_t c = 0;
                         if (lane == 0) c = atomicAdd(a.chunk_counters + my_shard * kShardStrideWords, 1u);
-                        const uint32_t chunk_id = __builtin_amdgcn_readfirstlane(c) * kClaimShards + my_shard;
+                        const uint32_t cs = __builtin_amdgcn_readfirstlane(c);
+                        const uint32_t chunk_id = cs * kClaimShards + ((my_shard + cs * 5u) & (kClaimShards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
                         if (chunk_id >= a.n_chunks) { exhausted = true; break; }
                         pool_next = (unsigned long long)chunk_id * a.pool;
                         pool_end = pool_next + a.pool;

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
                     const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6) & (a.n_shards - 1u);
                     uint32_t c = 0;
                     if (lane == 0) c = atomicAdd(a.chunk_counters + my_shard * kShardStrideWords, 1u);
-                    const uint32_t chunk_id = __builtin_amdgcn_readfirstlane(c) * a.n_shards + my_shard;
+                    const uint32_t cs = __builtin_amdgcn_readfirstlane(c);
+                        const uint32_t chunk_id = cs * a.n_shards + ((my_shard + cs * 5u) & (a.n_shards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
                     if (chunk_id >= (uint32_t)((a.n_rays + a.pool - 1) / a.pool)) { exhausted = true; break; }
                     pool_next = (unsigned long long)chunk_id * a.pool;
                     pool_end = pool_next + a.pool;
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                     const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6) & (a.n_shards - 1u);
                     uint32_t c = 0;
                     if (lane == 0) c = atomicAdd(a.chunk_counters + my_shard * kShardStrideWords, 1u);
-                    const uint32_t chunk_id = __builtin_amdgcn_readfirstlane(c) * a.n_shards + my_shard;
+                    const uint32_t cs = __builtin_amdgcn_readfirstlane(c);
+                        const uint32_t chunk_id = cs * a.n_shards + ((my_shard + cs * 5u) & (a.n_shards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
                     if (chunk_id >= (uint32_t)((a.n_rays + a.pool - 1) / a.pool)) { exhausted = true; break; }
                     pool_next = (unsigned long long)chunk_id * a.pool;
                     pool_end = pool_next + a.pool;

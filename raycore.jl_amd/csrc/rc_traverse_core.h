@@ -523,7 +523,9 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                     if (pool_next == pool_end) {
                         if (exhausted) break;
                         // A claim is one chunk of `pool` consecutive items (large claims keep a wave on neighbouring rays: coherent
-                        // fetches).  The chunks are dealt out by n_shards counters -- shard s owns chunks s, s + n_shards, ... -- because
+                        // fetches).  The chunks are dealt out by n_shards counters -- in round c of a shard's counter the shards share chunks
+                        // c * n .. c * n + n - 1, which of them a shard gets rotating with c: with a fixed assignment a shard would own one
+                        // column band of a 2048-ray-wide image, and bands differ in cost by 2x -- because
                         // returning atomics on ONE address serialise at 12.6 ns each however many waves issue them.  A wave stays with
                         // the shard it started on: the shards own the same number of interleaved chunks (+-1) and each is drained by
                         // 1/n_shards of the waves, so they run dry together, and probing other counters at the end costs more (every
@@ -532,7 +534,8 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         const uint32_t n_chunks = a.n_chunks;
                         uint32_t c = 0;
                         if (lane == 0) c = atomicAdd(a.work_counter + my_shard * kShardStrideWords, 1u);
-                        const uint32_t chunk_id = __builtin_amdgcn_readfirstlane(c) * a.n_shards + my_shard;
+                        const uint32_t cs = __builtin_amdgcn_readfirstlane(c);
+                        const uint32_t chunk_id = cs * a.n_shards + ((my_shard + cs * 5u) & (a.n_shards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
                         if (chunk_id >= n_chunks) { exhausted = true; break; }
                         pool_next = (unsigned long long)chunk_id * a.pool;
                         pool_end = pool_next + a.pool;
