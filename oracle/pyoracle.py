@@ -87,6 +87,9 @@ def lib():
         L.rco_get_illumination.argtypes = [vp, vp, u32, vp, C.c_int]
         L.rco_view_factors.argtypes = [vp, u32, u64, u32, u32, u32, u32, vp, C.c_int]
         L.rco_view_factor_ray.argtypes = [vp, u32, u32, u64, vp]
+        L.rco_view_factor_row.argtypes = [vp, u32, u64, u32, u32, u32, vp]
+        L.rco_trace_events.restype = u32
+        L.rco_trace_events.argtypes = [vp, vp, C.c_int, vp, vp, u32]
         L.rco_hit_points.argtypes = [vp, vp, vp, u64, vp, vp]
         L.rco_shadow_rays.argtypes = [vp, vp, vp, u64, vp, C.c_float, vp]
         L.rco_blas4_nodes.restype = u32
@@ -272,6 +275,20 @@ class Scene:
         r0, r1 = (0, rays_per_triangle) if rays is None else rays
         lib().rco_view_factors(self._h, rays_per_triangle, seed, s0, s1, r0, r1, _p(out), nthreads)
         return out
+
+    def view_factor_row(self, rays_per_triangle, src_idx0, seed=0, rays=None):
+        """Row of source primitive src_idx0 (0-based flat index) as a compact vector: row[hit_meta - 1] = counted rays."""
+        row = np.zeros(len(self.blas_prims), dtype=np.uint32)
+        r0, r1 = (0, rays_per_triangle) if rays is None else rays
+        lib().rco_view_factor_row(self._h, rays_per_triangle, seed, src_idx0, r0, r1, _p(row))
+        return row
+
+    def trace_events(self, ray, mode="closest", cap=4096):
+        """dev: (events, depths) byte arrays of one ray's traversal steps (tools/sched_sim.py)."""
+        ray = np.ascontiguousarray(ray, dtype=RAY_DT).reshape(1)
+        ev, dp = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        n = lib().rco_trace_events(self._h, _p(ray), 0 if mode == "closest" else 1, _p(ev), _p(dp), cap)
+        return ev[:min(n, cap)], dp[:min(n, cap)]
 
     def hit_points(self, rays, hits):
         pts, nrm = np.zeros((len(rays), 3), np.float32), np.zeros((len(rays), 3), np.float32)

@@ -582,6 +582,14 @@ static uint32_t* g_hist_tlas = NULL;
 static uint32_t* g_hist_blas = NULL;
 void rco_set_histograms(uint32_t* tlas, uint32_t* blas) { g_hist_tlas = tlas; g_hist_blas = blas; }
 static int32_t g_max_sp = 0;  /* dev: deepest stack seen (single-threaded use) */
+/* dev: per-step event trace of one ray (tools/sched_sim.py replays these through wave-scheduling policies).  One byte per loop
+ * iteration: low 3 bits = kind (0 TLAS interior, 1 BLAS interior, 2 instance entry, 3 leaf miss, 4 leaf hit), 0x20 = pushed the far
+ * child, 0x40 = popped (no near child / after a leaf), 0x80 = that pop returned to the top level (sentinel); a second byte array
+ * gets the stack depth after the step. */
+static __thread uint8_t* tl_ev = NULL;
+static __thread uint8_t* tl_ev_sp = NULL;
+static __thread uint32_t tl_ev_cap = 0, tl_ev_n = 0;
+#define EV_PUT(code, depth) do { if (tl_ev) { if (tl_ev_n < tl_ev_cap) { tl_ev[tl_ev_n] = (uint8_t)(code); if (tl_ev_sp) tl_ev_sp[tl_ev_n] = (uint8_t)((depth) > 255 ? 255 : (depth)); } ++tl_ev_n; } } while (0)
 int32_t rco_max_stack(int reset) { int32_t v = g_max_sp; if (reset) g_max_sp = 0; return v; }
 
 static void set_miss(rco_hit* h) {
@@ -618,11 +626,13 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
         ++n_node;
         if (g_hist_tlas) { if (current_instance < 0) g_hist_tlas[node_index - 1]++; else g_hist_blas[current_blas_offset + node_index - 1]++; }
         int is_leaf = node->child0 == RCO_INVALID_NODE;
+        uint32_t ev = 0;
         if (!is_leaf) {
             uint32_t near_c, far_c;
             intersect_internal_node(node, ray_inv_d, ray_o, ray_mint, ray_maxt, &near_c, &far_c);
-            if (far_c != RCO_INVALID_NODE) { if (sp < RCO_STACK) stack[sp++] = far_c; if (sp > g_max_sp) g_max_sp = sp; }
-            if (near_c != RCO_INVALID_NODE) { node_index = near_c; continue; }
+            ev = current_instance < 0 ? 0u : 1u;
+            if (far_c != RCO_INVALID_NODE) { if (sp < RCO_STACK) stack[sp++] = far_c; if (sp > g_max_sp) g_max_sp = sp; ev |= 0x20u; }
+            if (near_c != RCO_INVALID_NODE) { node_index = near_c; EV_PUT(ev, sp); continue; }
         } else if (current_instance < 0) {
             current_instance = (int32_t)node->child1;
             if (sp < RCO_STACK) stack[sp++] = RCO_TOP_LEVEL_SENTINEL;
@@ -634,9 +644,11 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
             ray_o = xf_point(inst->inv_transform, world_o);
             ray_d = xf_dir(inst->inv_transform, world_d);
             ray_inv_d = safe_invdir(ray_d);
+            EV_PUT(2u, sp);
             continue;
         } else {
             float t, u, v;
+            ev = 3u;
             int hit = fast_intersect_triangle(ray_o, ray_d, v3_from(node->aabb0_min), v3_from(node->aabb0_max),
                                               v3_from(node->aabb1_min), ray_mint, ray_maxt, &t, &u, &v);
             if (hit) {
@@ -648,19 +660,24 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
                     out->instance_id = (uint32_t)current_instance;
                     out->instance_custom_index = inst->instance_id;
                     if (counters) { counters[0] += n_node; counters[1] += n_inst; }
+                    EV_PUT(4u, sp);
                     return;
                 }
+                ev = 4u;
                 ray_maxt = t; closest_instance = current_instance; closest_prim = node->child1;
                 hit_u = u; hit_v = v;
             }
         }
         node_index = stack[--sp];
+        ev |= 0x40u;
         if (node_index == RCO_TOP_LEVEL_SENTINEL) { /* :1996-2006 */
             node_index = stack[--sp];
             current_instance = -1;
             ray_o = world_o; ray_d = world_d;
             ray_inv_d = safe_invdir(ray_d);
+            ev |= 0x80u;
         }
+        EV_PUT(ev, sp);
     }
     if (counters) { counters[0] += n_node; counters[1] += n_inst; }
     if (!any && closest_instance >= 0) { /* :2010-2017 */
@@ -674,6 +691,14 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
 }
 
 void rco_closest_hit(const rco_scene* s, const rco_ray* r, rco_hit* h, uint32_t* c) { traverse(s, r, h, c, 0); }
+/* dev: trace one ray and record its step events (see tl_ev); returns the number of steps (may exceed cap: then only cap were stored) */
+uint32_t rco_trace_events(const rco_scene* s, const rco_ray* r, int any, uint8_t* events, uint8_t* depths, uint32_t cap) {
+    rco_hit h;
+    tl_ev = events; tl_ev_sp = depths; tl_ev_cap = cap; tl_ev_n = 0;
+    traverse(s, r, &h, NULL, any);
+    tl_ev = NULL; tl_ev_sp = NULL;
+    return tl_ev_n;
+}
 void rco_any_hit(const rco_scene* s, const rco_ray* r, rco_hit* h, uint32_t* c) { traverse(s, r, h, c, 1); }
 
 void rco_brute_closest(const rco_scene* s, const rco_ray* r, rco_hit* out) {
@@ -703,22 +728,74 @@ void rco_brute_closest(const rco_scene* s, const rco_ray* r, rco_hit* out) {
  * pthread parallel-for (stands in for Threads.@threads, src/kernels.jl:64,82)
  * ---------------------------------------------------------------------------------------------- */
 typedef void (*range_fn)(void* ctx, uint64_t begin, uint64_t end);
-typedef struct { range_fn fn; void* ctx; uint64_t begin, end; } pf_job;
-static void* pf_main(void* p) { pf_job* j = (pf_job*)p; j->fn(j->ctx, j->begin, j->end); return NULL; }
-static void parallel_for(uint64_t n, int nthreads, range_fn fn, void* ctx) {
-    if (nthreads < 1) nthreads = 1;
-    if ((uint64_t)nthreads > n) nthreads = n ? (int)n : 1;
-    if (nthreads == 1) { fn(ctx, 0, n); return; }
-    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
-    pf_job* jobs = (pf_job*)malloc(sizeof(pf_job) * nthreads);
-    for (int t = 0; t < nthreads; ++t) {
-        jobs[t].fn = fn; jobs[t].ctx = ctx;
-        jobs[t].begin = n * (uint64_t)t / nthreads; jobs[t].end = n * (uint64_t)(t + 1) / nthreads;
-        pthread_create(&th[t], NULL, pf_main, &jobs[t]);
+/* A persistent pool: workers are created once (lazily, grown on demand) and parked on a condition variable between calls, and a
+ * call's range is handed out in dynamic chunks from one atomic cursor -- rays differ a lot in cost, so a static partition leaves
+ * most threads idle behind the slowest slice, and creating + joining 256 threads per call costs more than a 4 M-ray pass is worth.
+ * Calls are serialised by pf_call_mutex (the oracle is test infrastructure; concurrent callers simply queue). */
+#define PF_MAX_THREADS 1024
+#define PF_CHUNK 4096
+static pthread_mutex_t pf_call_mutex = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t pf_mutex = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t pf_start = PTHREAD_COND_INITIALIZER, pf_done = PTHREAD_COND_INITIALIZER;
+static pthread_t pf_threads[PF_MAX_THREADS];
+static int pf_n_threads = 0;           /* workers created so far */
+static uint64_t pf_generation = 0;     /* bumped per call */
+static int pf_want = 0, pf_running = 0;/* workers taking part in the current call / still inside it */
+static range_fn pf_fn; static void* pf_ctx; static uint64_t pf_n, pf_chunk;
+static volatile uint64_t pf_cursor;
+static void pf_drain(void) {
+    for (;;) {
+        uint64_t b = __atomic_fetch_add(&pf_cursor, pf_chunk, __ATOMIC_RELAXED);
+        if (b >= pf_n) return;
+        uint64_t e = b + pf_chunk < pf_n ? b + pf_chunk : pf_n;
+        pf_fn(pf_ctx, b, e);
     }
-    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
-    free(th); free(jobs);
 }
+static void* pf_worker(void* arg) {
+    const int id = (int)(intptr_t)arg;
+    uint64_t seen = 0;
+    pthread_mutex_lock(&pf_mutex);
+    for (;;) {
+        while (pf_generation == seen || id >= pf_want) {
+            seen = pf_generation; /* a call this worker is not part of (or none): nothing to do for it */
+            pthread_cond_wait(&pf_start, &pf_mutex);
+        }
+        seen = pf_generation;
+        pthread_mutex_unlock(&pf_mutex);
+        pf_drain();
+        pthread_mutex_lock(&pf_mutex);
+        if (--pf_running == 0) pthread_cond_signal(&pf_done);
+    }
+    return NULL;
+}
+static void parallel_for_chunked(uint64_t n, int nthreads, uint64_t chunk, range_fn fn, void* ctx) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > PF_MAX_THREADS) nthreads = PF_MAX_THREADS;
+    if (chunk < 1) chunk = 1;
+    if ((uint64_t)nthreads > (n + chunk - 1) / chunk) nthreads = n ? (int)((n + chunk - 1) / chunk) : 1;
+    if (nthreads == 1) { fn(ctx, 0, n); return; }
+    pthread_mutex_lock(&pf_call_mutex);
+    pthread_mutex_lock(&pf_mutex);
+    const int helpers = nthreads - 1;  /* the calling thread works too */
+    while (pf_n_threads < helpers) {
+        if (pthread_create(&pf_threads[pf_n_threads], NULL, pf_worker, (void*)(intptr_t)pf_n_threads) != 0) break;
+        pthread_detach(pf_threads[pf_n_threads]);
+        ++pf_n_threads;
+    }
+    pf_fn = fn; pf_ctx = ctx; pf_n = n; pf_chunk = chunk; pf_cursor = 0;
+    pf_want = helpers < pf_n_threads ? helpers : pf_n_threads;
+    pf_running = pf_want;
+    ++pf_generation;
+    pthread_cond_broadcast(&pf_start);
+    pthread_mutex_unlock(&pf_mutex);
+    pf_drain();
+    pthread_mutex_lock(&pf_mutex);
+    while (pf_running > 0) pthread_cond_wait(&pf_done, &pf_mutex);
+    pf_want = 0;
+    pthread_mutex_unlock(&pf_mutex);
+    pthread_mutex_unlock(&pf_call_mutex);
+}
+static void parallel_for(uint64_t n, int nthreads, range_fn fn, void* ctx) { parallel_for_chunked(n, nthreads, PF_CHUNK, fn, ctx); }
 
 typedef struct { const rco_scene* s; const rco_ray* rays; rco_hit* hits; int mode; uint32_t* counters; } trace_ctx;
 static void trace_range(void* p, uint64_t b, uint64_t e) {
@@ -906,13 +983,33 @@ static void vf_range(void* p, uint64_t b, uint64_t e) {
         }
     }
 }
+/* One source primitive's row of the matrix as a compact N-vector: row[hit_meta - 1] += 1 per counted ray (view_factors! :85-97 for a
+ * single src; lets a test check rows of a 50 k x 50 k matrix without allocating it).  `src` = 0-based flat (Morton-sorted) primitive. */
+void rco_view_factor_row(const rco_scene* s, uint32_t rpt, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t ray_end, uint32_t* row) {
+    const uint32_t N = s->n_blas_prims;
+    if (src >= N) return;
+    if (ray_end > rpt) ray_end = rpt;
+    const uint32_t tri_idx = s->blas_prims[src].meta;
+    for (uint32_t i = ray_begin; i < ray_end; ++i) {
+        rco_ray ray; rco_hit hit;
+        rco_view_factor_ray(s, src, i, seed, &ray);
+        traverse(s, &ray, &hit, NULL, 0);
+        if (!hit.hit) continue;
+        const uint32_t hit_idx = s->blas_prims[hit.primitive_id].meta;
+        if (hit_idx != tri_idx && tri_idx >= 1 && tri_idx <= N && hit_idx >= 1 && hit_idx <= N) row[hit_idx - 1] += 1u;
+    }
+}
 void rco_view_factors(const rco_scene* s, uint32_t rpt, uint64_t seed, uint32_t src_begin, uint32_t src_end,
                       uint32_t ray_begin, uint32_t ray_end, uint32_t* out, int nthreads) {
     if (src_end > s->n_blas_prims) src_end = s->n_blas_prims;
     if (ray_end > rpt) ray_end = rpt;
     if (src_begin >= src_end || ray_begin >= ray_end) return;
     vf_ctx c = {s, rpt, seed, src_begin, ray_begin, ray_end, out};
-    parallel_for(src_end - src_begin, nthreads, vf_range, &c);
+    {   /* one item = all rays of one source triangle: hand sources out a few at a time */
+        const uint64_t n_src = src_end - src_begin;
+        uint64_t chunk = n_src / ((uint64_t)(nthreads > 0 ? nthreads : 1) * 16u);
+        parallel_for_chunked(n_src, nthreads, chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk), vf_range, &c);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------

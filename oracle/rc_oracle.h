@@ -121,6 +121,9 @@ void rco_safe_invdir(const float d[3], float out[3]);       /* :1742-1748 */
 int rco_is_degenerate(const float v[9]);                    /* src/triangle_mesh.jl:14-17 */
 void rco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void rco_set_histograms(uint32_t* tlas_hist, uint32_t* blas_hist); /* dev: per-node visit counts (single-threaded use) */
+/* dev: trace one ray and record one byte per loop iteration (kind | flags, see rc_oracle.c) plus the stack depth after the step;
+ * returns the number of steps (only the first `cap` are stored).  Feeds tools/sched_sim.py. */
+uint32_t rco_trace_events(const rco_scene*, const rco_ray*, int any, uint8_t* events, uint8_t* depths, uint32_t cap);
 int32_t rco_max_stack(int reset); /* dev: deepest traversal stack seen since the last reset (single-threaded use) */
 void rco_sincos_f64(double x, double* s, double* c); /* sampler trig, see rc_oracle.c */
 double rco_acos_f64(double x);
@@ -138,6 +141,10 @@ void rco_get_illumination(const rco_scene*, const float viewdir[3], uint32_t gri
  * 0,N,0,rays_per_triangle for the whole job.  Accumulates into out (caller zeroes). */
 void rco_view_factors(const rco_scene*, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin,
                       uint32_t src_end, uint32_t ray_begin, uint32_t ray_end, uint32_t* out, int nthreads);
+/* One source primitive's row as a compact N-vector (row[hit_meta-1] += 1 per counted ray): lets a test check rows of a
+ * 50 k x 50 k matrix without allocating it.  src = 0-based flat (Morton-sorted) primitive index. */
+void rco_view_factor_row(const rco_scene*, uint32_t rays_per_triangle, uint64_t seed, uint32_t src, uint32_t ray_begin,
+                         uint32_t ray_end, uint32_t* row);
 /* The ray view_factors shoots for (src prim idx0, ray_idx): exposed so ray generation can be checked. */
 int rco_view_factor_ray(const rco_scene*, uint32_t src_idx0, uint32_t ray_idx, uint64_t seed, rco_ray* out);
 

@@ -225,9 +225,7 @@ struct Trace4Args {
     const RcRay* rays;
     RcHit* hits;
     uint64_t n_rays;
-    uint32_t* chunk_counters;  // kClaimShards counters, kShardStrideWords apart (rc_internal.h)
-    uint32_t n_chunks;
-    uint32_t pool;
+    RcClaim claim;             // how waves claim ray chunks (rc_traverse_core.h)
     int refill, int_thr;
     uint32_t* overflow;
     uint32_t total_threads;
@@ -357,16 +355,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                     if (nf == 0) break;
                     if (pool_next == pool_end) {
                         if (exhausted) break;
-                        // sharded chunk counters, as in phased_trace (rc_traverse_core.h): one counter serialises every claim at 12.6 ns
-                        const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6) & (kClaimShards - 1u);
-                        uint32_t c = 0;
-                        if (lane == 0) c = atomicAdd(a.chunk_counters + my_shard * kShardStrideWords, 1u);
-                        const uint32_t cs = __builtin_amdgcn_readfirstlane(c);
-                        const uint32_t chunk_id = cs * kClaimShards + ((my_shard + cs * 5u) & (kClaimShards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
-                        if (chunk_id >= a.n_chunks) { exhausted = true; break; }
-                        pool_next = (unsigned long long)chunk_id * a.pool;
-                        pool_end = pool_next + a.pool;
-                        if (pool_end > a.n_rays) pool_end = a.n_rays;
+                        if (!rc_claim_chunk(a.claim, (blockIdx.x * kBlock + threadIdx.x) >> 6, lane, a.n_rays, pool_next, pool_end)) { exhausted = true; break; }
                     }
                     const unsigned long long left = pool_end - pool_next;
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_mask, 0u));
@@ -472,18 +461,16 @@ void rc_launch_trace4(rc_scene* s, const Blas& b, const RcRay* d_rays, RcHit* d_
     Trace4Args a;
     a.nodes = b.nodes4.p; a.n_nodes = b.n_nodes4; a.root_word = b.root_word4; a.n_prims = b.n_prims;
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
-    a.chunk_counters = rc_counter_slot(s) + kShardBase;
-    a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);
-    a.n_chunks = (uint32_t)((n + a.pool - 1) / a.pool);
     if (n >= (1ull << 38)) throw RcError(1, "ray batches of 2^38 rays or more are not supported by the BVH4 kernels");
-     // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
+    rc_claim_begin(s, stream, n, total_threads / 64u, a.claim);
     a.refill = (int)s->opt.refill;
     a.int_thr = (int)s->opt.sched_thr;
     a.overflow = s->cur_overflow; a.total_threads = total_threads;
-    a.status = rc_counter_slot(s) + 4;
+    a.status = rc_status_word(s);
     RC_HIP(hipEventRecord(s->ev0, stream));
     if (any_hit) hipLaunchKernelGGL((k_trace4<true, 24>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else hipLaunchKernelGGL((k_trace4<false, 24>), dim3(blocks), dim3(kBlock), 0, stream, a);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
+    rc_claim_commit(s, stream, a.claim, total_threads / 64u, true);
 }

@@ -94,11 +94,18 @@ void require_synced(rc_scene* s) {
         throw RcError(RC_ERR_NOT_SYNCED, "scene has pending mutations: call rc_sync before tracing (Adapt.adapt does this per dispatch)");
 }
 
+// The scene's stack-overflow word is sticky: kernels only ever set it, and it is cleared here when it is reported -- so a launch can
+// never clear another launch's report, and an overflow in an earlier asynchronous launch is reported by the next call that looks.
 void check_status(rc_scene* s, hipStream_t stream) {
     uint32_t st = 0;
-    RC_HIP(hipMemcpyAsync(&st, rc_counter_slot(s) + 4, 4, hipMemcpyDeviceToHost, stream));
+    if (!s->counters.p) return;
+    RC_HIP(hipMemcpyAsync(&st, rc_status_word(s), 4, hipMemcpyDeviceToHost, stream));
     RC_HIP(hipStreamSynchronize(stream));
-    if (st) throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels)");
+    if (st) {
+        RC_HIP(hipMemsetAsync(rc_status_word(s), 0, 4, stream));
+        RC_HIP(hipStreamSynchronize(stream));
+        throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels) in this or an earlier asynchronous launch");
+    }
 }
 
 void export_nodes(rc_scene* s, const RcNode* d, uint32_t n, rc_bvh_node* out, uint32_t capacity, uint32_t* count) {
@@ -176,6 +183,8 @@ int rc_scene_destroy(rc_scene* s) {
     (void)hipDeviceSynchronize();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream_switch_ev) (void)hipEventDestroy(s->stream_switch_ev);
+    for (auto& slot : s->claim_slots) if (slot.done) (void)hipEventDestroy(slot.done);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return RC_OK;
@@ -459,15 +468,13 @@ int rc_wait(rc_scene* s) {
     return guarded([&] {
         use_device(s);
         RC_HIP(hipDeviceSynchronize());
-        // asynchronous launches (the *_device entry points) cannot report a traversal-stack overflow themselves: their status words
-        // (one per launch slot) are collected here
+        // asynchronous launches (the *_device entry points) cannot report a traversal-stack overflow themselves: the scene's sticky
+        // status word is read (and cleared) here
         if (s->counters.p) {
-            uint32_t status[kCounterSlots];  // word 4 of every slot, gathered with one strided copy
-            RC_HIP(hipMemcpy2D(status, sizeof(uint32_t), s->counters.p + 4, (size_t)kCounterSlotWords * sizeof(uint32_t), sizeof(uint32_t), kCounterSlots, hipMemcpyDeviceToHost));
-            bool overflow = false;
-            for (int slot = 0; slot < kCounterSlots; ++slot) overflow |= status[slot] != 0;
-            if (overflow) {
-                RC_HIP(hipMemset(s->counters.p, 0, (size_t)kCounterSlots * kCounterSlotWords * sizeof(uint32_t)));
+            uint32_t st = 0;
+            RC_HIP(hipMemcpy(&st, rc_status_word(s), 4, hipMemcpyDeviceToHost));
+            if (st) {
+                RC_HIP(hipMemset(rc_status_word(s), 0, 4));
                 throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow in an earlier asynchronous launch (tree deeper than 128 levels)");
             }
         }
@@ -538,14 +545,13 @@ static void populate_pages(void* p, size_t bytes) {
 // the kernel overlap: a 4 M-ray batch takes about one direction's transfer time (2.4 ms at 56 GB/s) plus one chunk's latency instead
 // of upload + kernel + download back to back.  The chunks are traced by the same kernels, so the results do not change.
 static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
-    // at most 48 chunks: every chunk's launch keeps its own counter / status slot (64 rotate) until the statuses are read below
+    // at most 48 chunks (each launch takes its own counter slot; 64 rotate)
     const uint64_t kChunk = std::max<uint64_t>(1ull << 19, ((n + 47) / 48 + 63) & ~63ull);
     const uint64_t n_chunks = (n + kChunk - 1) / kChunk;
     s->ray_stage.reserve(n);
     s->hit_stage.reserve(n);
     populate_pages(hits, sizeof(RcHit) * n);
     std::vector<hipEvent_t> ev_begin(n_chunks), ev_end(n_chunks);
-    std::vector<uint32_t*> status_words(n_chunks);
     for (uint64_t c = 0; c < n_chunks; ++c) { RC_HIP(hipEventCreate(&ev_begin[c])); RC_HIP(hipEventCreate(&ev_end[c])); }
     std::atomic<uint64_t> uploaded{0}, launched{0};
     std::atomic<int> copy_error{0};
@@ -588,7 +594,6 @@ static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, 
             uint64_t off, cnt; span(c, off, cnt);
             RC_HIP(hipEventRecord(ev_begin[c], s->stream));
             rc_launch_trace(s, s->ray_stage.p + off, s->hit_stage.p + off, cnt, any, s->stream);
-            status_words[c] = rc_counter_slot(s) + 4;
             RC_HIP(hipEventRecord(ev_end[c], s->stream));
             launched.store(c + 1, std::memory_order_release);
         }
@@ -605,11 +610,10 @@ static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, 
         if (c < done) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev_begin[c], ev_end[c]) == hipSuccess) total_ms += ms;
-            uint32_t st = 0;
-            if (hipMemcpy(&st, status_words[c], 4, hipMemcpyDeviceToHost) == hipSuccess) overflow |= st;
         }
         (void)hipEventDestroy(ev_begin[c]); (void)hipEventDestroy(ev_end[c]);
     }
+    if (s->counters.p && hipMemcpy(&overflow, rc_status_word(s), 4, hipMemcpyDeviceToHost) == hipSuccess && overflow) (void)hipMemset(rc_status_word(s), 0, 4);
     s->last_ms = total_ms;  // the chunks' kernel time, transfers excluded (as for the single-launch path)
     s->pipelined_ms = total_ms; s->pipelined_seq = s->launch_seq;
     if (launch_code) throw RcError(launch_code, launch_error);
@@ -916,17 +920,23 @@ int rc_refit_device(rc_scene* s, int recompute_inverse) {
 int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     if (!s || !name) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     std::string k(name);
-    if (k == "kernel") s->opt.kernel = value;
-    else if (k == "blocks_per_cu") s->opt.blocks_per_cu = value;
+    if (k == "kernel") s->opt.kernel = value < -1 ? -1 : (value > 6 ? 6 : value);
+    else if (k == "blocks_per_cu") s->opt.blocks_per_cu = value < 0 ? 0 : (value > 8 ? 8 : value);  // 0 = derive from the stack depth; the stack spill area is sized for 8 blocks of 256 threads per CU
     else if (k == "lds_stack") s->opt.lds_stack = value;
     else if (k == "refill") s->opt.refill = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (k == "stats") s->opt.stats = value;
-    else if (k == "pool") s->opt.pool = value;
+    else if (k == "pool") s->opt.pool = value <= 0 ? 0 : (value < 16 ? 16 : (value > (1 << 20) ? (1 << 20) : value));  // 0 = default (128 rays per claim)
     else if (k == "onesweep_min") s->opt.onesweep_min = value < 0 ? 0 : value;
     else if (k == "blas_top") s->opt.blas_top = value != 0;
     else if (k == "claim_shards") { int64_t p2 = 1; while (p2 * 2 <= value && p2 * 2 <= kClaimShards) p2 *= 2; s->opt.claim_shards = p2; }  // a power of two
     else if (k == "host_pipeline") s->opt.host_pipeline = value != 0;
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (k == "debug_set_overflow") {  // test hook: raise the sticky stack-overflow word as a kernel would (no LBVH is deep enough to do it for real)
+        if (!s->counters.p) return fail(RC_ERR_INVALID_ARGUMENT, "debug_set_overflow: no launch has run on this scene yet");
+        const uint32_t one = value ? 1u : 0u;
+        (void)hipSetDevice(s->device);
+        if (hipMemcpy(rc_status_word(s), &one, 4, hipMemcpyHostToDevice) != hipSuccess) return fail(RC_ERR_HIP, "status write failed");
+    }
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
     return RC_OK;
 }
@@ -938,16 +948,30 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "n_cus") *value = s->n_cus;
     else if (k == "lds_stack") *value = s->opt.lds_stack;
     else if (k == "refill") *value = s->opt.refill;
+    else if (k == "pool") *value = s->opt.pool;
+    else if (k == "claim_shards") *value = s->opt.claim_shards;
+    else if (k == "sched_thr") *value = s->opt.sched_thr;
     else if (k == "onesweep_min") *value = s->opt.onesweep_min;
     else if (k == "blas_top") *value = s->opt.blas_top;
-    else if (k == "claims") {  // dev: claim atomics issued by the last phased launch (successful + failed)
-        uint32_t w[kCounterSlotUsedWords];
+    else if (k == "claims" || k == "claim_drift") {
+        // dev: "claims" = claim atomics (successful + failed) the most recent launch's slot has seen since the scene was created;
+        // "claim_drift" = over ALL slots, how many shard counters differ from the host's image of them (rc_claim_commit) -- always 0
+        // unless the every-wave-fails-exactly-once accounting is broken
         (void)hipSetDevice(s->device);
         (void)hipDeviceSynchronize();
-        if (s->counters.p && hipMemcpy(w, rc_counter_slot(s), sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "counter read failed");
-        int64_t t = 0;
-        for (int sh = 0; sh < kClaimShards; ++sh) t += w[kShardBase + sh * kShardStrideWords];
-        *value = t;
+        int64_t t = 0, drift = 0;
+        if (s->counters.p) {
+            std::vector<uint32_t> w((size_t)kCounterSlots * kCounterSlotWords);
+            if (hipMemcpy(w.data(), s->counters.p, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "counter read failed");
+            const size_t cur = (size_t)(s->launch_seq % kCounterSlots);
+            for (int slot = 0; slot < kCounterSlots; ++slot)
+                for (int sh = 0; sh < kClaimShards; ++sh) {
+                    const uint32_t dev = w[(size_t)slot * kCounterSlotWords + kShardBase + (size_t)sh * kShardStrideWords];
+                    if ((size_t)slot == cur) t += dev;
+                    if (dev != s->claim_slots[slot].value[sh]) drift += 1;
+                }
+        }
+        *value = k == "claims" ? t : drift;
     }
     else if (k == "host_pipeline") *value = s->opt.host_pipeline;
     else if (k == "blas_top_k") *value = s->blas_top_k;
@@ -956,7 +980,7 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
         unsigned long long st[16] = {0};
         (void)hipSetDevice(s->device);
         (void)hipDeviceSynchronize();
-        if (s->counters.p && hipMemcpy(st, rc_counter_slot(s) + 8, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "stats read failed");
+        if (s->counters.p && hipMemcpy(st, rc_stats_words(s), sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "stats read failed");
         *value = (int64_t)st[k[4] <= '9' ? k[4] - '0' : k[4] - 'a' + 10];
     }
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);

@@ -70,7 +70,7 @@ uint64_t rc_collide_instances_launch(rc_scene* s, uint2* d_out, uint64_t capacit
     if (n == 0) return 0;
     s->collide_counts.reserve(n);
     rc_prepare_launch(s, stream);
-    uint32_t* status = rc_counter_slot(s) + 4;
+    uint32_t* status = rc_status_word(s);
     const uint32_t blocks = (n + 127) / 128;
     RC_HIP(hipEventRecord(s->ev0, stream));
     hipLaunchKernelGGL((k_collide<false>), dim3(blocks), dim3(128), 0, stream, s->tlas_nodes.p, n, s->collide_counts.p, (uint2*)nullptr, status);

@@ -75,16 +75,8 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
                 if (n_idle == 0) break;
                 if (pool_next == pool_end) {
                     if (exhausted) break;
-                    // one chunk of a.pool rays from this wave's shard of the interleaved chunk counters (see phased_trace)
-                    const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6) & (a.n_shards - 1u);
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(a.chunk_counters + my_shard * kShardStrideWords, 1u);
-                    const uint32_t cs = __builtin_amdgcn_readfirstlane(c);
-                        const uint32_t chunk_id = cs * a.n_shards + ((my_shard + cs * 5u) & (a.n_shards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
-                    if (chunk_id >= (uint32_t)((a.n_rays + a.pool - 1) / a.pool)) { exhausted = true; break; }
-                    pool_next = (unsigned long long)chunk_id * a.pool;
-                    pool_end = pool_next + a.pool;
-                    if (pool_end > a.n_rays) pool_end = a.n_rays;
+                    // one chunk of rays from this wave's shard of the interleaved chunk counters (RcClaim, rc_traverse_core.h)
+                    if (!rc_claim_chunk(a.claim, (blockIdx.x * kBlock + threadIdx.x) >> 6, lane, a.n_rays, pool_next, pool_end)) { exhausted = true; break; }
                 }
                 const unsigned long long left = pool_end - pool_next;
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
@@ -127,7 +119,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     const LdsTop top(smem + stack_bytes);
     if (a.v.n_tlas_nodes) stage_lds_top<BLOCK>(top, a.v, a.blas_k, a.lds_blas_base);
     __syncthreads();
-    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, 0u, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
+    PersistArgs p{a.n_rays, a.claim, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, 0u};
     phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
@@ -141,7 +133,7 @@ __global__ __launch_bounds__(kMidBlock, 6) void k_trace_phased_partial(TraceArgs
     top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
     stage_partial_top<kMidBlock>(top.tl, a.v, a.tlas_k, a.blas_k, a.lds_blas_base);
     __syncthreads();
-    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, a.tlas_k, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
+    PersistArgs p{a.n_rays, a.claim, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, a.tlas_k};
     phased_trace<ANY, kMidStack, false, ArraySource, HitWriter, kMidBlock, false, false, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
@@ -228,16 +220,8 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                 if (n_free == 0) break;
                 if (pool_next == pool_end) {
                     if (exhausted) break;
-                    // one chunk of a.pool rays from this wave's shard of the interleaved chunk counters (see phased_trace)
-                    const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6) & (a.n_shards - 1u);
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(a.chunk_counters + my_shard * kShardStrideWords, 1u);
-                    const uint32_t cs = __builtin_amdgcn_readfirstlane(c);
-                        const uint32_t chunk_id = cs * a.n_shards + ((my_shard + cs * 5u) & (a.n_shards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
-                    if (chunk_id >= (uint32_t)((a.n_rays + a.pool - 1) / a.pool)) { exhausted = true; break; }
-                    pool_next = (unsigned long long)chunk_id * a.pool;
-                    pool_end = pool_next + a.pool;
-                    if (pool_end > a.n_rays) pool_end = a.n_rays;
+                    // one chunk of rays from this wave's shard of the interleaved chunk counters (RcClaim, rc_traverse_core.h)
+                    if (!rc_claim_chunk(a.claim, (blockIdx.x * kBlock + threadIdx.x) >> 6, lane, a.n_rays, pool_next, pool_end)) { exhausted = true; break; }
                 }
                 const unsigned long long left = pool_end - pool_next;
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
@@ -370,14 +354,13 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
 template <bool ANY, int LDS_N, int MINW, bool STATS>
 __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
     __shared__ uint32_t lds_stack[LDS_N * kBlock];
-    PersistArgs p{a.n_rays, a.chunk_counters, a.pool, a.refill, a.sched_thr, a.stats, 0u, 0u, 0u, a.n_shards, (uint32_t)((a.n_rays + a.pool - 1) / a.pool)};
+    PersistArgs p{a.n_rays, a.claim, a.refill, a.sched_thr, a.stats, 0u, 0u, 0u};
     phased_trace<ANY, LDS_N, STATS>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits});
 }
 
 }  // namespace
 
-// Scratch shared by every traversal launch: the lane-stack spill area (sized for the largest persistent
-// grid: n_cus x 8 blocks) and the counter / status words, zeroed on the launch stream.
+// Scratch shared by every traversal launch: the lane-stack spill area of the launch's stream and the counter / status words.
 void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
     {
         size_t idx = 0;
@@ -393,17 +376,58 @@ void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
                 s->overflow_regions.emplace_back(stream, DevBuf<uint32_t>());
             }
         }
+        // sized for the largest grid any option can ask for: rc_set_option clamps blocks_per_cu to 8 blocks of 256 threads per CU
         s->overflow_regions[idx].second.reserve((size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock);
         s->cur_overflow = s->overflow_regions[idx].second.p;
     }
-    // one 256-byte slot of counter / status words per launch, rotated over 64 slots, so launches of one scene that
-    // are in flight on different streams never share a work counter
-    if (!s->counters.p) {
+    if (!s->counters.p) {  // first launch of the scene: counters, status and statistics start at zero (synchronous: no launch can race it)
         s->counters.reserve((size_t)kCounterSlots * kCounterSlotWords);
-        RC_HIP(hipMemsetAsync(s->counters.p, 0, sizeof(uint32_t) * (size_t)kCounterSlots * kCounterSlotWords, stream));
+        RC_HIP(hipMemset(s->counters.p, 0, sizeof(uint32_t) * (size_t)kCounterSlots * kCounterSlotWords));
+        s->claim_slots.assign(kCounterSlots, rc_scene::ClaimSlot());
     }
+    // Launches on one stream are ordered.  From the moment a second stream launches on this scene, every launch leaves an event in its
+    // counter slot and a launch that reuses a slot (kCounterSlots launches later) from another stream waits for it first.
+    if (s->any_launch && stream != s->last_launch_stream && !s->multi_stream) {
+        s->multi_stream = true;
+        if (!s->stream_switch_ev) RC_HIP(hipEventCreateWithFlags(&s->stream_switch_ev, hipEventDisableTiming));
+        RC_HIP(hipEventRecord(s->stream_switch_ev, s->last_launch_stream));  // everything launched before the switch had no slot events
+        RC_HIP(hipStreamWaitEvent(stream, s->stream_switch_ev, 0));
+    }
+    s->any_launch = true;
+    s->last_launch_stream = stream;
     s->launch_seq += 1;
-    RC_HIP(hipMemsetAsync(rc_counter_slot(s), 0, kCounterSlotUsedWords * sizeof(uint32_t), stream));
+    if (s->opt.stats) RC_HIP(hipMemsetAsync(rc_stats_words(s), 0, 16 * sizeof(unsigned long long), stream));
+}
+
+void rc_claim_begin(rc_scene* s, hipStream_t stream, uint64_t n_items, uint32_t total_waves, rc::RcClaim& out) {
+    rc_scene::ClaimSlot& slot = s->claim_slots[s->launch_seq % kCounterSlots];
+    if (s->multi_stream && slot.has_event) RC_HIP(hipStreamWaitEvent(stream, slot.done, 0));
+    out.counters = rc_counter_slot(s) + kShardBase;
+    for (int k = 0; k < kClaimShards; ++k) out.base[k] = slot.value[k];
+    uint32_t shards = (uint32_t)s->opt.claim_shards;
+    while (shards > 1 && shards > total_waves) shards >>= 1;  // every shard needs a wave: chunks dealt to a shard nobody drains would never be traced
+    out.n_shards = shards < 1 ? 1 : shards;
+    out.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
+    const uint64_t n_chunks = (n_items + out.pool - 1) / out.pool;
+    if (n_chunks >= (1ull << 32)) throw RcError(1, "ray batch too large for 32-bit chunk ids");
+    out.n_chunks = (uint32_t)n_chunks;
+}
+
+void rc_claim_commit(rc_scene* s, hipStream_t stream, const rc::RcClaim& c, uint32_t total_waves, bool claims) {
+    rc_scene::ClaimSlot& slot = s->claim_slots[s->launch_seq % kCounterSlots];
+    if (claims) {
+        const uint32_t n = c.n_shards, full_rounds = c.n_chunks / n, rem = c.n_chunks % n;
+        for (uint32_t sh = 0; sh < n; ++sh) {
+            const uint32_t chunks = full_rounds + ((((sh + full_rounds * 5u) & (n - 1u)) < rem) ? 1u : 0u);  // the partial round's rotation, as rc_claim_chunk deals it
+            const uint32_t waves = total_waves / n + (sh < total_waves % n ? 1u : 0u);                     // wave w claims from shard w & (n - 1); each fails exactly once
+            slot.value[sh] += chunks + waves;
+        }
+    }
+    if (s->multi_stream) {
+        if (!slot.done) RC_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+        RC_HIP(hipEventRecord(slot.done, stream));
+        slot.has_event = true;
+    }
 }
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
@@ -411,20 +435,19 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     v.tlas_nodes = s->tlas_nodes.p; v.blas_nodes = s->flat_nodes.p; v.inst = s->inst_recs.p; v.prims = s->flat_prims.p;
     v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims; v.tlas_off = s->n_flat_nodes; v.n_nodes_total = s->n_flat_nodes + s->n_tlas_nodes; v.n_inst = s->n_static_instances;
     v.overflow = s->cur_overflow; v.total_threads = total_threads;
-    v.status = rc_counter_slot(s) + 4;
+    v.status = rc_status_word(s);
     return v;
 }
 
-rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads) {
+// Arguments of a persistent launch on `stream` with `total_threads` threads (after rc_prepare_launch); the caller commits the claim
+// (rc_claim_commit) once the kernel has been enqueued.
+rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads, hipStream_t stream) {
     rc::PersistArgs p;
     p.n_items = n_items;
-    p.work_counter = rc_counter_slot(s) + kShardBase;  // chunk counters (phased_trace)
-    p.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
+    rc_claim_begin(s, stream, n_items, total_threads / 64u, p.claim);
     p.refill = (int)s->opt.refill;
     p.int_thr = (int)s->opt.sched_thr;
-    p.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
-    p.n_shards = (uint32_t)s->opt.claim_shards;
-    p.n_chunks = (uint32_t)((n_items + p.pool - 1) / p.pool);
+    p.stats = rc_stats_words(s);
     return p;
 }
 
@@ -504,6 +527,10 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     uint64_t want = (n + kBlock - 1) / kBlock, cap = (uint64_t)s->n_cus * rc_blocks_per_cu(s);
     uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     uint32_t total_threads = blocks * kBlock;
+    struct KernelOptionGuard {  // the fall-back rules below rewrite opt.kernel for this launch only, also when the launch throws
+        rc_scene* s; int64_t saved;
+        ~KernelOptionGuard() { s->opt.kernel = saved; }
+    } kernel_guard{s, s->opt.kernel};
     const int64_t saved_kernel = s->opt.kernel;
     if (saved_kernel < 0)  // auto: tiny batches gain nothing from refilling; a TLAS that fits the LDS planes (<= 256 instances) is read from there
         s->opt.kernel = (n < (uint64_t)total_threads * 5 / 4) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 6);  // measured crossover (tools/small_batch_probe.py): ~1.2 rays per resident lane
@@ -523,21 +550,17 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     TraceArgs a;
     a.v = rc_scene_view(s, total_threads);
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
-    a.chunk_counters = rc_counter_slot(s) + kShardBase;
-    a.n_shards = (uint32_t)s->opt.claim_shards;
+    rc_claim_begin(s, stream, n, total_threads / 64u, a.claim);
     a.refill = (int)s->opt.refill;
-    {
-        a.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
-    }
     a.sched_thr = s->opt.kernel == 2 ? 32 : (int)s->opt.sched_thr;  // kernel 2's vote threshold is its own (lanes that must wait for a batch), tuned at 32
-    a.stats = reinterpret_cast<unsigned long long*>(rc_counter_slot(s) + 8);
+    a.stats = rc_stats_words(s);
     if ((s->opt.kernel == 5 || s->opt.kernel == 4) && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
     if (s->opt.kernel == 6) {  // a plan made for the full-LDS kernels (<= 256 instances) has no TLAS renumbering: tlas_k = 0, its blas_k still fits
         a.tlas_k = s->tlas_top_k; a.blas_k = s->opt.blas_top ? s->blas_top_k : 0; a.lds_blas_base = s->tlas_top_k;
     }
     RC_HIP(hipEventRecord(s->ev0, stream));
     if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
-    s->opt.kernel = saved_kernel;
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
+    rc_claim_commit(s, stream, a.claim, total_threads / 64u, s->opt.kernel != 0 && s->n_tlas_nodes != 0);  // kernel 0 is grid-stride; an empty TLAS returns before claiming
 }

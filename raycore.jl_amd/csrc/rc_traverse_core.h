@@ -27,17 +27,49 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
     uint32_t* status;         // [0] = stack overflow flag
 };
 
+// How a persistent kernel's waves claim work (host side: rc_claim_begin / rc_claim_commit, rc_traverse.hip).  A claim is one chunk
+// of `pool` consecutive items (large claims keep a wave on neighbouring rays: coherent fetches).  The chunks are dealt out by
+// n_shards counters -- in round c of a shard's counter the shards share chunks c * n .. c * n + n - 1, which of them a shard gets
+// rotating with c: with a fixed assignment a shard would own one column band of a 2048-ray-wide image, and bands differ in cost by
+// 2x -- because returning atomics on ONE address serialise at 12.6 ns each however many waves issue them (tools/atomic_probe.hip).
+// A wave stays with the shard it started on: the shards own the same number of interleaved chunks (+-1) and each is drained by
+// 1/n_shards of the waves, so they run dry together, and probing other counters at the end costs more (every probe of a contended
+// line queues behind the claims) than the few chunks' worth of imbalance it could recover.
+// The counters are never reset: a launch counts from `base[shard]`, the value the host knows the counter has when the launch starts
+// (every wave ends with exactly one failed claim, so a launch advances shard s by its chunks + its waves; u32 wrap-around is
+// harmless) -- no memset node between back-to-back launches, nothing a later launch could clear under an earlier one.
+struct RcClaim {
+    uint32_t* counters;            // kClaimShards words, kShardStrideWords apart
+    uint32_t base[kClaimShards];
+    uint32_t n_shards;             // a power of two <= kClaimShards and <= the waves of the launch (every shard has a wave)
+    uint32_t n_chunks;             // ceil(n_items / pool), < 2^32
+    uint32_t pool;                 // items per claim
+};
+// Wave-uniform: the next chunk of this wave's shard, or false when the shard has run dry.  `wave_id` must be the same in all lanes.
+__device__ inline bool rc_claim_chunk(const RcClaim& c, uint32_t wave_id, int lane, uint64_t n_items, unsigned long long& pool_next,
+                                      unsigned long long& pool_end) {
+    const uint32_t my_shard = __builtin_amdgcn_readfirstlane(wave_id) & (c.n_shards - 1u);  // wave-uniform (keeps the claim in scalar registers); neighbouring waves use different counters
+    uint32_t got = 0;
+    if (lane == 0) got = atomicAdd(c.counters + my_shard * kShardStrideWords, 1u);
+    const uint32_t cs = __builtin_amdgcn_readfirstlane(got) - c.base[my_shard];
+    const uint32_t chunk_id = cs * c.n_shards + ((my_shard + cs * 5u) & (c.n_shards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
+    if (cs >= 0x0FFFFFFFu || chunk_id >= c.n_chunks) return false;  // (the first test keeps cs * n_shards from wrapping)
+    pool_next = (unsigned long long)chunk_id * c.pool;
+    pool_end = pool_next + c.pool;
+    if (pool_end > n_items) pool_end = n_items;
+    return true;
+}
+
 struct TraceArgs {
     SceneView v;
     const RcRay* rays;
     RcHit* hits;
     uint64_t n_rays;
-    uint32_t* chunk_counters;          // persistent kernels: the sharded chunk counters (PersistArgs::work_counter; rc_internal.h)
+    RcClaim claim;                     // persistent kernels: how waves claim ray chunks
     int refill;                        // persistent kernel: refill when this many lanes are idle
-    uint32_t pool;                     // persistent kernels: ray indices claimed per atomic
     int sched_thr;                     // scheduled kernel: run a leaf/entry batch once this many lanes wait for it
     unsigned long long* stats;         // optional instrumentation (dev builds), else nullptr
-    uint32_t blas_k = 0, lds_blas_base = 0, tlas_k = 0, n_shards = kClaimShards;
+    uint32_t blas_k = 0, lds_blas_base = 0, tlas_k = 0;
 };
 
 // Address-space-qualified pointers keep the two halves of the stack on their own instruction paths
@@ -280,16 +312,13 @@ __device__ inline float2 buf_f2(__amdgpu_buffer_rsrc_t r, uint32_t off, int soff
 // keeps it, inst = 0-based instance, -1 on a miss).
 struct PersistArgs {
     uint64_t n_items;                  // work items = rays
-    uint32_t* work_counter;            // kClaimShards chunk counters, kShardStrideWords apart: shard s hands out chunks s, s + kClaimShards, ... of `pool` items
-    uint32_t pool;                     // items claimed per atomic
+    RcClaim claim;                     // how waves claim chunks of items
     int refill;                        // refill when this many lanes are free
     int int_thr;                       // leave the interior loop when fewer lanes than this have an interior node pending
     unsigned long long* stats;
     uint32_t blas_k = 0;               // TLAS_LDS kernels: BLAS nodes 1..blas_k are staged in the planes at entry lds_blas_base + node - 1
     uint32_t lds_blas_base = 0;
     uint32_t tlas_k = 0;               // PARTIAL_LDS kernels: TLAS nodes 1..tlas_k are staged at entry node - 1 (the rest comes from memory)
-    uint32_t n_shards = kClaimShards;  // chunk counters in use, a power of two (1 = a single counter, for A/B measurement)
-    uint32_t n_chunks = 0;             // ceil(n_items / pool), < 2^32
 };
 
 // TLAS_LDS / INST_LDS: the block has staged the top level in LDS before the call (LdsTop below; layout and sizes in rc_internal.h):
@@ -522,24 +551,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                     if (nf == 0) break;
                     if (pool_next == pool_end) {
                         if (exhausted) break;
-                        // A claim is one chunk of `pool` consecutive items (large claims keep a wave on neighbouring rays: coherent
-                        // fetches).  The chunks are dealt out by n_shards counters -- in round c of a shard's counter the shards share chunks
-                        // c * n .. c * n + n - 1, which of them a shard gets rotating with c: with a fixed assignment a shard would own one
-                        // column band of a 2048-ray-wide image, and bands differ in cost by 2x -- because
-                        // returning atomics on ONE address serialise at 12.6 ns each however many waves issue them.  A wave stays with
-                        // the shard it started on: the shards own the same number of interleaved chunks (+-1) and each is drained by
-                        // 1/n_shards of the waves, so they run dry together, and probing other counters at the end costs more (every
-                        // probe of a contended line queues behind the claims) than the few chunks' worth of imbalance it could recover.
-                        const uint32_t my_shard = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6) & (a.n_shards - 1u);  // wave-uniform (keeps the claim in scalar registers); n_shards is a power of two, neighbouring waves use different counters
-                        const uint32_t n_chunks = a.n_chunks;
-                        uint32_t c = 0;
-                        if (lane == 0) c = atomicAdd(a.work_counter + my_shard * kShardStrideWords, 1u);
-                        const uint32_t cs = __builtin_amdgcn_readfirstlane(c);
-                        const uint32_t chunk_id = cs * a.n_shards + ((my_shard + cs * 5u) & (a.n_shards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
-                        if (chunk_id >= n_chunks) { exhausted = true; break; }
-                        pool_next = (unsigned long long)chunk_id * a.pool;
-                        pool_end = pool_next + a.pool;
-                        if (pool_end > a.n_items) pool_end = a.n_items;
+                        if (!rc_claim_chunk(a.claim, (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane, a.n_items, pool_next, pool_end)) { exhausted = true; break; }
                     }
                     const unsigned long long left = pool_end - pool_next;
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
@@ -590,7 +602,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
 }  // namespace rc
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads);  // rc_traverse.hip
-rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads);
+rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads, hipStream_t stream);
 bool rc_lds_driver_ok(rc_scene* s);
 uint32_t rc_lds_driver_blocks(rc_scene* s, uint64_t n_items);
 void rc_lds_driver_args(rc_scene* s, rc::PersistArgs& p);

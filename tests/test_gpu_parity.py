@@ -209,7 +209,7 @@ def test_build_parity_1m_repeated(rc, oracle):
 
 
 # ---- traversal parity -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5, 6, -1])
 def test_trace_parity_c1(rc, oracle, kernel):
     cfg = rc.scenes.config_c1()
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
@@ -221,7 +221,7 @@ def test_trace_parity_c1(rc, oracle, kernel):
     assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any"), "C1 any")
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5, 6, -1])
 def test_trace_parity_random_scene(rc, oracle, kernel):
     sc = rc.scenes
     xf, _, _ = sc.lattice_transforms(3, 3, 2, 1.2, 77)
@@ -239,7 +239,7 @@ def test_trace_parity_random_scene(rc, oracle, kernel):
     assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any", nthreads=8), "random any")
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 6, -1])
 def test_trace_parity_c3_and_shadow(rc, oracle, kernel):
     cfg = rc.scenes.config_c3()
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)

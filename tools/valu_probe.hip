@@ -1,0 +1,86 @@
+// Dev microbenchmark: VALU issue rate on gfx950 by instruction class, at the traversal kernel's occupancy (6 waves / SIMD).
+// The trace kernels are bound by VALU issue (profiles/r02_*: SQ_ACTIVE_INST_VALU), so the ceiling of the roofline is
+// "wave-instructions per second" of the mix the kernel issues.  Each kernel runs N dependent-free chains of one opcode.
+// build: hipcc --offload-arch=gfx950 -O3 tools/valu_probe.hip -o tools/valu_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kUnroll = 8;  // independent chains per lane
+
+template <int OP>
+__global__ __launch_bounds__(256, 6) void k_valu(float* out, int iters, float seed) {
+    float a[kUnroll], b[kUnroll];
+    v2f p[kUnroll], q[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) { a[k] = seed + k + threadIdx.x; b[k] = seed * 0.5f + k; p[k] = v2f{a[k], b[k]}; q[k] = v2f{b[k], a[k] * 0.25f}; }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k) {
+            if (OP == 0) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 1) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(q[k]));
+            if (OP == 2) asm volatile("v_maximum3_f32 %0, %0, %1, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 3) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[k]));
+            if (OP == 5) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 6) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(q[k]));
+            if (OP == 7) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[k]), "v"(b[k]) : "vcc");
+            if (OP == 8) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 9) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 10) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[k]) : "v"(q[k]));
+            if (OP == 11) asm volatile("v_minimum3_f32 %0, %0, %1, %1" : "+v"(a[k]) : "v"(b[k]));
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) acc += a[k] + p[k].x + p[k].y;
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int OP>
+static int run(const char* name, float* d_out, int n_cus) {
+    const int iters = 20000, blocks = n_cus * 6;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_valu<OP>), dim3(blocks), dim3(256), 0, 0, d_out, 200, 1.5f);
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_valu<OP>), dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.5f);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    // wave-instructions per SIMD: 6 waves x iters x kUnroll
+    const double inst_per_simd = 6.0 * iters * kUnroll;
+    const double ns_per_inst = best * 1e6 / inst_per_simd;
+    printf("%-18s %8.3f ms  %.3f ns per wave-instruction per SIMD  => %.2f G wave-inst/s chip-wide (%d SIMDs)\n", name, best, ns_per_inst,
+           n_cus * 4 / ns_per_inst, n_cus * 4);
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int n_cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs, clock %d kHz\n", prop.name, n_cus, prop.clockRate);
+    float* d_out;
+    CK(hipMalloc(&d_out, sizeof(float) * n_cus * 6 * 256));
+    if (run<0>("v_mul_f32", d_out, n_cus)) return 1;
+    if (run<1>("v_pk_mul_f32", d_out, n_cus)) return 1;
+    if (run<6>("v_pk_add_f32", d_out, n_cus)) return 1;
+    if (run<10>("v_pk_fma_f32", d_out, n_cus)) return 1;
+    if (run<5>("v_fma_f32", d_out, n_cus)) return 1;
+    if (run<2>("v_maximum3_f32", d_out, n_cus)) return 1;
+    if (run<11>("v_minimum3_f32", d_out, n_cus)) return 1;
+    if (run<3>("v_cndmask_b32", d_out, n_cus)) return 1;
+    if (run<7>("v_cmp_lt_f32", d_out, n_cus)) return 1;
+    if (run<8>("v_add_u32", d_out, n_cus)) return 1;
+    if (run<9>("v_lshl_add_u32", d_out, n_cus)) return 1;
+    if (run<4>("v_rcp_f32", d_out, n_cus)) return 1;
+    return 0;
+}
