@@ -472,5 +472,5 @@ void rc_launch_trace4(rc_scene* s, const Blas& b, const RcRay* d_rays, RcHit* d_
     else hipLaunchKernelGGL((k_trace4<false, 24>), dim3(blocks), dim3(kBlock), 0, stream, a);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
-    rc_claim_commit(s, stream, a.claim, total_threads / 64u, true);
+    rc_claim_commit(s, stream);
 }

@@ -953,25 +953,20 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "sched_thr") *value = s->opt.sched_thr;
     else if (k == "onesweep_min") *value = s->opt.onesweep_min;
     else if (k == "blas_top") *value = s->opt.blas_top;
-    else if (k == "claims" || k == "claim_drift") {
-        // dev: "claims" = claim atomics (successful + failed) the most recent launch's slot has seen since the scene was created;
-        // "claim_drift" = over ALL slots, how many shard counters differ from the host's image of them (rc_claim_commit) -- always 0
-        // unless the every-wave-fails-exactly-once accounting is broken
+    else if (k == "claim_drift") {
+        // dev: chunk counters, over all slots, that are not back at zero once the device is idle -- always 0 unless the
+        // every-wave-fails-exactly-once accounting of rc_claim_chunk is broken
         (void)hipSetDevice(s->device);
         (void)hipDeviceSynchronize();
-        int64_t t = 0, drift = 0;
+        int64_t drift = 0;
         if (s->counters.p) {
             std::vector<uint32_t> w((size_t)kCounterSlots * kCounterSlotWords);
             if (hipMemcpy(w.data(), s->counters.p, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "counter read failed");
-            const size_t cur = (size_t)(s->launch_seq % kCounterSlots);
             for (int slot = 0; slot < kCounterSlots; ++slot)
-                for (int sh = 0; sh < kClaimShards; ++sh) {
-                    const uint32_t dev = w[(size_t)slot * kCounterSlotWords + kShardBase + (size_t)sh * kShardStrideWords];
-                    if ((size_t)slot == cur) t += dev;
-                    if (dev != s->claim_slots[slot].value[sh]) drift += 1;
-                }
+                for (int sh = 0; sh < kClaimShards; ++sh)
+                    if (w[(size_t)slot * kCounterSlotWords + kShardBase + (size_t)sh * kShardStrideWords] != 0) drift += 1;
         }
-        *value = k == "claims" ? t : drift;
+        *value = drift;
     }
     else if (k == "host_pipeline") *value = s->opt.host_pipeline;
     else if (k == "blas_top_k") *value = s->blas_top_k;

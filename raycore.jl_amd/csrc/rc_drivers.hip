@@ -430,7 +430,7 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
     hipLaunchKernelGGL(k_illumination, dim3(blocks), dim3(kBlock), 0, stream, v, p, g, ray_begin, d_counts);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
-    rc_claim_commit(s, stream, p.claim, blocks * bs / 64u, s->n_tlas_nodes != 0);
+    rc_claim_commit(s, stream);
 }
 
 void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end,
@@ -461,7 +461,7 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
                        ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
-    rc_claim_commit(s, stream, p.claim, blocks * bs / 64u, s->n_tlas_nodes != 0);
+    rc_claim_commit(s, stream);
 }
 
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream) {

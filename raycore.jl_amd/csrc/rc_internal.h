@@ -148,10 +148,9 @@ struct rc_scene {
     static constexpr int kMaxOverflowRegions = 4;
     std::vector<std::pair<hipStream_t, DevBuf<uint32_t>>> overflow_regions;
     uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared (rc_prepare_launch)
-    DevBuf<uint32_t> counters;        // kCounterSlots slots of claim counters (never reset: ClaimSlot tracks their values), the sticky status word, dev statistics
+    DevBuf<uint32_t> counters;        // kCounterSlots slots of claim counters (self-resetting, rc_claim_chunk), the sticky status word, dev statistics
     uint64_t launch_seq = 0;
-    struct ClaimSlot {                // host image of one slot's chunk counters (rc_claim_begin / rc_claim_commit, rc_traverse.hip)
-        uint32_t value[16] = {0};     // what each shard's counter holds once the launches committed so far have finished
+    struct ClaimSlot {                // ordering of launches that share a slot of chunk counters (rc_claim_begin / rc_claim_commit, rc_traverse.hip)
         hipEvent_t done = nullptr;    // recorded after the slot's last launch once the scene has seen more than one stream
         bool has_event = false;
     };
@@ -217,17 +216,16 @@ void rc_launch_compact_hits(rc_scene* s, const RcHit* d_hits, uint64_t n, uint32
 // rc_traverse.hip helpers shared with rc_drivers.hip
 namespace rc { struct SceneView; struct RcClaim; }
 void rc_prepare_launch(rc_scene* s, hipStream_t stream);
-// Claim bookkeeping of a persistent launch: rc_claim_begin fills the kernel's RcClaim from the slot this launch uses (and orders the
-// launch behind the slot's previous user when that one ran on another stream), rc_claim_commit -- called once the launch has been
-// enqueued without error -- advances the host image by what the launch will add: each shard's valid chunks plus one failed claim per
-// wave.  `claims` = false for launches whose waves return without claiming (empty TLAS).
+// Claim bookkeeping of a persistent launch: rc_claim_begin fills the kernel's RcClaim for the counter slot this launch uses (and
+// orders the launch behind the slot's previous user when that one ran on another stream); rc_claim_commit, called once the launch
+// has been enqueued, leaves the event a later user of the slot on another stream waits for.
 void rc_claim_begin(rc_scene* s, hipStream_t stream, uint64_t n_items, uint32_t total_waves, rc::RcClaim& out);
-void rc_claim_commit(rc_scene* s, hipStream_t stream, const rc::RcClaim& c, uint32_t total_waves, bool claims);
+void rc_claim_commit(rc_scene* s, hipStream_t stream);
 // One slot of chunk counters per launch, rotated over kCounterSlots, so that launches of one scene in flight on different streams
 // never share a counter: from word kShardBase of a slot on, kClaimShards counters kShardStrideWords apart.  A returning atomic on
 // ONE address costs 12.6 ns on MI355X however many waves issue it (tools/atomic_probe.hip): 6144 waves claiming their first rays
 // wait up to 77 us, and the 32 768 claims of a 4 M-ray launch keep a single counter busy for 0.41 ms.  Sixteen counters 256 bytes
-// apart run at 0.9 ns per claim.  The counters are never reset (rc_claim_begin).  Words [4] and [8..] of SLOT 0 are the scene's
+// apart run at 0.9 ns per claim.  The counters zero themselves at the end of every launch (rc_claim_chunk).  Words [4] and [8..] of SLOT 0 are the scene's
 // sticky stack-overflow status (set by any launch, read and cleared by check_status / rc_wait: a later launch cannot clear an
 // earlier launch's report) and the dev statistics (zeroed per launch only while the "stats" option is on).
 constexpr int kCounterSlots = 64, kCounterSlotWords = 2048, kCounterSlotUsedWords = 1088;

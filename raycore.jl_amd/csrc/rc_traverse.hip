@@ -380,9 +380,12 @@ void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
         s->overflow_regions[idx].second.reserve((size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock);
         s->cur_overflow = s->overflow_regions[idx].second.p;
     }
-    if (!s->counters.p) {  // first launch of the scene: counters, status and statistics start at zero (synchronous: no launch can race it)
+    if (!s->counters.p) {
+        // first launch of the scene: counters, status and statistics start at zero.  Enqueued on the launch's stream (a plain hipMemset
+        // is not ordered with a non-blocking stream and may land after the kernel has started claiming); a launch on any other stream
+        // is ordered behind it by the stream-switch event below.
         s->counters.reserve((size_t)kCounterSlots * kCounterSlotWords);
-        RC_HIP(hipMemset(s->counters.p, 0, sizeof(uint32_t) * (size_t)kCounterSlots * kCounterSlotWords));
+        RC_HIP(hipMemsetAsync(s->counters.p, 0, sizeof(uint32_t) * (size_t)kCounterSlots * kCounterSlotWords, stream));
         s->claim_slots.assign(kCounterSlots, rc_scene::ClaimSlot());
     }
     // Launches on one stream are ordered.  From the moment a second stream launches on this scene, every launch leaves an event in its
@@ -403,31 +406,23 @@ void rc_claim_begin(rc_scene* s, hipStream_t stream, uint64_t n_items, uint32_t 
     rc_scene::ClaimSlot& slot = s->claim_slots[s->launch_seq % kCounterSlots];
     if (s->multi_stream && slot.has_event) RC_HIP(hipStreamWaitEvent(stream, slot.done, 0));
     out.counters = rc_counter_slot(s) + kShardBase;
-    for (int k = 0; k < kClaimShards; ++k) out.base[k] = slot.value[k];
-    uint32_t shards = (uint32_t)s->opt.claim_shards;
+    uint32_t shards = (uint32_t)s->opt.claim_shards, shift = 0;
     while (shards > 1 && shards > total_waves) shards >>= 1;  // every shard needs a wave: chunks dealt to a shard nobody drains would never be traced
-    out.n_shards = shards < 1 ? 1 : shards;
+    while ((2u << shift) <= shards) ++shift;
+    out.shard_shift = shift;
     out.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
     const uint64_t n_chunks = (n_items + out.pool - 1) / out.pool;
-    if (n_chunks >= (1ull << 32)) throw RcError(1, "ray batch too large for 32-bit chunk ids");
+    if (n_chunks >= (1ull << 31)) throw RcError(1, "ray batch too large for 32-bit chunk ids");
     out.n_chunks = (uint32_t)n_chunks;
+    out.total_waves = total_waves;
 }
 
-void rc_claim_commit(rc_scene* s, hipStream_t stream, const rc::RcClaim& c, uint32_t total_waves, bool claims) {
+void rc_claim_commit(rc_scene* s, hipStream_t stream) {
+    if (!s->multi_stream) return;
     rc_scene::ClaimSlot& slot = s->claim_slots[s->launch_seq % kCounterSlots];
-    if (claims) {
-        const uint32_t n = c.n_shards, full_rounds = c.n_chunks / n, rem = c.n_chunks % n;
-        for (uint32_t sh = 0; sh < n; ++sh) {
-            const uint32_t chunks = full_rounds + ((((sh + full_rounds * 5u) & (n - 1u)) < rem) ? 1u : 0u);  // the partial round's rotation, as rc_claim_chunk deals it
-            const uint32_t waves = total_waves / n + (sh < total_waves % n ? 1u : 0u);                     // wave w claims from shard w & (n - 1); each fails exactly once
-            slot.value[sh] += chunks + waves;
-        }
-    }
-    if (s->multi_stream) {
-        if (!slot.done) RC_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
-        RC_HIP(hipEventRecord(slot.done, stream));
-        slot.has_event = true;
-    }
+    if (!slot.done) RC_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    RC_HIP(hipEventRecord(slot.done, stream));
+    slot.has_event = true;
 }
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
@@ -562,5 +557,5 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
-    rc_claim_commit(s, stream, a.claim, total_threads / 64u, s->opt.kernel != 0 && s->n_tlas_nodes != 0);  // kernel 0 is grid-stride; an empty TLAS returns before claiming
+    rc_claim_commit(s, stream);
 }

@@ -35,25 +35,35 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
 // A wave stays with the shard it started on: the shards own the same number of interleaved chunks (+-1) and each is drained by
 // 1/n_shards of the waves, so they run dry together, and probing other counters at the end costs more (every probe of a contended
 // line queues behind the claims) than the few chunks' worth of imbalance it could recover.
-// The counters are never reset: a launch counts from `base[shard]`, the value the host knows the counter has when the launch starts
-// (every wave ends with exactly one failed claim, so a launch advances shard s by its chunks + its waves; u32 wrap-around is
-// harmless) -- no memset node between back-to-back launches, nothing a later launch could clear under an earlier one.
+// The counters reset themselves: every wave ends with exactly one failed claim, so shard s sees chunks(s) + waves(s) atomics per
+// launch, and the wave whose failed claim is the last of them puts the counter back to zero -- no memset node between back-to-back
+// launches (6 us, 1 % of a 4 M-ray launch, 3 % of a 1 M-ray one), nothing a later launch could clear under an earlier one, and
+// a launch that is never enqueued leaves nothing behind.
 struct RcClaim {
-    uint32_t* counters;            // kClaimShards words, kShardStrideWords apart
-    uint32_t base[kClaimShards];
-    uint32_t n_shards;             // a power of two <= kClaimShards and <= the waves of the launch (every shard has a wave)
+    uint32_t* counters;            // kClaimShards words, kShardStrideWords apart, zero between launches
+    uint32_t shard_shift;          // n_shards = 1 << shard_shift <= kClaimShards and <= the waves of the launch (every shard has a wave)
     uint32_t n_chunks;             // ceil(n_items / pool), < 2^32
     uint32_t pool;                 // items per claim
+    uint32_t total_waves;          // waves of the launch: wave w claims from shard w & (n_shards - 1)
 };
 // Wave-uniform: the next chunk of this wave's shard, or false when the shard has run dry.  `wave_id` must be the same in all lanes.
 __device__ inline bool rc_claim_chunk(const RcClaim& c, uint32_t wave_id, int lane, uint64_t n_items, unsigned long long& pool_next,
                                       unsigned long long& pool_end) {
-    const uint32_t my_shard = __builtin_amdgcn_readfirstlane(wave_id) & (c.n_shards - 1u);  // wave-uniform (keeps the claim in scalar registers); neighbouring waves use different counters
+    const uint32_t n = 1u << c.shard_shift;
+    const uint32_t my_shard = __builtin_amdgcn_readfirstlane(wave_id) & (n - 1u);  // wave-uniform (keeps the claim in scalar registers); neighbouring waves use different counters
+    uint32_t* const counter = c.counters + my_shard * kShardStrideWords;
     uint32_t got = 0;
-    if (lane == 0) got = atomicAdd(c.counters + my_shard * kShardStrideWords, 1u);
-    const uint32_t cs = __builtin_amdgcn_readfirstlane(got) - c.base[my_shard];
-    const uint32_t chunk_id = cs * c.n_shards + ((my_shard + cs * 5u) & (c.n_shards - 1u));  // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round
-    if (cs >= 0x0FFFFFFFu || chunk_id >= c.n_chunks) return false;  // (the first test keeps cs * n_shards from wrapping)
+    if (lane == 0) got = atomicAdd(counter, 1u);
+    const uint32_t cs = __builtin_amdgcn_readfirstlane(got);
+    // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round; this shard's share of the chunks:
+    const uint32_t full_rounds = c.n_chunks >> c.shard_shift, rem = c.n_chunks & (n - 1u);
+    const uint32_t my_chunks = full_rounds + ((((my_shard + full_rounds * 5u) & (n - 1u)) < rem) ? 1u : 0u);
+    if (cs >= my_chunks) {  // dry.  The last of this shard's waves to find it so -- nobody touches the counter after it -- zeroes it for the next launch
+        const uint32_t my_waves = (c.total_waves >> c.shard_shift) + (my_shard < (c.total_waves & (n - 1u)) ? 1u : 0u);
+        if (cs + 1u == my_chunks + my_waves && lane == 0) atomicExch(counter, 0u);
+        return false;
+    }
+    const uint32_t chunk_id = (cs << c.shard_shift) + ((my_shard + cs * 5u) & (n - 1u));
     pool_next = (unsigned long long)chunk_id * c.pool;
     pool_end = pool_next + c.pool;
     if (pool_end > n_items) pool_end = n_items;

@@ -106,7 +106,7 @@ def main():
                 else:
                     extra = (f" iters={v[0]} live/iter={v[1]/max(v[0],1):.1f} | I {v[2]} x{v[3]/max(v[2],1):.1f} | L {v[4]} x{v[5]/max(v[4],1):.1f}"
                              f" | E {v[6]} x{v[7]/max(v[6],1):.1f}")
-            extra += f" claims={t.get_option('claims')}"
+            extra += f" drift={t.get_option('claim_drift')}"
             print(f"[{var:40s}] {name:14s} n={len(rays):9d} {ms:9.3f} ms  {len(rays)/ms/1e3:9.1f} Mrays/s  hit={hits['hit'].mean():.3f}{extra}", flush=True)
 
 

@@ -14,6 +14,10 @@ template <int OP>
 __global__ __launch_bounds__(256, 6) void k_valu(float* out, int iters, float seed) {
     float a[kUnroll], b[kUnroll];
     v2f p[kUnroll], q[kUnroll];
+    unsigned long long w[kUnroll];
+    unsigned long long mask = 0x5555AAAA5555AAAAull + (unsigned long long)iters, mask2 = 0;
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) w[k] = threadIdx.x + k;
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) { a[k] = seed + k + threadIdx.x; b[k] = seed * 0.5f + k; p[k] = v2f{a[k], b[k]}; q[k] = v2f{b[k], a[k] * 0.25f}; }
     for (int i = 0; i < iters; ++i) {
@@ -31,11 +35,25 @@ __global__ __launch_bounds__(256, 6) void k_valu(float* out, int iters, float se
             if (OP == 9) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[k]) : "v"(b[k]));
             if (OP == 10) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[k]) : "v"(q[k]));
             if (OP == 11) asm volatile("v_minimum3_f32 %0, %0, %1, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 12) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b[k]), "s"(mask));
+            if (OP == 13) asm volatile("v_mov_b32 %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 14) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 15) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 16) asm volatile("v_mul_f32_e64 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 17) asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(w[k]) : "v"(b[k]) : "vcc");
+            if (OP == 18) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b[k]), "v"(p[k].y));
+            if (OP == 19) asm volatile("v_swap_b32 %0, %1" : "+v"(a[k]), "+v"(b[k]));
+            if (OP == 20) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 21) asm volatile("v_maximum3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b[k]), "v"(p[k].y));
+            if (OP == 22) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(mask2) : "v"(a[k]), "v"(b[k]));
+            if (OP == 23) asm volatile("v_mul_f32 %0, %0, %1\n v_add_f32 %0, %0, %2" : "+v"(a[k]) : "v"(b[k]), "v"(p[k].y));  // two instructions per count
+            if (OP == 24) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b[k]), "v"(p[k].y));
         }
     }
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) acc += a[k] + p[k].x + p[k].y;
+    for (int k = 0; k < kUnroll; ++k) acc += a[k] + p[k].x + p[k].y + (float)w[k] + b[k];
+    acc += (float)mask2;
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
@@ -82,5 +100,18 @@ int main() {
     if (run<8>("v_add_u32", d_out, n_cus)) return 1;
     if (run<9>("v_lshl_add_u32", d_out, n_cus)) return 1;
     if (run<4>("v_rcp_f32", d_out, n_cus)) return 1;
+    if (run<12>("v_cndmask_b32_e64 sgpr", d_out, n_cus)) return 1;
+    if (run<13>("v_mov_b32", d_out, n_cus)) return 1;
+    if (run<14>("v_max_f32", d_out, n_cus)) return 1;
+    if (run<15>("v_add_f32", d_out, n_cus)) return 1;
+    if (run<16>("v_mul_f32_e64", d_out, n_cus)) return 1;
+    if (run<17>("v_mad_u64_u32", d_out, n_cus)) return 1;
+    if (run<18>("v_fma_f32 3 regs", d_out, n_cus)) return 1;
+    if (run<19>("v_swap_b32", d_out, n_cus)) return 1;
+    if (run<20>("v_and_b32", d_out, n_cus)) return 1;
+    if (run<21>("v_maximum3 3 regs", d_out, n_cus)) return 1;
+    if (run<22>("v_cmp_lt_f32_e64 sgpr", d_out, n_cus)) return 1;
+    if (run<23>("v_mul+v_add pair", d_out, n_cus)) return 1;
+    if (run<24>("v_max3_f32", d_out, n_cus)) return 1;
     return 0;
 }
