@@ -7,17 +7,25 @@
 A step = one closest_hit pass over one batch of 4 194 304 synthetic primary rays (2048 x 2048 pinhole) against
 256 transformed instances of one 4 096-triangle BLAS (1 048 576 triangles), rays and scene already resident in
 HBM.  One process per GPU; rays are independent, so ranks are replicas of the scene tracing their own batch
-(no data-path collective; "scaling": "weak").  Rank 0 prints ONE JSON line.
+(no data-path collective; "scaling": "weak").  Rank 0 prints ONE JSON line.  Started as a plain `python bench.py
+--gpus N` (no WORLD_SIZE in the environment) with N > 1, the script launches its own N rank processes -- before anything
+touches a GPU -- and relays rank 0's line.
 
-roofline: achieved = algorithmic bytes per launch / average launch duration (HIP events on the launch stream,
-recorded inside the timed region).  Algorithmic bytes per ray = 32 (RTRay) + 32 (RTHitResult) + 60 x BVHNode2
-fetches + 140 x TLAS-leaf entries of the REFERENCE algorithm on this exact ray set, counted
-by the instrumented CPU oracle in the cpu_baseline leg (N=1); at N>1 the committed count for this workload is used.
-cpu_baseline: the reference algorithm's C restatement (oracle/), all host cores, same rays.
+roofline: the dominant kernel (k_trace_phased_lds) is bound by VALU ISSUE, not by memory -- the scene is LDS / L1 / L2 resident
+and physical HBM traffic is the ray-in / hit-out stream (6 % of the HBM peak).  `achieved` = VALU wave-instructions per launch
+(SQ_INSTS_VALU from the counter file named in `roofline.sources`, collected with rocprofv3 --pmc on this kernel and workload) /
+the average launch duration measured live with HIP events on the launch stream; `peak` = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+per wave64 VALU instruction (tools/valu_probe.hip, profiles/r02_valu_probe.txt: v_mul / v_add / v_mov 604-652 G/s, the packed-f32 and
+3-operand min / max forms the slab test is made of 500-555 G/s).  `lane_utilisation` says how many of those issue slots carry a ray.
+The figure SURVEY.md section 8d prescribes -- algorithmic bytes of the REFERENCE algorithm (32 + 32 + 60 x BVHNode2 fetches + 140 x
+TLAS-leaf entries per ray, counted by the instrumented CPU oracle in the cpu_baseline leg) against the 8 TB/s HBM peak -- is kept
+as `algorithmic_vs_hbm`: it exceeds 1 because those bytes come from LDS and caches, which is why it is not `frac`.
+cpu_baseline: the reference algorithm's C restatement (oracle/), all host cores and one thread, same rays.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,10 +35,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-# Reference-algorithm fetch counts for this workload (avg per ray), measured by the oracle; refreshed by the
-# cpu_baseline leg whenever it runs.  Used only when the oracle leg is skipped (N > 1).
+VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 4.0  # one wave64 VALU instruction per SIMD per 4 cycles: 614.4 G wave-instructions / s
+COUNTER_FILE = os.path.join("profiles", "r02_pmc_c3.json")          # per-launch PMC counters of the bench kernel (tools/capture_profiles.sh)
+COUNTS_FILE = os.path.join("profiles", "c3_reference_counts.json")  # reference-algorithm fetch counts per ray for this workload (written by the N=1 run)
+# Fallback when the counts file is missing (same numbers, measured by the oracle in round 1)
 C3_NODE_FETCHES_PER_RAY = 33.006
 C3_INST_ENTRIES_PER_RAY = 1.922
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start N rank processes (fresh children: this process never
+    touches a GPU) and relay rank 0's output.  Exit code = the worst child's."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -42,7 +72,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for dry runs)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercises the launcher, the process group and the JSON line (CPU tests)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -51,6 +85,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     n_dev = torch.cuda.device_count()
     if local_rank >= n_dev:
         if args.backend == "nccl":
@@ -61,10 +97,12 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        import datetime
+        limit = datetime.timedelta(seconds=300)  # a rank that leaves the collective sequence makes the others fail, not hang
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"), timeout=limit)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=limit)
 
     import raycore_jl_amd as rc
     sc = rc.scenes
@@ -197,8 +235,6 @@ def main():
         extras["random_geometry_1M_rays_closest"] = ref
         torch.cuda.empty_cache()
 
-    if not args.no_extras and rank == 0:
-        guarded_extra("traces", extra_traces)
 
     def extra_builds():
         # LBVH build (row a14): device pipeline time for triangle soup already in HBM; the reference publishes
@@ -217,8 +253,6 @@ def main():
         extras["blas_build_device"] = builds
         torch.cuda.empty_cache()
 
-    if not args.no_extras and rank == 0:
-        guarded_extra("builds", extra_builds)
 
     def extra_bvh4_and_collision():
         # BVH4 (row a16): collapse time and closest_hit4 rate on C2's 100k-triangle BLAS, same coherent 1 M rays as the BVH2 extra
@@ -253,8 +287,6 @@ def main():
         extras["collide_instances_5000"] = {"pairs": res.num_contacts, "device_ms": round(tc.last_kernel_ms(), 3)}
         tc.free()
 
-    if not args.no_extras and rank == 0:
-        guarded_extra("bvh4_collision", extra_bvh4_and_collision)
 
     def extra_view_factors():
         # view_factors (BASELINE config C5: ~50k-triangle closed scene, rays_per_triangle = 4096 => 204.9 M rays, N x N
@@ -294,7 +326,16 @@ def main():
         if rank == 0:
             extras["view_factors_c5"] = vf
 
-    node_f, inst_f = C3_NODE_FETCHES_PER_RAY, C3_INST_ENTRIES_PER_RAY
+    def load_json(rel):
+        try:
+            return json.load(open(os.path.join(ROOT, rel)))
+        except Exception:  # noqa: BLE001
+            return None
+
+    counts = load_json(COUNTS_FILE) or {}
+    node_f = float(counts.get("node_fetches_per_ray", C3_NODE_FETCHES_PER_RAY))
+    inst_f = float(counts.get("instance_entries_per_ray", C3_INST_ENTRIES_PER_RAY))
+    counts_source = COUNTS_FILE if counts else "bench.py constants (round-1 oracle run)"
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The oracle is the checker / CPU baseline only; nothing above this line touches it.
@@ -307,15 +348,23 @@ def main():
                 o.add_instance(b, x, int(i))
         o.build()
         cores = os.cpu_count() or 1
-        o.trace(rays[:65536], nthreads=cores)  # warm
+        o.trace(rays, nthreads=cores)  # warm: creates the oracle's worker pool, faults the result pages in
         cdt = 1e30
         for _ in range(5):  # 5 passes over the whole batch, best one reported (a single 0.3 s pass on 256 threads is noisy)
             c0 = time.perf_counter()
             ohits, cnt = o.trace(rays, nthreads=cores, counters=True)
             cdt = min(cdt, time.perf_counter() - c0)
         node_f, inst_f = float(cnt[:, 0].mean()), float(cnt[:, 1].mean())
+        counts_source = "instrumented oracle, this run"
         same = bool(np.array_equal(ohits["primitive_id"], hits["primitive_id"]) and np.array_equal(ohits["instance_id"], hits["instance_id"])
                     and np.array_equal(ohits["t"].view(np.uint32), hits["t"].view(np.uint32)))
+        # one thread on a bounded sample (every 16th ray: the same image, 262 144 rays, a fraction of a second) -- separates the
+        # algorithm's per-core rate from the harness's scaling
+        sample = np.ascontiguousarray(rays[::16])
+        o.trace(sample[:4096], nthreads=1)
+        s0 = time.perf_counter()
+        o.trace(sample, nthreads=1)
+        sdt = time.perf_counter() - s0
         cpu_model = "unknown"
         try:
             for line in open("/proc/cpuinfo"):
@@ -326,18 +375,42 @@ def main():
             pass
         cpu_baseline = {"value": round(n / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
                         "sample": f"all {n} primary rays of the workload, closest_hit, C restatement of the reference algorithm "
-                                  f"(oracle/, gcc -O2, {cores} pthreads), best of 5 passes, {cdt:.2f} s per pass", "gpu_matches_bit_exact": same}
+                                  f"(oracle/, gcc -O2, persistent pool of {cores} pthreads, dynamic 4096-ray chunks), best of 5 passes, {cdt:.2f} s per pass",
+                        "single_thread": {"value": round(len(sample) / sdt / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                                          "sample": f"every 16th ray of the batch ({len(sample)} rays), one pass, {sdt:.2f} s"},
+                        "gpu_matches_bit_exact": same}
+        try:
+            json.dump({"workload": "C3 primary rays, 2048 x 2048", "node_fetches_per_ray": node_f, "instance_entries_per_ray": inst_f,
+                       "source": "oracle/ (instrumented reference algorithm), bench.py cpu_baseline leg"}, open(os.path.join(ROOT, COUNTS_FILE), "w"), indent=1)
+        except OSError:
+            pass
 
     if rank == 0:
         bytes_per_ray = 32 + 32 + 60.0 * node_f + 140.0 * inst_f
-        achieved = bytes_per_ray * n / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("c3_closest_bytes_per_launch")
-            except Exception:
-                traffic = None
+        alg_gbs = bytes_per_ray * n / (launch_ms * 1e-3) / 1e9
+        pmc = load_json(COUNTER_FILE) or {}
+        c = pmc.get("counters_mean_per_launch", {})
+        valu = c.get("SQ_INSTS_VALU")
+        traffic = (pmc.get("hbm") or {}).get("c3_closest_bytes_per_launch")
+        kname = {-1: "k_trace_phased_lds<false, 768, 16, 6>", 5: "k_trace_phased_lds<false, 768, 16, 6>", 3: "k_trace_phased<false, 24, 6, false>"}.get(t.get_option("kernel"), f"kernel option {t.get_option('kernel')}")
+        if valu and args.res == 2048:
+            achieved = valu / (launch_ms * 1e-3) / 1e9
+            roofline = {"bound": "valu-issue", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s",
+                        "frac": round(achieved / VALU_PEAK_GINST_S, 4), "traffic": traffic, "kernel": kname, "avg_launch_ms": round(launch_ms, 4),
+                        "valu_wave_instructions_per_launch": valu,
+                        "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0), 4) if c.get("SQ_THREAD_CYCLES_VALU") else None,
+                        "hbm_physical_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                        "vmem_wave_instructions_per_launch": c.get("SQ_INSTS_VMEM_RD"),
+                        "sources": {"valu_wave_instructions_per_launch, lane_utilisation, traffic": COUNTER_FILE + " (rocprofv3 --pmc passes over this bench command, tools/capture_profiles.sh; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md)",
+                                    "avg_launch_ms": "HIP events around every timed launch, this run",
+                                    "peak": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction; profiles/r02_valu_probe.txt has the measured per-opcode rates",
+                                    "node / instance counts": counts_source}}
+        else:  # no counter file for this configuration: only the section-8d figure can be given, and it is not a utilisation
+            roofline = {"bound": "valu-issue", "achieved": None, "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s", "frac": None, "traffic": traffic,
+                        "kernel": kname, "avg_launch_ms": round(launch_ms, 4), "sources": {"note": f"{COUNTER_FILE} missing or --res differs from the profiled 2048"}}
+        roofline["algorithmic_vs_hbm"] = {"achieved_GBs": round(alg_gbs, 1), "peak_GBs": HBM_PEAK_GBS, "ratio": round(alg_gbs / HBM_PEAK_GBS, 4),
+                                          "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3),
+                                          "note": "SURVEY section 8d's figure; > 1 because the reference algorithm's node / instance bytes are served from LDS, L1 and L2, not HBM"}
         out = {
             "metric": "Mrays/s closest_hit (1M-tri TLAS)", "value": round(world * n * args.steps / elapsed / 1e6, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -346,13 +419,7 @@ def main():
                                    f"{n} pinhole primary rays per GPU per step, closest_hit",
                        "triangles": int(n_tris), "rays_per_step_per_gpu": n, "hit_fraction": round(hit_frac, 4),
                        "kernel": {-1: "auto (phased persistent, top level in LDS)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased", 4: "phased + top level in LDS, 1024-thread workgroups", 5: "phased + top level in LDS"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": {-1: "k_trace_phased_lds<false, 768, 16, 6>", 5: "k_trace_phased_lds<false, 768, 16, 6>", 3: "k_trace_phased<false, 24, 6, false>"}.get(t.get_option("kernel"), f"kernel option {t.get_option('kernel')}"), "avg_launch_ms": round(launch_ms, 4),
-                         "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3),
-                         # the scene is L1/L2 resident (see traffic), so the physical ceiling is the 64-byte gather rate of the vector-memory / LDS
-                         # paths, not HBM: 64 B per node or instance-record visit against the 11.7 TB/s measured by tools/td_probe.hip
-                         "cache_gather": {"achieved_GBs": round((node_f + inst_f) * 64.0 * n / (launch_ms * 1e-3) / 1e9, 1), "vector_memory_ceiling_GBs": 11700.0,
-                                          "note": "the default kernel reads the TLAS half of the visits, the instance records and the top of the single BLAS from LDS, which is how it can pass the vector-memory-only gather ceiling"}},
+            "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "extras": extras,
         }
@@ -372,26 +439,76 @@ def main():
         print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
 
     if not args.no_extras and args.backend == "nccl":
-        # The view-factor extra is the only measurement with collectives in it.  It runs last, with the headline result already
-        # assembled, under a watchdog: if a rank fails inside a collective the others would wait for ever, and a hung extra must not
-        # cost the headline line -- every rank gives up together, rank 0 prints what it has.
+        # The view-factor extra is the only measurement with collectives in it.  It runs first among the extras, with the headline
+        # result already assembled, under a watchdog: if a rank fails inside a collective the others would wait for the process
+        # group's time-out, and a hung extra must not cost the headline line -- rank 0 prints what it has, then every rank exits
+        # NON-ZERO (a launcher must not read a hung run as a success).
         import threading
         finished = threading.Event()
 
         def watchdog():
-            if not finished.wait(300.0):
-                extras["view_factors_error"] = "timed out after 300 s (a rank left the collective sequence?)"
+            if not finished.wait(360.0):
+                extras["view_factors_error"] = "timed out after 360 s (a rank left the collective sequence?)"
                 emit()
-                os._exit(0)
+                os._exit(3)
 
         if world > 1:
             threading.Thread(target=watchdog, daemon=True).start()
         guarded_extra("view_factors", extra_view_factors)
         finished.set()
     if use_dist:
+        # every collective is behind us: the peers leave now instead of idling inside RCCL while rank 0 runs its single-GPU extras
+        failed = torch.tensor([1 if any(k.endswith("_error") for k in extras) else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
         dist.barrier()
         dist.destroy_process_group()
+        if rank != 0:
+            raise SystemExit(3 if int(failed.item()) else 0)
+        if int(failed.item()) and "view_factors_error" not in extras:
+            extras["view_factors_error"] = "a peer rank failed inside the view-factor extra"
+    if not args.no_extras and rank == 0:
+        guarded_extra("traces", extra_traces)
+        guarded_extra("builds", extra_builds)
+        guarded_extra("bvh4_collision", extra_bvh4_and_collision)
     emit()
+    if any(k == "view_factors_error" for k in extras) and world > 1:
+        raise SystemExit(3)
+
+
+def dry_run(args, rank, world):
+    """No GPU: the same control flow -- process group, barrier-bracketed timed region, max over ranks, peers leaving before rank 0's
+    single-process tail, ONE JSON line from rank 0 -- with a sleep standing in for the launch.  Used by the CPU tests."""
+    import torch
+    import torch.distributed as dist
+    use_dist = world > 1
+    if use_dist:
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    n = args.res * args.res
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "Mrays/s closest_hit (1M-tri TLAS)", "value": round(world * n * args.steps / elapsed / 1e6, 1), "unit": "Mrays/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dry run (no GPU work)",
+                          "config": {"workload": "dry run"}, "roofline": None, "cpu_baseline": None}), flush=True)
+    return 0
 
 
 if __name__ == "__main__":

@@ -193,8 +193,13 @@ int rc_get_illumination_device(rc_scene* scene, const float viewdir[3], uint32_t
  * which is what makes a contiguous source range own a contiguous row block.  Julia's column-major N x N
  * Matrix is row_stride=1, col_stride=N, row_offset=0, flags=0; a row-sharded block is row_stride=N,
  * col_stride=1, row_offset=src_begin, flags=RC_VF_ROW_BY_PRIMITIVE (the gatherer then permutes rows by
- * metadata once). */
+ * metadata once).  With RC_VF_SOURCES_BY_METADATA, [src_begin, src_end) are positions in the primitives' order
+ * by ascending metadata (ties by flat index) and row = that position: when the metadata are a permutation of
+ * 1..N -- the view-factor convention, src/kernels.jl:85 -- position p IS matrix row src_meta-1, so a contiguous
+ * source range owns a contiguous block of FINAL rows and a multi-GPU gather / reduce needs no row permutation
+ * and no second N x N buffer. */
 #define RC_VF_ROW_BY_PRIMITIVE 1u
+#define RC_VF_SOURCES_BY_METADATA 2u
 int rc_view_factors_device(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin,
                            uint32_t src_end, uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix,
                            uint64_t row_stride, uint64_t col_stride, uint32_t row_offset, uint32_t flags, void* stream);

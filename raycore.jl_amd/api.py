@@ -123,6 +123,10 @@ class TLAS:
         self.device = int(device)
         self._static = StaticTLAS(self)
         self._prims_cache = None
+        # Triangle{TMeta} for any TMeta (src/triangle_mesh.jl:1-7): the library keeps one uint32 per primitive; metadata that is not a
+        # 32-bit unsigned integer is interned here and the word holds its 1-based index (`intern_metadata`, `typed_metadata`).
+        self._meta_table = None
+        self.meta_type = np.uint32
 
     # -- lifetime -------------------------------------------------------------------------------------
     def save(self, path):
@@ -397,6 +401,32 @@ class TLAS:
         check(lib().rc_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def intern_metadata(self, values):
+        """Metadata words for `values`: the values themselves when they are all uint32-representable integers and the accel is still
+        in uint32 mode (TMetadata = UInt32, the reference's default), otherwise 1-based indices into the accel's metadata table."""
+        values = list(values)
+        ints = all(isinstance(v, (int, np.integer)) and not isinstance(v, (bool, np.bool_)) and 0 <= int(v) <= 0xFFFFFFFF for v in values)
+        if ints and self._meta_table is None:
+            return np.array(values, dtype=np.uint32)
+        if self._meta_table is None:
+            if self.n_geometries() > 0:
+                raise RaycoreError(_capi.RC_ERR_INVALID_ARGUMENT, "an accel's metadata type is fixed by its first geometry (Triangle{TMetadata})")
+            self._meta_table = []
+            self.meta_type = type(values[0]) if values else object
+        base = len(self._meta_table)
+        self._meta_table.extend(values)
+        return np.arange(base + 1, base + 1 + len(values), dtype=np.uint32)
+
+    def typed_metadata(self, word):
+        """The metadata value a primitive's uint32 word stands for (identity in uint32 mode; 0 = the empty triangle's metadata)."""
+        if self._meta_table is None:
+            return word
+        word = int(word)
+        return self._meta_table[word - 1] if word >= 1 else None
+
+    def eltype(self):  # Base.eltype(tlas), src/instanced-bvh.jl:2334-2345
+        return ("Triangle", self.meta_type)
+
     def _prims(self):
         if self._prims_cache is None:
             self._prims_cache = self._static.all_blas_prims
@@ -436,7 +466,11 @@ def _tuple_from_hit(t, h, miss_prim):
         return (False, miss_prim, np.float32(0), np.zeros(3, np.float32), np.uint32(0))
     u, v = h["bary_u"], h["bary_v"]
     w = (np.float32(1.0) - u) - v  # 1f0 - hit_u - hit_v (:2015)
-    return (True, _triangle(t._triangles()[h["primitive_id"]]), h["t"], np.array([w, u, v], np.float32), np.uint32(h["instance_id"] + 1))
+    return (True, _typed(t, _triangle(t._triangles()[h["primitive_id"]])), h["t"], np.array([w, u, v], np.float32), np.uint32(h["instance_id"] + 1))
+
+
+def _typed(t, tri):
+    return tri if t._meta_table is None else tri._replace(metadata=t.typed_metadata(tri.metadata))
 
 
 def closest_hit(accel, ray):
@@ -450,7 +484,7 @@ def any_hit(accel, ray):
     t = _owner(accel)
     h = t.trace(_as_rays(ray), mode="any")[0]
     tris = t._triangles()
-    dummy = _triangle(tris[0]) if len(tris) else EMPTY_TRIANGLE
+    dummy = _typed(t, _triangle(tris[0])) if len(tris) else EMPTY_TRIANGLE
     return _tuple_from_hit(t, h, dummy)
 
 
@@ -589,12 +623,20 @@ def hits_from_grid(accel, viewdir, grid_size=32):
         # sum_mul (src/math.jl:52): a[1]*b[1] + a[2]*b[2] + a[3]*b[3], left to right, in Float32
         out["point"][m] = (w[:, None] * p["v"][:, 0] + u[:, None] * p["v"][:, 1]) + v[:, None] * p["v"][:, 2]
         out["metadata"][m] = p["meta"]
-    return out.reshape(grid_size, grid_size, order="F")
+    out = out.reshape(grid_size, grid_size, order="F")
+    if t._meta_table is not None:  # RayHit{TMetadata}: the typed values ride along as an object array of the same shape
+        typed = np.empty(out.shape, dtype=object)
+        for idx in np.ndindex(out.shape):
+            typed[idx] = t.typed_metadata(out["metadata"][idx]) if out["hit"][idx] else None
+        return out, typed
+    return out
 
 
 def get_centroid(accel, viewdir, grid_size=32):
     """get_centroid (src/kernels.jl:106-110): the hit points and their mean."""
     hits = hits_from_grid(accel, viewdir, grid_size)
+    if isinstance(hits, tuple):
+        hits = hits[0]
     pts = hits["point"][hits["hit"]]
     return pts, (pts.mean(axis=0) if len(pts) else np.full(3, np.nan, np.float32))
 
@@ -623,7 +665,7 @@ def TLAS_from_items(items, metadata_fn, device=0):
     t = TLAS(device)
     for mi, verts in enumerate(items, start=1):
         verts = np.asarray(verts, dtype=np.float32).reshape(-1, 9)
-        meta = np.array([metadata_fn(mi, fi) for fi in range(1, len(verts) + 1)], dtype=np.uint32)
+        meta = t.intern_metadata([metadata_fn(mi, fi) for fi in range(1, len(verts) + 1)])  # TMetadata = typeof(metadata_fn(1, 1)), :2281-2282
         b = t.add_geometry(verts, meta)
         ident = np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]], dtype=np.float32)
         t.push_instances(b, ident, [mi], inv_transforms=ident)  # identity for both, :2314-2320

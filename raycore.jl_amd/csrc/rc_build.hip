@@ -788,6 +788,7 @@ void rc_build_tlas(rc_scene* s) {
     }
     s->n_flat_nodes = tn; s->n_flat_prims = tp;
     s->flat_attrs_valid = false;
+    s->vf_order_valid = false;
     s->flat_nodes.reserve((size_t)tn + 2 * (size_t)n + 1);  // + room for the TLAS copy behind the BLAS nodes
     s->flat_prims.reserve(tp ? tp : 1);
     s->d_descs.reserve(nb ? nb : 1);

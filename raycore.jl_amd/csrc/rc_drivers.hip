@@ -216,15 +216,18 @@ __device__ inline RcRay view_factor_ray(const RcPrim& tri, uint32_t src, uint32_
 // primitive's metadata differs.  One u32 atomic per counted ray.  Runs on the persistent phased traversal core.
 struct ViewFactorSource {
     const RcPrim* prims;
+    const uint32_t* order;  // RC_VF_SOURCES_BY_METADATA: source position -> flat primitive index, else nullptr (position = index)
     uint32_t k0, k1, src_begin, ray_begin, n_ray;
     __device__ inline RcRay operator()(uint64_t w) const {
-        const uint32_t src = src_begin + (uint32_t)(w / n_ray), ray_idx = ray_begin + (uint32_t)(w % n_ray);
-        return view_factor_ray(prims[src], src, ray_idx, k0, k1);
+        const uint32_t pos = src_begin + (uint32_t)(w / n_ray), ray_idx = ray_begin + (uint32_t)(w % n_ray);
+        const uint32_t src = order ? order[pos] : pos;
+        return view_factor_ray(prims[src], src, ray_idx, k0, k1);  // Philox is keyed by the PRIMITIVE index: the rays do not depend on the addressing
     }
 };
 struct ViewFactorSink {
     const RcInstRec* inst;
     const RcPrim* prims;
+    const uint32_t* order;
     uint32_t n_prims, src_begin, n_ray;
     uint32_t* matrix;
     uint64_t row_stride, col_stride;
@@ -233,32 +236,39 @@ struct ViewFactorSink {
         bool counted = false;
         unsigned long long index = 0;
         if (hit) {
-            const uint32_t src = src_begin + (uint32_t)(w / n_ray);
+            const uint32_t pos = src_begin + (uint32_t)(w / n_ray);
+            const uint32_t src = order ? order[pos] : pos;
             const uint4 m3 = *(reinterpret_cast<const uint4*>(inst + instance) + 3);
             const uint32_t hit_meta = prims[m3.y + prim - 1u].meta, src_meta = prims[src].meta;
             counted = hit_meta != src_meta && src_meta >= 1 && src_meta <= n_prims && hit_meta >= 1 && hit_meta <= n_prims;
-            if (counted) index = (uint64_t)(((flags & 1u) ? src : src_meta - 1) - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride;
+            const uint32_t row = (flags & 2u) ? pos : ((flags & 1u) ? src : src_meta - 1);
+            if (counted) index = (uint64_t)(row - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride;
         }
         wave_count(matrix, index, counted);
     }
 };
 __global__ __launch_bounds__(kBlock, 6) void k_view_factors(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin,
                                                              uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
-                                                             uint64_t col_stride, uint32_t row_offset, uint32_t flags) {
+                                                             uint64_t col_stride, uint32_t row_offset, uint32_t flags, const uint32_t* order) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    phased_trace<false, kLdsStack, false>(v, p, lds_stack, ViewFactorSource{v.prims, k0, k1, src_begin, ray_begin, n_ray},
-                                          ViewFactorSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags});
+    phased_trace<false, kLdsStack, false>(v, p, lds_stack, ViewFactorSource{v.prims, order, k0, k1, src_begin, ray_begin, n_ray},
+                                          ViewFactorSink{v.inst, v.prims, order, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags});
 }
 __global__ __launch_bounds__(kMidBlock, 6) void k_view_factors_lds(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin,
                                                                     uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
-                                                                    uint64_t col_stride, uint32_t row_offset, uint32_t flags) {
+                                                                    uint64_t col_stride, uint32_t row_offset, uint32_t flags, const uint32_t* order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsTop top(smem + (size_t)kMidStack * kMidBlock * 4);
     stage_lds_top<kMidBlock>(top, v, p.blas_k, p.lds_blas_base);
     __syncthreads();
     phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorSink, kMidBlock, true, true>(
-        v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, k0, k1, src_begin, ray_begin, n_ray},
-        ViewFactorSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags}, top);
+        v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, order, k0, k1, src_begin, ray_begin, n_ray},
+        ViewFactorSink{v.inst, v.prims, order, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags}, top);
+}
+
+__global__ void k_meta_keys(const RcPrim* prims, uint32_t n, uint32_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = prims[i].meta; vals[i] = i; }
 }
 
 __global__ void k_view_factor_rays(SceneView v, uint32_t k0, uint32_t k1, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* out) {
@@ -441,6 +451,21 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     if (src_begin >= src_end || ray_begin >= ray_end) return;
     check_buffer_range(s);
     uint64_t total = (uint64_t)(src_end - src_begin) * (ray_end - ray_begin);
+    const uint32_t* order = nullptr;
+    if (flags & 2u) {  // RC_VF_SOURCES_BY_METADATA: the flat primitives' indices sorted by (metadata, index), cached until the next rebuild
+        if (!s->vf_order_valid) {
+            const uint32_t np = s->n_flat_prims;
+            s->keys_a.reserve(np); s->keys_b.reserve(np); s->vals_a.reserve(np); s->vf_order.reserve(np);
+            hipLaunchKernelGGL(k_meta_keys, dim3((np + 255) / 256), dim3(256), 0, stream, s->flat_prims.p, np, s->keys_a.p, s->vals_a.p);
+            size_t tmp = 0;
+            RC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vf_order.p, (int)np, 0, 32, stream));
+            s->sort_tmp.reserve(tmp ? tmp : 1);
+            RC_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vf_order.p, (int)np, 0, 32, stream));  // stable: ties keep the flat order
+            RC_HIP(hipStreamSynchronize(stream));  // the scratch arrays are shared with the builds on the scene's own stream
+            s->vf_order_valid = true;
+        }
+        order = s->vf_order.p;
+    }
     const bool lds = rc_lds_driver_ok(s);
     const uint32_t bs = lds ? (uint32_t)kMidBlock : (uint32_t)kBlock;
     uint32_t blocks = lds ? rc_lds_driver_blocks(s, total) : rc_persistent_blocks(s, total);
@@ -455,10 +480,10 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
             s->lds_attr_set[5] = true;
         }
         hipLaunchKernelGGL(k_view_factors_lds, dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, v, p, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
-                           ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags);
+                           ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags, order);
     } else
     hipLaunchKernelGGL(k_view_factors, dim3(blocks), dim3(kBlock), 0, stream, v, p, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
-                       ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags);
+                       ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags, order);
     RC_HIP(hipEventRecord(s->ev1, stream));
     RC_HIP(hipGetLastError());
     rc_claim_commit(s, stream);

@@ -168,6 +168,8 @@ struct rc_scene {
     DevBuf<uint32_t> slot_face;       // rc_add_mesh: source face of every compacted slot
     DevBuf<float> flat_attrs;         // 15 floats per flat primitive (normals 9, uv 6), built on demand after a rebuild
     bool flat_attrs_valid = false;
+    DevBuf<uint32_t> vf_order;        // flat primitive indices by ascending metadata (RC_VF_SOURCES_BY_METADATA), built on demand after a rebuild
+    bool vf_order_valid = false;
     DevBuf<uint32_t> compact_flags, compact_pos;  // rc_compact_hits scratch
     DevBuf<unsigned char> compact_tmp;
     DevBuf<uint32_t> collide_counts;  // collide_instances' per-leaf counts / prefix sums (the reference's `cache`)

@@ -6,16 +6,22 @@ Only the parts of the path that shard get a collective:
   splits the ray array, no data-path collective.
 * view_factors (src/kernels.jl:74-104): every (source primitive, ray) pair is independent and draws its
   randomness from Philox keyed by (seed; ray, source), so the job can be cut either way and the result is
-  bit-identical to the single-GPU matrix:
-    - mode="rays"  (the north-star wording): every rank shoots rays [r0, r1) of ALL source primitives into a
-      full N x N accumulator, then ONE reduce(SUM) of the accumulators over RCCL.  Message = 4 N^2 bytes.
-    - mode="rows_sharded": like "rows" below but the result STAYS sharded (each rank returns its own row block and the
-      metadata of its rows): no collective at all -- the layout a row-parallel consumer (e.g. a radiosity solve) wants,
-      and the only one whose cost does not grow with N^2 bytes over xGMI.
-    - mode="rows": rank g owns source primitives [s0, s1) and shoots all their rays into its own
-      (s1 - s0) x N row block; rows are disjoint (result[src, :] is written only by src, :85-97), so the
-      exchange is a gather of row blocks -- each byte crosses xGMI once, the 7 peers use the root's 7
-      distinct links concurrently.  Preferred when N is large (N = 50k: 10 GB matrix).
+  bit-identical to the single-GPU matrix.  Sources are addressed in METADATA order (RC_VF_SOURCES_BY_METADATA):
+  with the view-factor convention metadata = a permutation of 1..N, a contiguous source range is a contiguous block of
+  FINAL matrix rows, so no partition needs a row permutation or a second N x N buffer.
+    - mode="rows_sharded": rank g owns rows [gN/G, (g+1)N/G), shoots all their rays into its own block and the result STAYS
+      sharded (block + row index): no collective at all -- the layout a row-parallel consumer (e.g. a radiosity solve)
+      wants, and the only one whose cost does not include 4 N^2 bytes over xGMI.
+    - mode="rows": the same compute, then the blocks are collected on rank `dst`: the root traces straight into its
+      slice of the final matrix and receives every peer's block straight into that peer's slice (point-to-point, all peers
+      at once: xGMI is point-to-point, the G-1 transfers use the root's G-1 links concurrently) -- each byte crosses xGMI
+      once, nothing is padded, copied or permuted afterwards.
+    - mode="rays" (the north-star wording): every rank shoots rays [r0, r1) of ALL sources into a full N x N accumulator
+      and the accumulators are summed on `dst` with RCCL reduce.  The job is cut into row chunks: while chunk k is being
+      traced the reduce of chunk k-1 is in flight (async_op), so all but the last chunk's exchange hides behind tracing
+      as far as the link budget allows (DESIGN.md section 5 has the byte / time budget).
+  Metadata that are not a permutation of 1..N (duplicates, gaps) take the general path: rows addressed by primitive,
+  one index_add by metadata on the root.
 * get_illumination: the ray grid is cut into contiguous ranges, each rank histograms its range, one
   reduce(SUM) of N floats (exact: integer-valued f32 counts).
 
@@ -26,6 +32,8 @@ import numpy as np
 
 from . import _capi
 from ._capi import check, lib, ptr
+
+VF_ROW_BY_PRIMITIVE, VF_SOURCES_BY_METADATA = 1, 2
 
 
 def shard_range(n, rank, world):
@@ -38,79 +46,148 @@ def _dist():
     return dist
 
 
+def _ranks(group):
+    """(world size, this process's rank IN THE GROUP, its global rank).  Sharding uses the group rank; `dst` arguments are
+    global ranks, as everywhere in torch.distributed."""
+    dist = _dist()
+    if not dist.is_initialized():
+        return 1, 0, 0
+    return dist.get_world_size(group), dist.get_rank(group), dist.get_rank()
+
+
+def _global_rank(group, group_rank):
+    dist = _dist()
+    if group is None or not dist.is_initialized():
+        return group_rank
+    return dist.get_global_rank(group, group_rank)
+
+
 def _gpu_view_factors(tlas, rays_per_triangle, seed):
-    def compute(local, src, rays, row_stride, col_stride, row_offset, by_prim):
+    def compute(local, src, rays, row_stride, col_stride, row_offset, addressing):
         import torch
+        flags = {None: 0, "primitive": VF_ROW_BY_PRIMITIVE, "metadata": VF_SOURCES_BY_METADATA}[addressing]
         check(lib().rc_view_factors_device(tlas._h, int(rays_per_triangle), int(seed), src[0], src[1], rays[0], rays[1],
-                                           ptr(local.data_ptr()), row_stride, col_stride, row_offset, 1 if by_prim else 0,
+                                           ptr(local.data_ptr()), row_stride, col_stride, row_offset, flags,
                                            ptr(torch.cuda.current_stream().cuda_stream) or None))
     return compute
 
 
 def view_factors_distributed(tlas, rays_per_triangle=10000, seed=0, mode="rows", group=None, dst=0, n_prims=None,
-                             compute=None, device=None, prim_meta=None):
-    """view_factors sharded over the ranks of `group`.  Returns, on rank `dst`, an int32 torch tensor whose
+                             compute=None, device=None, prim_meta=None, chunks=None):
+    """view_factors sharded over the ranks of `group`.  Returns, on global rank `dst`, an int32 torch tensor whose
     uint32 view is the N x N matrix M[src_meta-1, hit_meta-1] (row-major; Julia's Matrix is its transpose in
     memory); other ranks return None.  mode="rows_sharded" returns (block, row_index) on EVERY rank instead: block[r]
-    is matrix row row_index[r].  `compute(local, (s0,s1), (r0,r1), row_stride, col_stride, row_offset,
-    by_prim)` must ACCUMULATE into `local`; the default launches the HIP kernel through the C ABI.
-    prim_meta: metadata of the flat (Morton-sorted) primitive array (default: read back from the scene)."""
+    is matrix row row_index[r].  `compute(local, (s0,s1), (r0,r1), row_stride, col_stride, row_offset, addressing)` must
+    ACCUMULATE into `local`; addressing = "metadata" (source positions and rows in metadata order), "primitive" (flat
+    primitive order) or None (sources by primitive, rows by metadata); the default launches the HIP kernel through the C ABI.
+    prim_meta: metadata of the flat (Morton-sorted) primitive array (default: read back from the scene).
+    chunks: row chunks of the pipelined "rays" exchange (default: about 256 MiB of matrix per chunk, at least 2 x world)."""
     import torch
     dist = _dist()
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank, me = _ranks(group)
     n = int(n_prims if n_prims is not None else tlas.n_primitives())
+    rpt = int(rays_per_triangle)
     if device is None:
         device = torch.device("cuda", tlas.device)
     if compute is None:
-        compute = _gpu_view_factors(tlas, rays_per_triangle, seed)
-    if mode == "rays":
-        r0, r1 = shard_range(int(rays_per_triangle), rank, world)
-        local = torch.zeros(n * n, dtype=torch.int32, device=device)
-        compute(local, (0, n), (r0, r1), n, 1, 0, False)  # row-major [src_meta-1][hit_meta-1]
-        if world > 1:
-            dist.reduce(local, dst=dst, op=dist.ReduceOp.SUM, group=group)
-        return local.view(n, n) if rank == dst else None
+        compute = _gpu_view_factors(tlas, rpt, seed)
+    if prim_meta is None:
+        prim_meta = tlas._prims()["meta"]
+    meta = np.asarray(prim_meta).astype(np.int64)
+    order = np.argsort(meta, kind="stable")                 # position in metadata order -> flat primitive index
+    is_perm = len(meta) == n and np.array_equal(meta[order], np.arange(1, n + 1))
+    if mode not in ("rays", "rows", "rows_sharded"):
+        raise ValueError("mode must be 'rays', 'rows' or 'rows_sharded'")
+
     if mode == "rows_sharded":
         s0, s1 = shard_range(n, rank, world)
         local = torch.zeros((s1 - s0) * n, dtype=torch.int32, device=device)
-        compute(local, (s0, s1), (0, int(rays_per_triangle)), n, 1, s0, True)
-        if prim_meta is None:
-            prim_meta = tlas._prims()["meta"]
-        # row r of the block belongs to matrix row prim_meta[s0 + r] - 1
-        return local.view(s1 - s0, n), np.asarray(prim_meta)[s0:s1].astype(np.int64) - 1
+        compute(local, (s0, s1), (0, rpt), n, 1, s0, "metadata")
+        # row r of the block is the source at position s0 + r of the metadata order: matrix row meta - 1 (= s0 + r for a permutation)
+        return local.view(s1 - s0, n), meta[order[s0:s1]] - 1
+
+    if not is_perm:
+        return _view_factors_general(dist, group, world, rank, me, dst, mode, n, rpt, compute, device, meta)
+
     if mode == "rows":
+        out = torch.zeros(n * n if me == dst else 0, dtype=torch.int32, device=device)
         s0, s1 = shard_range(n, rank, world)
-        rows_max = max(shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world))
-        local = torch.zeros(rows_max * n, dtype=torch.int32, device=device)  # padded to the largest shard
-        # rows are indexed by the source's position in the Morton-sorted primitive array, so a contiguous
-        # source range owns a contiguous block; the root scatters rows to their metadata slot once.
-        compute(local, (s0, s1), (0, int(rays_per_triangle)), n, 1, s0, True)
-        if rank == dst:
+        if me == dst:
+            compute(out[s0 * n:s1 * n], (s0, s1), (0, rpt), n, 1, s0, "metadata")    # the root traces into its slice of the result
             if world > 1:
-                parts = [torch.empty_like(local) for _ in range(world)]
-                dist.gather(local, gather_list=parts, dst=dst, group=group)
-            else:
-                parts = [local]
-            if prim_meta is None:
-                prim_meta = tlas._prims()["meta"]
-            rows = torch.as_tensor(np.asarray(prim_meta).astype(np.int64) - 1, device=device)
-            out = torch.zeros(n, n, dtype=torch.int32, device=device)
-            for r, p in enumerate(parts):
-                a, b = shard_range(n, r, world)
-                out.index_add_(0, rows[a:b], p[:(b - a) * n].view(b - a, n))  # index_add: duplicate metadata accumulates, like the reference
-            return out
-        dist.gather(local, gather_list=None, dst=dst, group=group)
+                ops = []
+                for r in range(world):
+                    if r == rank:
+                        continue
+                    a, b = shard_range(n, r, world)
+                    ops.append(dist.P2POp(dist.irecv, out[a * n:b * n], _global_rank(group, r), group))
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return out.view(n, n)
+        local = torch.zeros((s1 - s0) * n, dtype=torch.int32, device=device)
+        compute(local, (s0, s1), (0, rpt), n, 1, s0, "metadata")
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst, group)]):
+            w.wait()
         return None
-    raise ValueError("mode must be 'rays', 'rows' or 'rows_sharded'")
+
+    # mode == "rays": a full accumulator per rank, reduced chunk by chunk while the next chunk is traced
+    r0, r1 = shard_range(rpt, rank, world)
+    local = torch.zeros(n * n, dtype=torch.int32, device=device)
+    if chunks is None:
+        chunks = max(2 * world, (4 * n * n + (256 << 20) - 1) // (256 << 20)) if world > 1 else 1
+    chunks = max(1, min(int(chunks), n))
+    pending = []
+    for k in range(chunks):
+        c0, c1 = shard_range(n, k, chunks)
+        slab = local[c0 * n:c1 * n]
+        compute(slab, (c0, c1), (r0, r1), n, 1, c0, "metadata")
+        if world > 1:
+            pending.append(dist.reduce(slab, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in pending:
+        w.wait()
+    return local.view(n, n) if me == dst else None
+
+
+def _view_factors_general(dist, group, world, rank, me, dst, mode, n, rpt, compute, device, meta):
+    """Metadata with duplicates or gaps: rows cannot be addressed by metadata position, so rows travel in primitive order and the
+    root folds them by metadata with one index_add (duplicates accumulate, as result[src_meta, :] does in the reference)."""
+    import torch
+    rows = torch.as_tensor(meta - 1, device=device)
+    if mode == "rays":
+        r0, r1 = shard_range(rpt, rank, world)
+        local = torch.zeros(n * n, dtype=torch.int32, device=device)
+        compute(local, (0, n), (r0, r1), n, 1, 0, None)  # row-major [src_meta-1][hit_meta-1]
+        if world > 1:
+            dist.reduce(local, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        return local.view(n, n) if me == dst else None
+    s0, s1 = shard_range(n, rank, world)
+    local = torch.zeros((s1 - s0) * n, dtype=torch.int32, device=device)
+    compute(local, (s0, s1), (0, rpt), n, 1, s0, "primitive")
+    if me != dst:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst, group)]):
+            w.wait()
+        return None
+    out = torch.zeros(n, n, dtype=torch.int32, device=device)
+    valid = (rows >= 0) & (rows < n)
+    for r in range(world):
+        a, b = shard_range(n, r, world)
+        if r == rank:
+            part = local
+        else:
+            part = torch.empty((b - a) * n, dtype=torch.int32, device=device)
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, part, _global_rank(group, r), group)]):
+                w.wait()
+        sel = valid[a:b]
+        out.index_add_(0, rows[a:b][sel], part.view(b - a, n)[sel])
+        del part
+    return out
 
 
 def get_illumination_distributed(tlas, viewdir, grid_size=1000, group=None, dst=0, n_prims=None, compute=None, device=None):
     """get_illumination with the ray grid sharded over ranks and one reduce(SUM) of the N-float histogram."""
     import torch
     dist = _dist()
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank, me = _ranks(group)
     n = int(n_prims if n_prims is not None else tlas.n_primitives())
     if device is None:
         device = torch.device("cuda", tlas.device)
@@ -124,14 +201,12 @@ def get_illumination_distributed(tlas, viewdir, grid_size=1000, group=None, dst=
         compute(local, (b, e))
     if world > 1:
         dist.reduce(local, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    return local[:n] if rank == dst else None
+    return local[:n] if me == dst else None
 
 
 def trace_sharded(tlas, rays, mode="closest", group=None):
     """Replica tracing: this rank traces its contiguous shard of `rays` (RAY_DT array) and returns
     ((begin, end), hits) -- no collective; the caller concatenates shards if it needs the whole batch."""
-    dist = _dist()
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank, _ = _ranks(group)
     b, e = shard_range(len(rays), rank, world)
     return (b, e), tlas.trace(rays[b:e], mode=mode)

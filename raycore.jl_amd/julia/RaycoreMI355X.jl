@@ -31,19 +31,25 @@ mutable struct MI355XTLAS <: AbstractAccel
     ptr::Ptr{Cvoid}
     prims::Vector{Triangle{UInt32}}      # host copy of all_blas_prims (Morton-sorted), refreshed after a rebuild
     prims_valid::Bool
+    # Triangle{TMeta} for any TMeta (src/triangle_mesh.jl:1-7): the library keeps one UInt32 per primitive; for a metadata type other
+    # than UInt32 that word is an index into this table and the wrapper hands out Triangle{TMeta}(..., meta_table[word]).
+    meta_table::Vector{Any}
+    meta_type::DataType
     function MI355XTLAS(backend::MI355XBackend = MI355XBackend())
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:rc_scene_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), backend.device, ref))   # TLAS(backend), :334-358
-        tlas = new(backend, ref[], Triangle{UInt32}[], false)
+        tlas = new(backend, ref[], Triangle{UInt32}[], false, Any[], UInt32)
         finalizer(Raycore.free!, tlas)
         return tlas
     end
 end
+Base.eltype(t::MI355XTLAS) = Triangle{t.meta_type}                                            # Base.eltype(::TLAS), :2334-2341
 
 "The adapted form (StaticTLAS analogue, src/instanced-bvh.jl:155-168): what gets passed to trace calls."
 struct MI355XStaticTLAS <: AbstractAdaptedAccel
     owner::MI355XTLAS
 end
+Base.eltype(a::MI355XStaticTLAS) = eltype(a.owner)
 
 function Raycore.free!(t::MI355XTLAS)                                   # free!, :383-399
     t.ptr == C_NULL && return nothing
@@ -188,7 +194,7 @@ end
 function result_tuple(a::MI355XStaticTLAS, h::RTHitResult, miss_prim)
     h.hit == 0 && return (false, miss_prim, 0f0, SVector{3, Float32}(0, 0, 0), UInt32(0))
     w = 1f0 - h.bary_u - h.bary_v
-    return (true, primitives(a)[h.primitive_id + 1], h.t, SVector{3, Float32}(w, h.bary_u, h.bary_v), h.instance_id + UInt32(1))
+    return (true, typed_triangle(a.owner, primitives(a)[h.primitive_id + 1]), h.t, SVector{3, Float32}(w, h.bary_u, h.bary_v), h.instance_id + UInt32(1))
 end
 Raycore.closest_hit(a::MI355XStaticTLAS, ray::Raycore.AbstractRay) =
     result_tuple(a, trace(a, [to_rtray(ray)])[1], empty_triangle(Triangle{UInt32}))
@@ -209,6 +215,275 @@ function Raycore.view_factors(a::MI355XStaticTLAS; rays_per_triangle = 10000, se
     out = Matrix{UInt32}(undef, n, n)      # column-major, [src_meta, hit_meta] as in the reference
     check(ccall((:rc_view_factors, LIB), Cint, (Ptr{Cvoid}, UInt32, UInt64, Ptr{UInt32}), a.owner.ptr, rays_per_triangle, seed, out))
     return out
+end
+
+# the reference's RayHit (src/kernels.jl:1-5)
+struct RayHit{T}
+    hit::Bool
+    point::Point3f
+    metadata::T
+end
+metadata_of(t::MI355XTLAS, word::UInt32) = t.meta_type === UInt32 ? word : t.meta_table[word]
+typed_triangle(t::MI355XTLAS, tri::Triangle{UInt32}) = t.meta_type === UInt32 ? tri :
+    Triangle(tri.vertices, tri.normals, tri.tangents, tri.uv, metadata_of(t, tri.metadata))
+
+"hits_from_grid (src/kernels.jl:58-72): the ray grid is generated on the device (rc_generate_ray_grid_device is what the fused
+ drivers use; here the host-buffer trace is enough), hit point = sum_mul(bary, prim.vertices) in Float32."
+function hits_from_grid(a::MI355XStaticTLAS, viewdir; grid_size = 32)
+    dir = normalize(Vec3f(viewdir))
+    rays = ray_grid(a, dir, grid_size)
+    hits = trace(a, rays)
+    prims = primitives(a)
+    T = a.owner.meta_type
+    out = Matrix{RayHit{T}}(undef, grid_size, grid_size)
+    for k in eachindex(hits)
+        h = hits[k]
+        if h.hit == 0
+            out[k] = RayHit{T}(false, Point3f(0), metadata_of(a.owner, empty_triangle(Triangle{UInt32}).metadata + UInt32(T === UInt32 ? 0 : 1)))
+        else
+            p = prims[h.primitive_id + 1]
+            w = (1f0 - h.bary_u) - h.bary_v
+            out[k] = RayHit{T}(true, Point3f(w * p.vertices[1] + h.bary_u * p.vertices[2] + h.bary_v * p.vertices[3]), metadata_of(a.owner, p.metadata))
+        end
+    end
+    return out
+end
+"get_centroid (src/kernels.jl:106-110)"
+function Raycore.get_centroid(a::MI355XStaticTLAS, viewdir; grid_size = 32)
+    hits = hits_from_grid(a, viewdir; grid_size = grid_size)
+    pts = [h.point for h in hits if h.hit]
+    return pts, sum(pts) / length(pts)
+end
+
+# ---- device-pointer entry points: rays / hits / matrices that already live in HBM (ROCArray pointers, a HIP stream) ---------------
+"generate_ray_grid (src/kernels.jl:10-56) into a device buffer of grid^2 RTRay records."
+ray_grid_device!(a::MI355XStaticTLAS, viewdir, grid_size::Integer, d_rays::Ptr{RTRay}; stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_generate_ray_grid_device, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, UInt32, Ptr{RTRay}, Ptr{Cvoid}),
+                a.owner.ptr, Float32[viewdir...], grid_size, d_rays, stream))
+function ray_grid(a::MI355XStaticTLAS, viewdir, grid_size::Integer)   # host copy, through the host-buffer illumination path's generator
+    n = grid_size * grid_size
+    rays = Vector{RTRay}(undef, n)
+    # a device scratch buffer is the caller's business in a GPU pipeline; the host form stages through AMDGPU.jl when it is loaded
+    buf = device_alloc(sizeof(RTRay) * n)
+    ray_grid_device!(a, viewdir, grid_size, Ptr{RTRay}(buf))
+    Raycore.wait_for_gpu!(a.owner)
+    device_download!(rays, buf)
+    device_free(buf)
+    return rays
+end
+# minimal device-memory helpers over the HIP runtime the library already links (hipMalloc / hipMemcpy / hipFree)
+const HIP = get(ENV, "RAYCORE_MI355X_HIP", "libamdhip64.so")
+function device_alloc(bytes::Integer)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    ccall((:hipMalloc, HIP), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, bytes) == 0 || error("hipMalloc failed")
+    return p[]
+end
+device_free(p::Ptr{Cvoid}) = (ccall((:hipFree, HIP), Cint, (Ptr{Cvoid},), p); nothing)
+device_download!(dst::Vector, src::Ptr{Cvoid}) =
+    (ccall((:hipMemcpy, HIP), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), dst, src, sizeof(dst), 2) == 0 || error("hipMemcpy failed"); dst)
+
+"closest_hit / any_hit over device-resident RTRay / RTHitResult arrays, asynchronous on `stream` (errors surface at wait_for_gpu!)."
+trace_device!(a::MI355XStaticTLAS, d_rays::Ptr{RTRay}, d_hits::Ptr{RTHitResult}, n::Integer; any::Bool = false, stream::Ptr{Cvoid} = C_NULL) =
+    check(any ? ccall((:rc_trace_any_device, LIB), Cint, (Ptr{Cvoid}, Ptr{RTRay}, Ptr{RTHitResult}, UInt64, Ptr{Cvoid}), a.owner.ptr, d_rays, d_hits, n, stream) :
+                ccall((:rc_trace_closest_device, LIB), Cint, (Ptr{Cvoid}, Ptr{RTRay}, Ptr{RTHitResult}, UInt64, Ptr{Cvoid}), a.owner.ptr, d_rays, d_hits, n, stream))
+
+"One shard of get_illumination: rays [ray_begin, ray_end) of the grid, histogram ACCUMULATED into the device vector d_counts."
+illumination_device!(a::MI355XStaticTLAS, viewdir, grid_size::Integer, ray_begin::Integer, ray_end::Integer, d_counts::Ptr{Float32};
+                     stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_get_illumination_device, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, UInt32, UInt64, UInt64, Ptr{Float32}, Ptr{Cvoid}),
+                a.owner.ptr, Float32[viewdir...], grid_size, ray_begin, ray_end, d_counts, stream))
+
+"One shard of view_factors! (src/kernels.jl:80-104): source primitives [src_begin, src_end) x rays [ray_begin, ray_end), counts
+ ACCUMULATED into d_matrix at row * row_stride + col * col_stride (row = src_meta - 1, or the source's sorted position - row_offset
+ when by_primitive); the multi-GPU drivers (one process per GPU, RCCL) are built on this entry point."
+view_factors_device!(a::MI355XStaticTLAS, rays_per_triangle::Integer, seed::UInt64, src_begin::Integer, src_end::Integer,
+                     ray_begin::Integer, ray_end::Integer, d_matrix::Ptr{UInt32}, row_stride::Integer, col_stride::Integer;
+                     row_offset::Integer = 0, by_primitive::Bool = false, stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_view_factors_device, LIB), Cint,
+                (Ptr{Cvoid}, UInt32, UInt64, UInt32, UInt32, UInt32, UInt32, Ptr{UInt32}, UInt64, UInt64, UInt32, UInt32, Ptr{Cvoid}),
+                a.owner.ptr, rays_per_triangle, seed, src_begin, src_end, ray_begin, ray_end, d_matrix, row_stride, col_stride,
+                row_offset, by_primitive ? 1 : 0, stream))
+"The rays view_factors shoots for one source primitive (for inspection / tests)."
+view_factor_rays_device!(a::MI355XStaticTLAS, seed::UInt64, src_prim::Integer, ray_begin::Integer, n_rays::Integer, d_rays::Ptr{RTRay};
+                         stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_view_factor_rays_device, LIB), Cint, (Ptr{Cvoid}, UInt64, UInt32, UInt32, UInt32, Ptr{RTRay}, Ptr{Cvoid}),
+                a.owner.ptr, seed, src_prim, ray_begin, n_rays, d_rays, stream))
+
+# wavefront stages next to the trace (docs/src/wavefront-renderer.jl:219-476)
+hit_points_device!(a::MI355XStaticTLAS, d_rays::Ptr{RTRay}, d_hits::Ptr{RTHitResult}, n::Integer, d_points::Ptr{Float32},
+                   d_normals::Ptr{Float32} = Ptr{Float32}(C_NULL); stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_hit_points_device, LIB), Cint, (Ptr{Cvoid}, Ptr{RTRay}, Ptr{RTHitResult}, UInt64, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}),
+                a.owner.ptr, d_rays, d_hits, n, d_points, d_normals, stream))
+shadow_rays_device!(a::MI355XStaticTLAS, d_rays::Ptr{RTRay}, d_hits::Ptr{RTHitResult}, n::Integer, light, d_out::Ptr{RTRay};
+                    bias::Float32 = 0.01f0, stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_shadow_rays_device, LIB), Cint, (Ptr{Cvoid}, Ptr{RTRay}, Ptr{RTHitResult}, UInt64, Ptr{Float32}, Cfloat, Ptr{RTRay}, Ptr{Cvoid}),
+                a.owner.ptr, d_rays, d_hits, n, Float32[light...], bias, d_out, stream))
+reflection_rays_device!(a::MI355XStaticTLAS, d_rays::Ptr{RTRay}, d_hits::Ptr{RTHitResult}, n::Integer, d_out::Ptr{RTRay};
+                        bias::Float32 = 0.01f0, stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_reflection_rays_device, LIB), Cint, (Ptr{Cvoid}, Ptr{RTRay}, Ptr{RTHitResult}, UInt64, Cfloat, Ptr{RTRay}, Ptr{Cvoid}),
+                a.owner.ptr, d_rays, d_hits, n, bias, d_out, stream))
+shading_attributes_device!(a::MI355XStaticTLAS, d_hits::Ptr{RTHitResult}, n::Integer, d_normals::Ptr{Float32}, d_uvs::Ptr{Float32};
+                           stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_shading_attributes_device, LIB), Cint, (Ptr{Cvoid}, Ptr{RTHitResult}, UInt64, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}),
+                a.owner.ptr, d_hits, n, d_normals, d_uvs, stream))
+compact_hits_device!(a::MI355XStaticTLAS, d_hits::Ptr{RTHitResult}, n::Integer, d_indices::Ptr{UInt32}, d_count::Ptr{UInt32};
+                     stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_compact_hits_device, LIB), Cint, (Ptr{Cvoid}, Ptr{RTHitResult}, UInt64, Ptr{UInt32}, Ptr{UInt32}, Ptr{Cvoid}),
+                a.owner.ptr, d_hits, n, d_indices, d_count, stream))
+primary_rays_lookat_device!(a::MI355XStaticTLAS, pos, right, up, forward, half_width::Float32, half_height::Float32, width::Integer,
+                            height::Integer, d_rays::Ptr{RTRay}; samples::Integer = 1, seed::UInt64 = UInt64(0), jitter::Bool = true,
+                            stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_primary_rays_lookat_device, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cfloat, Cfloat, UInt32, UInt32, UInt32, UInt64, Cint, Ptr{RTRay}, Ptr{Cvoid}),
+                a.owner.ptr, Float32[pos...], Float32[right...], Float32[up...], Float32[forward...], half_width, half_height, width, height,
+                samples, seed, jitter ? 1 : 0, d_rays, stream))
+
+# instance_buffer(tlas, handle) + refit_tlas!(tlas) (src/Raycore.jl:117-128, src/instanced-bvh.jl:2197-2222): rewrite the handle's
+# InstanceDescriptor records on the device (the caller's own kernel), then commit without a host round trip.
+function Raycore.instance_buffer(t::MI355XTLAS, h::TLASHandle)
+    p = Ref{Ptr{InstanceDescriptor}}(C_NULL); n = Ref{UInt32}(0)
+    check(ccall((:rc_instance_buffer_device, LIB), Cint, (Ptr{Cvoid}, UInt32, Ref{Ptr{InstanceDescriptor}}, Ref{UInt32}), t.ptr, h.id, p, n))
+    return p[], Int(n[])
+end
+Raycore.refit_tlas!(t::MI355XTLAS; recompute_inverse::Bool = true) =
+    (check(ccall((:rc_refit_device, LIB), Cint, (Ptr{Cvoid}, Cint), t.ptr, recompute_inverse ? 1 : 0)); t)
+
+# collide_instances / collide_instances_any (src/collision.jl:189-262)
+function Raycore.collide_instances(t::MI355XTLAS)
+    n = Ref{UInt64}(0)
+    check(ccall((:rc_collide_instances, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Ref{UInt64}), t.ptr, C_NULL, 0, n))
+    out = Vector{Raycore.ContactPair}(undef, n[])                                              # 2 x UInt32, same layout as rc_contact_pair
+    n[] > 0 && check(ccall((:rc_collide_instances, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Ref{UInt64}), t.ptr, out, n[], n))
+    return out
+end
+function Raycore.collide_instances_any(t::MI355XTLAS, a::TLASHandle, b::TLASHandle)::Bool
+    o = Ref{Cint}(0)
+    check(ccall((:rc_collide_instances_any, LIB), Cint, (Ptr{Cvoid}, UInt32, UInt32, Ref{Cint}), t.ptr, a.id, b.id, o))
+    return o[] != 0
+end
+
+collide_instances_device!(t::MI355XTLAS, d_out::Ptr{Raycore.ContactPair}, capacity::Integer; stream::Ptr{Cvoid} = C_NULL) = begin
+    n = Ref{UInt64}(0)
+    check(ccall((:rc_collide_instances_device, LIB), Cint, (Ptr{Cvoid}, Ptr{Raycore.ContactPair}, UInt64, Ref{UInt64}, Ptr{Cvoid}), t.ptr, d_out, capacity, n, stream))
+    Int(n[])
+end
+
+# ---- triangle soup without a GeometryBasics mesh: 9 Float32 per triangle (v0 v1 v2) + one UInt32 of metadata each -----------------
+"build_blas(triangles) + push! of its instances (src/instanced-bvh.jl:1376-1443, 661-684) for a caller that already holds plain triangles."
+function push_triangles!(t::MI355XTLAS, verts::AbstractMatrix{Float32}, meta::Union{Nothing, Vector{UInt32}}, transforms::AbstractVector;
+                         instance_ids::Union{Nothing, AbstractVector{<:Integer}} = nothing)
+    size(verts, 1) == 9 || throw(ArgumentError("verts must be 9 x n (column-major: one triangle per column)"))
+    blas = Ref{UInt32}(0); handle = Ref{UInt32}(0)
+    check(ccall((:rc_add_blas, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{UInt32}, UInt32, Ref{UInt32}),
+                t.ptr, verts, meta === nothing ? C_NULL : meta, size(verts, 2), blas))
+    check(ccall((:rc_add_instances, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{Float32}, Ptr{UInt32}, UInt32, Ref{UInt32}),
+                t.ptr, blas[], xforms_buffer(transforms), instance_ids === nothing ? C_NULL : UInt32.(instance_ids), length(transforms), handle))
+    t.prims_valid = false
+    return TLASHandle(handle[])
+end
+"The same with the soup already in HBM (e.g. written by a simulation kernel): no PCIe traffic, the LBVH is built where the data is."
+function add_triangles_device!(t::MI355XTLAS, d_verts::Ptr{Float32}, d_meta::Ptr{UInt32}, n::Integer)
+    blas = Ref{UInt32}(0)
+    check(ccall((:rc_add_blas_device, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{UInt32}, UInt32, Ref{UInt32}), t.ptr, d_verts, d_meta, n, blas))
+    t.prims_valid = false
+    return blas[]
+end
+"update!(tlas, handle, triangles) for plain triangles (:808-857)."
+function update_triangles!(t::MI355XTLAS, h::TLASHandle, verts::AbstractMatrix{Float32}, meta::Union{Nothing, Vector{UInt32}} = nothing)
+    check(ccall((:rc_update_geometry, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{Float32}, Ptr{UInt32}, UInt32),
+                t.ptr, h.id, verts, meta === nothing ? C_NULL : meta, size(verts, 2)))
+    t.prims_valid = false
+    return nothing
+end
+
+# ---- the StaticTLAS fields, read back in the reference's own layouts (src/instanced-bvh.jl:155-168) -------------------------------
+function export_array(a::MI355XStaticTLAS, sym::Symbol, ::Type{T}) where {T}
+    n = Ref{UInt32}(0)
+    export_call(sym, a.owner.ptr, C_NULL, UInt32(0), n)
+    out = Vector{T}(undef, n[])
+    n[] > 0 && export_call(sym, a.owner.ptr, pointer(out), n[], n)
+    return out
+end
+function export_call(sym::Symbol, scene, out, cap, n)
+    sym === :nodes ? check(ccall((:rc_export_tlas_nodes, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ref{UInt32}), scene, out, cap, n)) :
+    sym === :all_blas_nodes ? check(ccall((:rc_export_blas_nodes, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ref{UInt32}), scene, out, cap, n)) :
+    sym === :instances ? check(ccall((:rc_export_instances, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ref{UInt32}), scene, out, cap, n)) :
+    sym === :blas_descriptors ? check(ccall((:rc_export_blas_descs, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ref{UInt32}), scene, out, cap, n)) :
+    sym === :prims ? check(ccall((:rc_export_prims, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ref{UInt32}), scene, out, cap, n)) :
+    error("unknown export $sym")
+end
+struct PrimRecord            # 40 bytes: what the traversal keeps of a triangle (vertices + metadata word)
+    v::NTuple{9, Float32}
+    meta::UInt32
+end
+function Base.getproperty(a::MI355XStaticTLAS, f::Symbol)
+    f === :nodes ? export_array(a, :nodes, Raycore.BVHNode2) :                                  # 60-byte BVHNode2 records
+    f === :all_blas_nodes ? export_array(a, :all_blas_nodes, Raycore.BVHNode2) :
+    f === :instances ? export_array(a, :instances, InstanceDescriptor) :
+    f === :blas_descriptors ? export_array(a, :blas_descriptors, Raycore.BLASDescriptor) :
+    f === :all_blas_prims ? map(p -> typed_triangle(getfield(a, :owner), p), primitives(a)) :
+    f === :prim_records ? export_array(a, :prims, PrimRecord) :
+    f === :root_aabb ? Raycore.world_bound(a) :
+    getfield(a, f)
+end
+
+# scene files (no counterpart in the reference, SURVEY section 5) and the library's tuning options
+save(t::MI355XTLAS, path::AbstractString) = check(ccall((:rc_scene_save, LIB), Cint, (Ptr{Cvoid}, Cstring), t.ptr, path))
+function load(backend::MI355XBackend, path::AbstractString)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rc_scene_load, LIB), Cint, (Cint, Cstring, Ref{Ptr{Cvoid}}), backend.device, path, ref))
+    t = MI355XTLAS(backend)            # a fresh handle whose scene is replaced by the loaded one
+    Raycore.free!(t); t.ptr = ref[]
+    return t
+end
+set_option!(t::MI355XTLAS, name::AbstractString, value::Integer) =
+    check(ccall((:rc_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), t.ptr, name, value))
+function get_option(t::MI355XTLAS, name::AbstractString)
+    v = Ref{Int64}(0); check(ccall((:rc_get_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), t.ptr, name, v)); v[]
+end
+function last_kernel_ms(t::MI355XTLAS)
+    ms = Ref{Cfloat}(0); check(ccall((:rc_last_kernel_ms, LIB), Cint, (Ptr{Cvoid}, Ref{Cfloat}), t.ptr, ms)); ms[]
+end
+device_count() = Int(ccall((:rc_device_count, LIB), Cint, ()))
+
+# ---- the reference's two convenience constructors ---------------------------------------------------------------------------------
+"""
+    MI355XTLAS(items, metadata_fn; backend) -> adapted accel          (TLAS(primitives, metadata_fn; backend), src/instanced-bvh.jl:2276-2324)
+
+One BLAS + one identity instance per item, `instance_id = item index`, per-triangle metadata = `metadata_fn(item_idx, face_idx)`
+evaluated BEFORE the degenerate filter drops faces (the face index is the mesh's), `TMetadata = typeof(metadata_fn(1, 1))`.
+"""
+function MI355XTLAS(items::AbstractVector, metadata_fn::Function; backend::MI355XBackend = MI355XBackend())
+    t = MI355XTLAS(backend)
+    T = typeof(metadata_fn(1, 1))
+    t.meta_type = T
+    ident = Float32[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]
+    for (mi, item) in enumerate(items)
+        mesh = item isa GeometryBasics.Mesh ? item : GeometryBasics.uv_normal_mesh(item)
+        d = decomposed(mesh)
+        words = Vector{UInt32}(undef, d.nv)     # rc_add_mesh reads metadata per VERTEX of the face-view-expanded mesh: the face's first vertex carries it
+        for fi in 1:d.nf
+            m = metadata_fn(mi, fi)
+            w = T === UInt32 ? m : (push!(t.meta_table, m); UInt32(length(t.meta_table)))
+            words[d.indices[3 * (fi - 1) + 1] + 1] = w
+        end
+        blas = Ref{UInt32}(0); handle = Ref{UInt32}(0)
+        check(ccall((:rc_add_mesh, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{UInt32}, Ref{UInt32}),
+                    t.ptr, d.verts, d.normals, d.uvs === nothing ? C_NULL : d.uvs, d.nv, d.indices, d.nf, words, blas))
+        check(ccall((:rc_add_instances_with_inverse, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{Float32}, Ptr{Float32}, Ptr{UInt32}, UInt32, Ref{UInt32}),
+                    t.ptr, blas[], ident, ident, UInt32[mi], 1, handle))                          # identity for both matrices, :2314-2320
+    end
+    return Adapt.adapt(backend, t)
+end
+"""
+    MI355XTLAS(meshes; backend) -> (tlas, handles)                      (TLAS(meshes; backend), src/instanced-bvh.jl:2361-2378)
+"""
+function MI355XTLAS(meshes::AbstractVector{<:GeometryBasics.Mesh}; backend::MI355XBackend = MI355XBackend())
+    isempty(meshes) && error("Cannot create TLAS from empty mesh list")
+    t = MI355XTLAS(backend)
+    handles = TLASHandle[push!(t, m) for m in meshes]
+    Raycore.sync!(t)
+    return t, handles
 end
 
 # ---- BVH4 (src/bvh4.jl): BLAS-level 4-wide tree, collapsed on the device ------------------------------------
@@ -234,5 +509,8 @@ function trace4(b::MI355XBLAS4, rays::Vector{RTRay}; any::Bool = false)         
     check(ccall((f, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{RTRay}, Ptr{RTHitResult}, UInt64), b.scene.ptr, b.blas_id, rays, hits, length(rays)))
     return hits     # (hit, primitives[primitive_id + 1], t, (1 - u - v, u, v)) per ray; no instance index at this level
 end
+trace4_device!(b::MI355XBLAS4, d_rays::Ptr{RTRay}, d_hits::Ptr{RTHitResult}, n::Integer; any::Bool = false, stream::Ptr{Cvoid} = C_NULL) =
+    check(any ? ccall((:rc_trace_any4_device, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{RTRay}, Ptr{RTHitResult}, UInt64, Ptr{Cvoid}), b.scene.ptr, b.blas_id, d_rays, d_hits, n, stream) :
+                ccall((:rc_trace_closest4_device, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{RTRay}, Ptr{RTHitResult}, UInt64, Ptr{Cvoid}), b.scene.ptr, b.blas_id, d_rays, d_hits, n, stream))
 
 end # module

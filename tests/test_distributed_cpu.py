@@ -10,17 +10,21 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _scene(po, rc):
+def _scene(po, rc, dup_meta=False):
     sc = rc.scenes
     verts = np.concatenate([sc.fan_sphere(8, 5, radius=0.5), sc.box_room((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5), 1)])
     n = len(verts)
+    meta = np.arange(1, n + 1, dtype=np.uint32)
+    if dup_meta:  # metadata that are not a permutation of 1..N: groups of faces share a row, one id is out of range
+        meta = (meta + 1) // 2
+        meta[3] = n + 7
     s = po.Scene()
-    b = s.add_blas(verts, np.arange(1, n + 1, dtype=np.uint32))
+    b = s.add_blas(verts, meta)
     s.add_instance(b)
     return s.build(), n
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, variant="plain"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -30,21 +34,32 @@ def _worker(rank, world, port, mode, q):
     from oracle import pyoracle as po
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        o, n = _scene(po, rc)
+        o, n = _scene(po, rc, dup_meta=(variant == "dup"))
         rpt, seed = 64, 99
 
-        meta = o.blas_prims["meta"]
+        meta = o.blas_prims["meta"].astype(np.int64)
+        order = np.argsort(meta, kind="stable")
+        group, dst = None, 0
+        if variant == "subgroup":  # ranks 1 and 2 of a 3-process world: group rank != global rank, dst is the GLOBAL rank 2
+            group, dst = dist.new_group([1, 2]), 2
 
-        def compute(local, src, rays, row_stride, col_stride, row_offset, by_prim):
+        def compute(local, src, rays, row_stride, col_stride, row_offset, addressing):
+            """Stand-in for rc_view_factors_device: the oracle's rays for one source at a time (rco_view_factor_row), accumulated with
+            the kernel's addressing rules (RC_VF_SOURCES_BY_METADATA / RC_VF_ROW_BY_PRIMITIVE / metadata rows)."""
             assert (row_stride, col_stride) == (n, 1)
-            m = o.view_factors(rpt, seed=seed, src=src, rays=rays)  # m[src_meta-1, hit_meta-1]
             rows = local.numpy().view(np.uint32).reshape(-1, n)
-            for p_idx in range(src[0], src[1]):
-                row = p_idx if by_prim else meta[p_idx] - 1
-                rows[row - row_offset] += m[meta[p_idx] - 1]
+            for pos in range(src[0], src[1]):
+                prim = order[pos] if addressing == "metadata" else pos
+                row = pos if addressing in ("metadata", "primitive") else meta[prim] - 1
+                if not (1 <= meta[prim] <= n):
+                    continue  # view_factors! would index out of bounds; the kernel drops such sources
+                rows[row - row_offset] += o.view_factor_row(rpt, int(prim), seed=seed, rays=rays)
 
-        if mode in ("rays", "rows"):
-            out = rd.view_factors_distributed(None, rpt, seed, mode=mode, n_prims=n, compute=compute, device=torch.device("cpu"), prim_meta=meta)
+        if variant == "subgroup" and rank == 0:
+            res = "not in the group"
+        elif mode in ("rays", "rows"):
+            out = rd.view_factors_distributed(None, rpt, seed, mode=mode, n_prims=n, compute=compute, device=torch.device("cpu"), prim_meta=meta,
+                                              group=group, dst=dst, chunks=5 if mode == "rays" else None)
             res = None if out is None else out.numpy().view(np.uint32).copy()
         elif mode == "rows_sharded":
             block, rows = rd.view_factors_distributed(None, rpt, seed, mode=mode, n_prims=n, compute=compute, device=torch.device("cpu"), prim_meta=meta)
@@ -94,6 +109,69 @@ def test_sharded_drivers_world2(oracle, mode):
     else:
         want = o.view_factors(64, seed=99)
         assert results[0].shape == (n, n) and np.array_equal(results[0], want) and want.sum() > 0
+
+
+def _run(world, mode, variant, port_offset):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + port_offset
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q, variant)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("mode", ["rays", "rows"])
+def test_metadata_with_duplicates_takes_the_general_path(oracle, mode):
+    """Metadata that are not a permutation of 1..N (shared rows, an out-of-range id): rows travel in primitive order and the root
+    folds them by metadata; the result is the reference's matrix (result[src_meta, hit_meta], out-of-range ids dropped)."""
+    import raycore_jl_amd as rc
+    results = _run(2, mode, "dup", 10 + (mode == "rows"))
+    o, n = _scene(oracle, rc, dup_meta=True)
+    want = o.view_factors(64, seed=99)
+    assert results[1] is None and np.array_equal(results[0], want) and want.sum() > 0
+
+
+@pytest.mark.parametrize("mode", ["rays", "rows"])
+def test_subgroup_uses_group_ranks_for_shards_and_a_global_rank_for_dst(oracle, mode):
+    """dist.get_rank(group) is a group-local rank; `dst` (and every peer of a send / recv) is a global rank.  Ranks 1 and 2
+    of a three-process world form the group, the matrix lands on global rank 2."""
+    import raycore_jl_amd as rc
+    results = _run(3, mode, "subgroup", 20 + (mode == "rows"))
+    o, n = _scene(oracle, rc)
+    assert results[0] == "not in the group" and results[1] is None
+    assert np.array_equal(results[2], o.view_factors(64, seed=99))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a rank environment starts its own two rank processes (before anything touches a GPU) and
+    relays rank 0's ONE JSON line; under torch.distributed.run it takes the ranks it is given.  --dry-run: no GPU work."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--res", "64"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    port = 29000 + os.getpid() % 400
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--res", "64"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    # a rank count that contradicts the environment is an error, not a silent single-GPU run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0
 
 
 def test_shard_range_covers_everything():

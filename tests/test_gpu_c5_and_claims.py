@@ -29,35 +29,34 @@ def test_c5_full_size_view_factors(rc, oracle):
     meta = t._prims()["meta"].astype(np.int64)
     assert np.array_equal(np.sort(meta), np.arange(1, n + 1))  # metadata = 1..N: rows are a permutation of the sorted primitives
 
-    # rows_sharded on one rank: block row r = source primitive r (Morton-sorted order), matrix row meta[r] - 1
+    # rows_sharded on one rank: sources are addressed in metadata order, so block row r IS matrix row r (metadata r + 1)
     block, row_index = rd.view_factors_distributed(t, rpt, seed, mode="rows_sharded")
     torch.cuda.synchronize()
-    assert block.shape == (n, n) and np.array_equal(row_index, meta - 1)
+    assert block.shape == (n, n) and np.array_equal(row_index, np.arange(n))
     g = np.random.default_rng(5)
-    for src in g.choice(n, 64, replace=False):
+    for src in g.choice(n, 64, replace=False):   # flat (Morton-sorted) primitive index, the oracle's addressing
         want = o.view_factor_row(rpt, int(src), seed=seed)
-        got = block[int(src)].cpu().numpy().view(np.uint32)
+        got = block[int(meta[src] - 1)].cpu().numpy().view(np.uint32)
         assert np.array_equal(got, want), f"source primitive {src}: {int((got != want).sum())} entries differ"
         assert got[meta[src] - 1] == 0 and got.sum() <= rpt
     row_sums = block.sum(dim=1, dtype=torch.int64)
     assert int(row_sums.max()) <= rpt and int(row_sums.min()) >= 0
     total = int(row_sums.sum())
     assert total > 0.5 * n * rpt  # a closed room: most rays hit something that is not their source
-    diag = block[torch.arange(n, device=block.device), torch.as_tensor(meta - 1, device=block.device)]
-    assert int(diag.abs().sum()) == 0
-    # the matrix in metadata order, kept as a checksum per row to compare the other partitions without holding two 10 GB matrices
+    assert int(torch.diagonal(block).abs().sum()) == 0   # hit_meta != src_meta (:94)
+    # a checksum per row to compare the other partitions without holding two 10 GB matrices
     w = torch.arange(1, n + 1, device=block.device, dtype=torch.int64)
-    perm = torch.as_tensor(np.argsort(meta), device=block.device)   # matrix row m comes from block row perm[m]
-    want_sum = row_sums[perm].cpu().numpy()
-    want_chk = (block.to(torch.int64) * w).sum(dim=1)[perm].cpu().numpy()
-    del block, diag, row_sums
+    want_sum = row_sums.cpu().numpy()
+    want_chk = torch.cat([(block[a:a + 4096].to(torch.int64) * w).sum(dim=1) for a in range(0, n, 4096)]).cpu().numpy()
+    del block, row_sums
     torch.cuda.empty_cache()
     for mode in ("rows", "rays"):
         m = rd.view_factors_distributed(t, rpt, seed, mode=mode)
         torch.cuda.synchronize()
         assert m.shape == (n, n)
         assert np.array_equal(m.sum(dim=1, dtype=torch.int64).cpu().numpy(), want_sum), mode
-        assert np.array_equal((m.to(torch.int64) * w).sum(dim=1).cpu().numpy(), want_chk), mode
+        chk = torch.cat([(m[a:a + 4096].to(torch.int64) * w).sum(dim=1) for a in range(0, n, 4096)]).cpu().numpy()  # in row slabs: no 20 GB temporaries
+        assert np.array_equal(chk, want_chk), mode
         del m
         torch.cuda.empty_cache()
     assert t.get_option("claim_drift") == 0
@@ -175,4 +174,66 @@ def test_status_word_is_not_cleared_by_later_launches(rc, oracle):
     with pytest.raises(rc.RaycoreError, match="overflow"):
         t.trace(rays)  # the synchronous entry points look at the same word
     assert t.trace(rays)["hit"].all()
+    t.free()
+
+
+def test_generic_triangle_metadata(rc, oracle):
+    """Triangle{TMetadata} for a metadata type other than UInt32 (src/triangle_mesh.jl:1-7, TLAS(items, metadata_fn) :2276-2324 takes
+    TMetadata = typeof(metadata_fn(1, 1))): the library stores a uint32 word per primitive, the host mirror interns the values."""
+    sc = rc.scenes
+    items = [sc.fan_sphere(8, 5, centre=(0, 0, 0), radius=0.5), sc.fan_sphere(8, 5, centre=(2, 0, 0), radius=0.5)]
+    acc = rc.TLAS_from_items(items, lambda mi, fi: ("mesh%d" % mi, fi * 0.5))
+    t = acc._owner
+    assert t.eltype() == ("Triangle", tuple)
+    hit, tri, dist, bary, inst = rc.closest_hit(acc, rc.Ray((2.0, 0.05, -3.0), (0.0, 0.0, 1.0)))
+    assert hit and inst == 2 and tri.metadata[0] == "mesh2" and isinstance(tri.metadata[1], float)
+    # the same scene with integer metadata: same hit, the word is the value itself
+    acc_u = rc.TLAS_from_items(items, lambda mi, fi: 1000 * mi + fi)
+    hit_u, tri_u, dist_u, _, inst_u = rc.closest_hit(acc_u, rc.Ray((2.0, 0.05, -3.0), (0.0, 0.0, 1.0)))
+    assert hit_u and inst_u == 2 and dist_u == dist and tri_u.metadata // 1000 == 2
+    assert tri.metadata[1] == (tri_u.metadata % 1000) * 0.5          # the same face, through the table
+    assert acc_u._owner.eltype() == ("Triangle", np.uint32)
+    miss = rc.closest_hit(acc, rc.Ray((9.0, 9.0, -3.0), (0.0, 0.0, 1.0)))
+    assert not miss[0] and miss[4] == 0
+    grid, typed = rc.hits_from_grid(acc, (0.0, 0.0, 1.0), grid_size=16)
+    assert grid["hit"].any() and all((typed[i] is not None) == bool(grid["hit"][i]) for i in np.ndindex(grid.shape))
+    pts, centre = rc.get_centroid(acc, (0.0, 0.0, 1.0), grid_size=16)
+    assert len(pts) == int(grid["hit"].sum()) and np.all(np.isfinite(centre))
+
+
+def test_view_factor_source_addressing_and_general_metadata(rc, oracle):
+    """RC_VF_SOURCES_BY_METADATA (a contiguous source range = a contiguous block of final rows when the metadata are a permutation
+    of 1..N) against the plain matrix, with shuffled metadata; and metadata with duplicates / out-of-range ids through the
+    multi-GPU driver's general path (src/kernels.jl:85-97: result[src_meta, hit_meta], several faces may share a row)."""
+    import torch
+    from raycore_jl_amd import distributed as rd
+    from raycore_jl_amd._capi import check, lib, ptr
+    sc = rc.scenes
+    verts = np.concatenate([sc.fan_sphere(10, 6, radius=0.5), sc.box_room((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5), 2)])
+    n = len(verts)
+    perm_meta = (np.random.default_rng(3).permutation(n) + 1).astype(np.uint32)
+    cfg = {"blas": [(verts, perm_meta)], "instances": [(1, sc.IDENTITY3x4[None], np.zeros(1, np.uint32))]}
+    t = build_product(rc, cfg)
+    want = rc.view_factors(t, rays_per_triangle=64, seed=5)                    # [src_meta-1, hit_meta-1]
+    m = torch.zeros(n * n, dtype=torch.int32, device="cuda")
+    a = n // 3
+    for s0, s1 in ((0, a), (a, n)):                                            # two row blocks, each written at its own offset
+        check(lib().rc_view_factors_device(t._h, 64, 5, s0, s1, 0, 64, ptr(m[s0 * n:].data_ptr()), n, 1, s0, 2, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(m.cpu().numpy().view(np.uint32).reshape(n, n), want)
+    for mode in ("rows", "rays"):
+        out = rd.view_factors_distributed(t, 64, 5, mode=mode, chunks=7)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want), mode
+    t.free()
+    dup_meta = ((np.arange(n) // 3) + 1).astype(np.uint32)
+    dup_meta[5] = n + 100                                                      # out of range: dropped, as an out-of-bounds index would be
+    cfg = {"blas": [(verts, dup_meta)], "instances": [(1, sc.IDENTITY3x4[None], np.zeros(1, np.uint32))]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    want = o.view_factors(32, seed=8, nthreads=8)
+    assert np.array_equal(rc.view_factors(t, rays_per_triangle=32, seed=8), want)
+    for mode in ("rows", "rays"):
+        out = rd.view_factors_distributed(t, 32, 8, mode=mode)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want), mode
     t.free()

@@ -1,40 +1,63 @@
 #!/bin/bash
-# Round-end evidence: rocprofv3 kernel stats + HBM PMC passes of the bench command, summarised under profiles/.
+# Round evidence: rocprofv3 kernel stats + PMC passes of the bench command, summarised under profiles/ (copy gpurun_out/$R/profiles/* there).
+#   tools/capture_profiles.sh r02
+# Counters are collected in their own passes (--pmc with --kernel-trace only), HBM counters FETCH_SIZE / WRITE_SIZE in separate passes,
+# FETCH_SIZE doubled afterwards (gfx950 reports half of a 16 B/lane coalesced stream; MI355X_MICROARCH.md, HBM section).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${1:-r01}
-mkdir -p gpurun_out/$R
+R=${1:-r02}
+O=gpurun_out/$R; P=$O/profiles
+mkdir -p $O $P
 CMD="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -- $CMD > gpurun_out/$R/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_fetch -- $CMD > gpurun_out/$R/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_write -- $CMD > gpurun_out/$R/pmc_write.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/$R/pmc_l2 -- $CMD > gpurun_out/$R/pmc_l2.log 2>&1
-rocprofv3 --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum --kernel-trace --output-format csv -d gpurun_out/$R/pmc_ta -- $CMD > gpurun_out/$R/pmc_ta.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU --kernel-trace --output-format csv -d gpurun_out/$R/pmc_sq -- $CMD > gpurun_out/$R/pmc_sq.log 2>&1
-python3 bench.py > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/stats.log 2>&1
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TD_TD_BUSY_sum" "GRBM_GUI_ACTIVE GRBM_COUNT" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU" \
+           "SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$i -- $CMD > $O/pmc_$i.log 2>&1
+done
+python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 - "$R" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, sys, collections, shutil, os
 R = sys.argv[1]
-out = {"command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras (one pass per set)"}
+O, P = f"gpurun_out/{R}", f"gpurun_out/{R}/profiles"
+out = {"command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras (one pass per counter set; FETCH_SIZE and WRITE_SIZE in separate passes)",
+       "workload": "BASELINE C3: 4 194 304 primary rays, closest_hit, 1 048 576-triangle instanced TLAS"}
 agg = collections.defaultdict(list)
 meta = {}
-for f in glob.glob(f"gpurun_out/{R}/pmc_*/**/*_counter_collection.csv", recursive=True):
+for f in glob.glob(f"{O}/pmc_*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "k_trace" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size")}
+            meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size") if k in r}
 out["kernel"] = meta
+out["dispatches_averaged"] = {k: len(v) for k, v in sorted(agg.items())}
 out["counters_mean_per_launch"] = {k: sum(v) / len(v) for k, v in sorted(agg.items())}
 c = out["counters_mean_per_launch"]
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-    out["hbm"] = {"correction": "FETCH_SIZE x2 (gfx950 reports half of a 16 B/lane coalesced stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KiB",
+    out["hbm"] = {"correction": "FETCH_SIZE x2 (gfx950 reports half of a 16 B/lane coalesced stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; both in KiB",
                   "read_bytes_per_launch": c["FETCH_SIZE"] * 1024 * 2, "write_bytes_per_launch": c["WRITE_SIZE"] * 1024,
                   "c3_closest_bytes_per_launch": c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024,
                   "expected_stream_bytes": {"rays_in": 4194304 * 32, "hits_out": 4194304 * 32}}
 if "TCC_HIT_sum" in c:
     out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
-json.dump(out, open(f"gpurun_out/{R}/pmc_summary.json", "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
-for f in glob.glob(f"gpurun_out/{R}/stats/**/*_kernel_stats.csv", recursive=True):
-    print(open(f).read()[:1500])
+for f in glob.glob(f"{O}/stats/**/*_kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    for r in rows:
+        if "k_trace" in r["Name"]:
+            out["kernel_stats"] = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+    with open(f"{P}/{R}_bench_c3_kernel_stats.csv", "w") as o:
+        o.write(open(f).read())
+if "SQ_INSTS_VALU" in c and "kernel_stats" in out:
+    t = out["kernel_stats"]["average_ns"] * 1e-9
+    simd_cycles = 1024 * 2.4e9 * t
+    out["derived"] = {"valu_wave_instructions_per_second": c["SQ_INSTS_VALU"] / t,
+                      "valu_issue_fraction_of_one_per_4_cycles": c["SQ_INSTS_VALU"] * 4 / simd_cycles,
+                      "lane_utilisation": c.get("SQ_THREAD_CYCLES_VALU", 0) / (c["SQ_INSTS_VALU"] * 64),
+                      "note": "kernel duration from the un-profiled --stats pass; PMC passes run ~2-3 % slower (DVFS), counters themselves do not change"}
+json.dump(out, open(f"{P}/{R}_pmc_c3.json", "w"), indent=1)
+print(json.dumps(out, indent=1)[:3500])
+line = open(f"{O}/bench.json").read().strip().splitlines()[-1]
+open(f"{P}/{R}_bench.json", "w").write(json.dumps(json.loads(line), indent=1))
 PY
-cat gpurun_out/$R/bench.json | tail -1
+tail -c 2500 $O/bench.json

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256, 6) void k_valu(float* out, int iters, float se
     v2f p[kUnroll], q[kUnroll];
     unsigned long long w[kUnroll];
     unsigned long long mask = 0x5555AAAA5555AAAAull + (unsigned long long)iters, mask2 = 0;
+    const float negzero = __builtin_amdgcn_readfirstlane(iters) > 1 ? -0.0f : seed;
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) w[k] = threadIdx.x + k;
 #pragma unroll
@@ -48,6 +49,22 @@ __global__ __launch_bounds__(256, 6) void k_valu(float* out, int iters, float se
             if (OP == 22) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(mask2) : "v"(a[k]), "v"(b[k]));
             if (OP == 23) asm volatile("v_mul_f32 %0, %0, %1\n v_add_f32 %0, %0, %2" : "+v"(a[k]) : "v"(b[k]), "v"(p[k].y));  // two instructions per count
             if (OP == 24) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b[k]), "v"(p[k].y));
+            if (OP == 25) asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 26) asm volatile("v_max_f32_e64 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 27) asm volatile("v_min_f32_e64 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 28) asm volatile("v_and_b32_e64 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 29) asm volatile("v_mov_b32_e64 %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 30) asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 31) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[k]) : "v"(b[k]), "v"(p[k].y));          // VOP2, destination not a source
+            if (OP == 32) asm volatile("v_mul_f32_e64 %0, %1, %2" : "=v"(a[k]) : "v"(b[k]), "v"(p[k].y));
+            if (OP == 33) asm volatile("v_maximum3_f32 %0, %1, %2, %2" : "=v"(a[k]) : "v"(b[k]), "v"(p[k].y));
+            if (OP == 34) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p[k]) : "v"(q[k]), "v"(p[(k + 1) % kUnroll]));
+            if (OP == 35) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2\n v_cndmask_b32_e64 %3, %1, %2, %0" : "=&s"(mask2), "+v"(a[k]), "+v"(b[k]), "=v"(p[k].x));  // cmp + select pair
+            if (OP == 36) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %0, %1, vcc" : "+v"(a[k]), "+v"(b[k]), "=v"(p[k].x) : : "vcc");      // VOP2/VOPC forms through vcc
+            if (OP == 37) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b[k]), "v"(p[k].y));
+            if (OP == 38) asm volatile("v_sub_f32_e64 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            if (OP == 39) asm volatile("v_lshlrev_b32_e64 %0, 3, %0" : "+v"(a[k]));
+            if (OP == 40) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b[k]), "s"(negzero));
         }
     }
     float acc = 0.f;
@@ -113,5 +130,21 @@ int main() {
     if (run<22>("v_cmp_lt_f32_e64 sgpr", d_out, n_cus)) return 1;
     if (run<23>("v_mul+v_add pair", d_out, n_cus)) return 1;
     if (run<24>("v_max3_f32", d_out, n_cus)) return 1;
+    if (run<25>("v_add_f32_e64", d_out, n_cus)) return 1;
+    if (run<26>("v_max_f32_e64", d_out, n_cus)) return 1;
+    if (run<27>("v_min_f32_e64", d_out, n_cus)) return 1;
+    if (run<28>("v_and_b32_e64", d_out, n_cus)) return 1;
+    if (run<29>("v_mov_b32_e64", d_out, n_cus)) return 1;
+    if (run<30>("v_add_u32_e64", d_out, n_cus)) return 1;
+    if (run<31>("v_mul_f32 d!=s", d_out, n_cus)) return 1;
+    if (run<32>("v_mul_f32_e64 d!=s", d_out, n_cus)) return 1;
+    if (run<33>("v_maximum3 d!=s", d_out, n_cus)) return 1;
+    if (run<34>("v_pk_mul_f32 d!=s", d_out, n_cus)) return 1;
+    if (run<35>("cmp_e64+cndmask_e64", d_out, n_cus)) return 1;
+    if (run<36>("cmp_vcc+cndmask_vcc", d_out, n_cus)) return 1;
+    if (run<37>("v_med3_f32", d_out, n_cus)) return 1;
+    if (run<38>("v_sub_f32_e64", d_out, n_cus)) return 1;
+    if (run<39>("v_lshlrev_b32_e64", d_out, n_cus)) return 1;
+    if (run<40>("v_fma_f32 x*y-0", d_out, n_cus)) return 1;
     return 0;
 }
