@@ -74,6 +74,39 @@ __global__ __launch_bounds__(256, 6) void k_valu(float* out, int iters, float se
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// Does a wave64 VALU instruction get cheaper when whole 16- or 32-lane groups are masked off?  (It would make lane compaction pay.)
+__global__ __launch_bounds__(256, 6) void k_valu_masked(float* out, int iters, float seed, int active_lanes) {
+    float a[kUnroll], b[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) { a[k] = seed + k + threadIdx.x; b[k] = seed * 0.5f + k; }
+    if ((int)(threadIdx.x & 63) < active_lanes) {
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < kUnroll; ++k) asm volatile("v_maximum3_f32 %0, %0, %1, %1" : "+v"(a[k]) : "v"(b[k]));
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) acc += a[k];
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+static int run_masked(float* d_out, int n_cus, int active) {
+    const int iters = 20000, blocks = n_cus * 6;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_valu_masked, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.5f, active);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    printf("v_maximum3_f32 with lanes 0..%2d active: %.3f ns per wave-instruction per SIMD\n", active - 1, best * 1e6 / (6.0 * iters * kUnroll));
+    return 0;
+}
+
 template <int OP>
 static int run(const char* name, float* d_out, int n_cus) {
     const int iters = 20000, blocks = n_cus * 6;
@@ -105,6 +138,7 @@ int main() {
     printf("device %s, %d CUs, clock %d kHz\n", prop.name, n_cus, prop.clockRate);
     float* d_out;
     CK(hipMalloc(&d_out, sizeof(float) * n_cus * 6 * 256));
+    for (int active : {64, 48, 32, 16, 8, 1}) if (run_masked(d_out, n_cus, active)) return 1;
     if (run<0>("v_mul_f32", d_out, n_cus)) return 1;
     if (run<1>("v_pk_mul_f32", d_out, n_cus)) return 1;
     if (run<6>("v_pk_add_f32", d_out, n_cus)) return 1;
