@@ -115,6 +115,38 @@ struct LaneStackT {
 };
 using LaneStack = LaneStackT<kLdsStack>;
 
+// The same stack addressed by a POINTER to the next free LDS slot instead of an entry index (phased_trace): a push is compare +
+// ds_write + add, a pop add + compare + ds_read -- the index form pays a 64-bit multiply-add (v_mad_u64_u32, 5 cycles of VALU issue
+// on a kernel bound by exactly that) for every address.  Entries beyond the LDS depth live in the global spill area as before; the
+// entry index is only reconstructed on that rare path.
+template <int LDS_N, int BLOCK>
+struct LaneStackP {
+    typedef lds_u32* pos_t;
+    lds_u32* base;       // &lds_stack[threadIdx.x]: entry k at base + k * BLOCK
+    lds_u32* limit;      // base + LDS_N * BLOCK
+    glb_u32* ovf;
+    uint32_t ovf_stride;
+    uint32_t* status;
+    __device__ inline LaneStackP(uint32_t* lds_base, uint32_t* ovf_base, uint32_t stride, uint32_t* st)
+        : base((lds_u32*)lds_base), limit((lds_u32*)lds_base + LDS_N * BLOCK), ovf((glb_u32*)ovf_base), ovf_stride(stride), status(st) {}
+    __device__ inline pos_t empty() const { return base; }
+    __device__ inline int depth(pos_t top) const { return (int)(top - base) / BLOCK; }
+    __device__ inline void push(pos_t& top, uint32_t v) {
+        if (__builtin_expect(top < limit, 1)) *top = v;
+        else {
+            const int k = depth(top);
+            if (k < kTotalStack) ovf[(size_t)(k - LDS_N) * ovf_stride] = v;
+            else { *status = 1u; return; }
+        }
+        top += BLOCK;
+    }
+    __device__ inline uint32_t pop(pos_t& top) {
+        top -= BLOCK;
+        if (__builtin_expect(top < limit, 1)) return *top;
+        return ovf[(size_t)(depth(top) - LDS_N) * ovf_stride];
+    }
+};
+
 struct NodeRegs {
     float4 a, b, c;
     uint4 d;
@@ -402,7 +434,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     const uint32_t* const lt = top.lt;
     const float2* const il = top.il;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
-    LaneStackT<LDS_N, BLOCK> st(lds_stack + threadIdx.x, av.overflow + gtid, av.total_threads, av.status);
+    LaneStackP<LDS_N, BLOCK> st(lds_stack + threadIdx.x, av.overflow + gtid, av.total_threads, av.status);
     const int lane = threadIdx.x & 63;
     if (av.n_tlas_nodes == 0) {  // empty TLAS: every ray misses (test/test_tlas_stress.jl:808-831)
         for (uint64_t i = gtid; i < a.n_items; i += av.total_threads) sink(i, false, 0.0f, 0.0f, 0.0f, RC_INVALID_NODE, -1);
@@ -421,11 +453,12 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     float tmin = 0.f, closest_t = 0.f, hit_u = 0.f, hit_v = 0.f;
     uint32_t closest_prim = RC_INVALID_NODE, cur_off = 0, n_level = 0;
     uint32_t node = RC_INVALID_NODE;  // INVALID + !live = empty lane; INVALID + live = finished, result pending
-    int closest_inst = -1, cur_inst = -1, sp = 0;
+    int closest_inst = -1, cur_inst = -1;
+    typename LaneStackP<LDS_N, BLOCK>::pos_t sp = st.empty();
     bool live = false;
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0};
     unsigned long long st_t0 = STATS ? wall_clock64() : 0ull, st_tx = 0ull;
-    int thr_eff = a.int_thr;
+    int thr_eff = __builtin_amdgcn_readfirstlane(a.int_thr);  // wave-uniform: keeps the loop-exit compare on the scalar unit
 
     for (;;) {
         // ---- interior phase: intersect_internal_node (:1807-1832) + push far / descend near / pop (:1946-1960, 1991-1993)
@@ -508,8 +541,10 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 node = st.pop(sp);
                 cur_inst = -1;
                 cur_off = tlas_off; n_level = n_instances;
-                o = wo; d = wd; inv = winv;
-                ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                // back to the world ray (:2003-2005).  Only inv and (-o) * inv are restored: the top level has no triangle tests, so the
+                // ray's o and d are not read again before the next instance entry overwrites them from wo / wd
+                inv = winv;
+                ox = mk3(-wo.x * inv.x, -wo.y * inv.y, -wo.z * inv.z);
             } else if (is_entry) {
                 float4 m0, m1, m2;
                 u4v m3;
@@ -546,7 +581,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             if (STATS && !can_refill && st_tx == 0) st_tx = wall_clock64();
             if (!can_refill) {  // drain: no more rays to hand out, so the interior loop's exit threshold follows the lanes still alive
                 const int half_live = (64 - n_free) / 2;
-                thr_eff = half_live < a.int_thr ? (half_live > 1 ? half_live : 1) : a.int_thr;
+                thr_eff = __builtin_amdgcn_readfirstlane(half_live < a.int_thr ? (half_live > 1 ? half_live : 1) : a.int_thr);
             }
             if (n_free == 64 && !can_refill && !__ballot(fin)) break;
             if (n_free >= a.refill || n_free == 64 || !can_refill) {
@@ -572,15 +607,15 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         wo = mk3(r.ox, r.oy, r.oz);  // init (:1904-1927); check_direction (src/ray.jl:39-49)
                         wd = mk3(r.dx == 0.0f ? 0.0f : r.dx, r.dy == 0.0f ? 0.0f : r.dy, r.dz == 0.0f ? 0.0f : r.dz);
                         winv = mk3(safe_inv1(wd.x), safe_inv1(wd.y), safe_inv1(wd.z));
-                        o = wo; d = wd; inv = winv;
-                        ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                        inv = winv;  // (o, d are the instance-local ray: set at the first instance entry)
+                        ox = mk3(-wo.x * inv.x, -wo.y * inv.y, -wo.z * inv.z);
                         tmin = ANY ? 0.0f : r.tmin;
                         closest_t = r.tmax;
                         hit_u = hit_v = 0.0f;
                         closest_prim = RC_INVALID_NODE;
                         closest_inst = -1; cur_inst = -1;
                         cur_off = tlas_off; n_level = n_instances;
-                        sp = 0;
+                        sp = st.empty();
                         st.push(sp, RC_INVALID_NODE);
                         node = 1;
                         live = true;
