@@ -1,4 +1,4 @@
-"""Dev tool (CPU only): replay the reference algorithm's per-ray step sequences through wave-scheduling policies.
+"""Dev tool (CPU only; lives under tests/ because it drives the oracle, which only test infrastructure may do): replay the reference algorithm's per-ray step sequences through wave-scheduling policies.
 
 Per-ray results are fixed by the reference algorithm (bit-exact parity), so a ray's sequence of steps -- interior box tests,
 leaf triangle tests, instance entries, returns to the top level -- is the same whatever the kernel does; only WHEN a lane's next
@@ -7,7 +7,7 @@ cost of a policy is the number of wave-level VALU instructions it issues: every 
 count however few lanes take part.  This tool samples waves' worth of rays from a BASELINE workload, records each ray's steps with
 the oracle (rco_trace_events) and counts phase executions under the kernel's current policy and under candidates.
 
-    python tools/sched_sim.py --workload c3 --waves 48
+    python tests/dev/sched_sim.py --workload c3 --waves 48
 """
 import argparse
 import os
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import pyoracle as po  # noqa: E402  (dev tool: allowed to use the oracle)
 
 # phase costs in VALU wave-instructions, counted in the ISA of k_trace_phased_lds<false,768,16,6> (round 2)
@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--res", type=int, default=2048)
     args = ap.parse_args()
     import importlib.util
-    spec = importlib.util.spec_from_file_location("scenes", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raycore.jl_amd", "scenes.py"))
+    spec = importlib.util.spec_from_file_location("scenes", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "raycore.jl_amd", "scenes.py"))
     sc = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(sc)
     if args.workload == "c3":
