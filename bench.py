@@ -156,6 +156,12 @@ def main():
 
     extras = {}
 
+    def load_json(rel):
+        try:
+            return json.load(open(os.path.join(ROOT, rel)))
+        except Exception:  # noqa: BLE001
+            return None
+
     def guarded_extra(name, fn):
         """An extra measurement must never cost the headline line: failures are recorded, not raised."""
         try:
@@ -233,6 +239,38 @@ def main():
             ref[str(nt)] = {"mrays_s": rate, "ms_per_1M_rays": round(1e3 / rate, 3), "reference_rx7900xtx_ms": ref_ms}
             tb.free()
         extras["random_geometry_1M_rays_closest"] = ref
+        torch.cuda.empty_cache()
+        # An HBM-bound regime (the only place BASELINE's "HBM roofline" wording is testable): a 4 M-triangle BLAS -- a 512 MB node array,
+        # far beyond L2 + Infinity Cache -- and 4 M incoherent rays.  Rate and node fetches (the product's instrumented kernel) are
+        # measured here; the physical HBM bytes per launch come from the rocprofv3 passes in profiles/r02_hbm_regime.json.
+        g = np.random.default_rng(7)
+        ro = g.random((n, 3))
+        rd = g.standard_normal((n, 3))
+        rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+        inc = sc.make_rays(ro, rd)
+        tb = rc.TLAS(local_rank)
+        dv = torch.from_numpy(sc.random_triangles(4_000_000, 42, edge=0.01)).cuda()
+        tb.add_geometry_device(dv.data_ptr(), 4_000_000)
+        tb.push_instances(1)
+        tb.sync()
+        del dv
+        rate = timed(tb, inc, "closest", reps=3)
+        tb.set_option("kernel", 3); tb.set_option("stats", 1)
+        timed(tb, inc, "closest", reps=1)
+        st = [tb.get_option(f"stat{i}") for i in range(8)]
+        tb.set_option("stats", 0); tb.set_option("kernel", -1)
+        tb.free()
+        fetches = (st[3] + st[5]) / n + 1.0
+        alg = (64 + 60.0 * fetches + 140.0) * n
+        secs = n / (rate * 1e6)
+        prof = (load_json(os.path.join("profiles", "r02_hbm_regime.json")) or {}).get("scenes", {}).get("4000000", {})
+        phys = prof.get("hbm_read_bytes_per_launch", 0) + prof.get("hbm_write_bytes_per_launch", 0)
+        extras["hbm_regime_4M_tris_4M_incoherent_rays"] = {
+            "mrays_s": rate, "node_fetches_per_ray": round(fetches, 2), "algorithmic_GBs": round(alg / secs / 1e9, 1),
+            "hbm_physical_GBs": round(phys / secs / 1e9, 1) if phys else None, "hbm_physical_frac": round(phys / secs / 1e9 / HBM_PEAK_GBS, 4) if phys else None,
+            "fetch_amplification": round(phys / alg, 3) if phys else None,
+            "sources": {"hbm bytes per launch": "profiles/r02_hbm_regime.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE calibrated x1 for random 64-byte gathers, profiles/r02_fetch_calibration.txt)",
+                        "rate, node fetches": "this run"}}
         torch.cuda.empty_cache()
 
 
@@ -325,12 +363,6 @@ def main():
         t5.free()
         if rank == 0:
             extras["view_factors_c5"] = vf
-
-    def load_json(rel):
-        try:
-            return json.load(open(os.path.join(ROOT, rel)))
-        except Exception:  # noqa: BLE001
-            return None
 
     counts = load_json(COUNTS_FILE) or {}
     node_f = float(counts.get("node_fetches_per_ray", C3_NODE_FETCHES_PER_RAY))
