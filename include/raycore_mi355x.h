@@ -323,6 +323,15 @@ int rc_scene_load(int device, const char* path, rc_scene** out);
 int rc_instance_buffer_device(rc_scene* scene, uint32_t handle, rc_instance_desc** d_descs, uint32_t* count);
 int rc_refit_device(rc_scene* scene, int recompute_inverse);
 
+/* Page-lock (pin) a caller-owned host array so that the host-buffer entry points (rc_trace_closest / rc_trace_any, rc_add_blas,
+ * rc_view_factors ...) move it by DMA at the full PCIe rate instead of through the driver's staging copies: the option a Julia
+ * `Vector{RTRay}` / `Vector{RTHitResult}` pair that is traced every frame wants (there is no counterpart in the reference, whose
+ * arrays live in the backend's memory).  Thin wrappers over hipHostRegister / hipHostUnregister so that a caller without HIP
+ * bindings can use them; the memory stays the caller's.  Registering an array twice, or unregistering one that is not
+ * registered, is an error (non-zero status). */
+int rc_host_register(rc_scene* scene, void* ptr, uint64_t bytes);
+int rc_host_unregister(rc_scene* scene, void* ptr);
+
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);

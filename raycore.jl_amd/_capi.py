@@ -95,6 +95,8 @@ SYMBOLS = [
     ("rc_scene_load", _int, [_int, C.c_char_p, C.POINTER(_vp)]),
     ("rc_instance_buffer_device", _int, [_vp, _u32, C.POINTER(_vp), _pu32]),
     ("rc_refit_device", _int, [_vp, _int]),
+    ("rc_host_register", _int, [_vp, _vp, _u64]),
+    ("rc_host_unregister", _int, [_vp, _vp]),
     ("rc_last_kernel_ms", _int, [_vp, _pf]),
 ]
 

@@ -401,6 +401,15 @@ class TLAS:
         check(lib().rc_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def host_register(self, array):
+        """Page-lock a numpy array (rays, a reused `out=` hit array, triangle soup) so the host-buffer calls move it by DMA at the full
+        PCIe rate; undo with host_unregister before the array is freed."""
+        check(lib().rc_host_register(self._h, ptr(array), array.nbytes))
+        return array
+
+    def host_unregister(self, array):
+        check(lib().rc_host_unregister(self._h, ptr(array)))
+
     def intern_metadata(self, values):
         """Metadata words for `values`: the values themselves when they are all uint32-representable integers and the accel is still
         in uint32 mode (TMetadata = UInt32, the reference's default), otherwise 1-based indices into the accel's metadata table."""

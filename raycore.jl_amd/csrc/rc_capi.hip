@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <sys/mman.h>
 
@@ -1069,6 +1070,32 @@ int rc_shadow_rays_device(rc_scene* s, const rc_ray* d_rays, const rc_hit* d_hit
         use_device(s);
         require_synced(s);
         rc_launch_shadow_rays(s, reinterpret_cast<const RcRay*>(d_rays), reinterpret_cast<const RcHit*>(d_hits), n, light, bias, reinterpret_cast<RcRay*>(d_shadow_rays), (hipStream_t)stream);
+    });
+}
+
+// (the HIP runtime accepts a second hipHostRegister of the same range silently; the library keeps its own table so that the two
+// calls have defined semantics: one registration per array, unregister only what was registered through this interface)
+static std::mutex g_host_reg_mutex;
+static std::map<void*, uint64_t> g_host_reg;
+int rc_host_register(rc_scene* s, void* p, uint64_t bytes) {
+    if (!s || !p || bytes == 0) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        std::lock_guard<std::mutex> lock(g_host_reg_mutex);
+        if (g_host_reg.count(p)) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_host_register: this array is already registered");
+        RC_HIP(hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+        g_host_reg[p] = bytes;
+    });
+}
+int rc_host_unregister(rc_scene* s, void* p) {
+    if (!s || !p) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        std::lock_guard<std::mutex> lock(g_host_reg_mutex);
+        if (!g_host_reg.count(p)) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_host_unregister: this array was not registered with rc_host_register");
+        RC_HIP(hipStreamSynchronize(s->stream));  // no transfer of the scene may still be reading or writing the array
+        RC_HIP(hipHostUnregister(p));
+        g_host_reg.erase(p);
     });
 }
 

@@ -445,6 +445,9 @@ function last_kernel_ms(t::MI355XTLAS)
     ms = Ref{Cfloat}(0); check(ccall((:rc_last_kernel_ms, LIB), Cint, (Ptr{Cvoid}, Ref{Cfloat}), t.ptr, ms)); ms[]
 end
 device_count() = Int(ccall((:rc_device_count, LIB), Cint, ()))
+"Page-lock a host array that is traced again and again (`Vector{RTRay}`, a reused `Vector{RTHitResult}`): DMA at the full PCIe rate."
+host_register!(t::MI355XTLAS, a::Array) = (check(ccall((:rc_host_register, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64), t.ptr, a, sizeof(a))); a)
+host_unregister!(t::MI355XTLAS, a::Array) = (check(ccall((:rc_host_unregister, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), t.ptr, a)); a)
 
 # ---- the reference's two convenience constructors ---------------------------------------------------------------------------------
 """

@@ -237,3 +237,30 @@ def test_view_factor_source_addressing_and_general_metadata(rc, oracle):
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want), mode
     t.free()
+
+
+def test_pinned_host_buffers(rc, oracle):
+    """rc_host_register / rc_host_unregister: a page-locked ray / hit array pair goes through the same host-buffer entry points with the
+    same results (single-launch path and the chunked three-stage pipeline), registering twice is an error, and after unregistering the
+    arrays are ordinary pageable memory again."""
+    cfg = rc.scenes.config_c3(lattice=(3, 3, 2))
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    for w, h in ((256, 256), (2048, 1600)):     # 65 k rays: one launch; 3.3 M rays: the pipelined path (>= 3 Mi rays)
+        rays = rc.scenes.c3_primary_rays(cfg, w, h)
+        out = np.empty(len(rays), dtype=rc.HIT_DT)
+        want = t.trace(rays).copy()
+        if len(rays) < 100_000:
+            assert_hits_equal(want, o.trace(rays, nthreads=8), "pageable vs oracle")
+        t.host_register(rays); t.host_register(out)
+        try:
+            got = t.trace(rays, out=out)
+            assert got is out and got.tobytes() == want.tobytes()
+            assert t.trace(rays, mode="any", out=out)["hit"].tobytes() == t.trace(rays, mode="any")["hit"].tobytes()
+            with pytest.raises(rc.RaycoreError):
+                t.host_register(rays)
+        finally:
+            t.host_unregister(out); t.host_unregister(rays)
+        with pytest.raises(rc.RaycoreError):
+            t.host_unregister(rays)
+        assert t.trace(rays).tobytes() == want.tobytes()
+    t.free()

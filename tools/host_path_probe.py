@@ -30,5 +30,14 @@ for res in (512, 1024, 1449, 2048, 4096):
         check(lib().rc_trace_closest(t3._h, ptr(rays), ptr(hits), len(rays)))
         best2 = min(best2, time.perf_counter() - t0)
     print(f"{len(rays):9d} rays: rc_trace_closest into a reused, touched output buffer {best2 * 1e3:8.3f} ms = {len(rays) / best2 / 1e6:7.1f} Mrays/s")
+    t3.host_register(rays); t3.host_register(hits)
+    best3 = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        check(lib().rc_trace_closest(t3._h, ptr(rays), ptr(hits), len(rays)))
+        best3 = min(best3, time.perf_counter() - t0)
+    t3.host_unregister(hits); t3.host_unregister(rays)
+    print(f"{len(rays):9d} rays: the same with both arrays page-locked (rc_host_register)      {best3 * 1e3:8.3f} ms = {len(rays) / best3 / 1e6:7.1f} Mrays/s "
+          f"({64 * len(rays) / best3 / 1e9:.1f} GB/s over the bus)")
     print(f"{len(rays):9d} rays: host-buffer trace {best * 1e3:8.3f} ms wall = {len(rays) / best / 1e6:7.1f} Mrays/s (kernel {t3.last_kernel_ms():.3f} ms; "
           f"{64 * len(rays) / best / 1e9:.1f} GB/s over the bus)", flush=True)
