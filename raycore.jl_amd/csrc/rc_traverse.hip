@@ -368,7 +368,10 @@ void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
             if (s->overflow_regions[idx].first == stream) break;
         if (idx == s->overflow_regions.size()) {
             if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // a fifth stream: wait for the oldest region's stream, then take it over
-                RC_HIP(hipStreamSynchronize(s->overflow_regions[0].first));
+                if (hipStreamSynchronize(s->overflow_regions[0].first) != hipSuccess) {  // the caller may have destroyed that stream since
+                    (void)hipGetLastError();
+                    RC_HIP(hipDeviceSynchronize());
+                }
                 std::rotate(s->overflow_regions.begin(), s->overflow_regions.begin() + 1, s->overflow_regions.end());
                 idx -= 1;
                 s->overflow_regions[idx].first = stream;
@@ -393,8 +396,13 @@ void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
     if (s->any_launch && stream != s->last_launch_stream && !s->multi_stream) {
         s->multi_stream = true;
         if (!s->stream_switch_ev) RC_HIP(hipEventCreateWithFlags(&s->stream_switch_ev, hipEventDisableTiming));
-        RC_HIP(hipEventRecord(s->stream_switch_ev, s->last_launch_stream));  // everything launched before the switch had no slot events
-        RC_HIP(hipStreamWaitEvent(stream, s->stream_switch_ev, 0));
+        // everything launched before the switch had no slot events: order the new stream behind the old one once
+        if (hipEventRecord(s->stream_switch_ev, s->last_launch_stream) == hipSuccess) {
+            RC_HIP(hipStreamWaitEvent(stream, s->stream_switch_ev, 0));
+        } else {  // the previous stream no longer exists: whatever ran on it is ordered by a device-wide wait
+            (void)hipGetLastError();
+            RC_HIP(hipDeviceSynchronize());
+        }
     }
     s->any_launch = true;
     s->last_launch_stream = stream;
