@@ -43,6 +43,36 @@ C3_NODE_FETCHES_PER_RAY = 33.006
 C3_INST_ENTRIES_PER_RAY = 1.922
 
 
+def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_option=-1, profiled_config=True):
+    """The `roofline` object of the JSON line from a launch time (ms, measured live), the reference algorithm's fetch counts per ray
+    and the per-launch PMC counters of the counter file.  Pure arithmetic, so a reader can recompute every number from profiles/."""
+    bytes_per_ray = 32 + 32 + 60.0 * node_f + 140.0 * inst_f
+    alg_gbs = bytes_per_ray * n_rays / (launch_ms * 1e-3) / 1e9
+    c = pmc.get("counters_mean_per_launch", {})
+    valu = c.get("SQ_INSTS_VALU")
+    traffic = (pmc.get("hbm") or {}).get("c3_closest_bytes_per_launch")
+    kname = {-1: "k_trace_phased_lds<false, 768, 16, 6>", 5: "k_trace_phased_lds<false, 768, 16, 6>", 3: "k_trace_phased<false, 24, 6, false>"}.get(kernel_option, f"kernel option {kernel_option}")
+    if valu and profiled_config:
+        achieved = valu / (launch_ms * 1e-3) / 1e9
+        roofline = {"bound": "valu-issue", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s",
+                    "frac": round(achieved / VALU_PEAK_GINST_S, 4), "traffic": traffic, "kernel": kname, "avg_launch_ms": round(launch_ms, 4),
+                    "valu_wave_instructions_per_launch": valu,
+                    "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0), 4) if c.get("SQ_THREAD_CYCLES_VALU") else None,
+                    "hbm_physical_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "vmem_wave_instructions_per_launch": c.get("SQ_INSTS_VMEM_RD"),
+                    "sources": {"valu_wave_instructions_per_launch, lane_utilisation, traffic": COUNTER_FILE + " (rocprofv3 --pmc passes over this bench command, tools/capture_profiles.sh; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md: the traffic is the coalesced ray / hit stream)",
+                                "avg_launch_ms": "HIP events around every timed launch, this run",
+                                "peak": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction; profiles/r02_valu_probe.txt has the measured per-opcode rates",
+                                "node / instance counts": counts_source}}
+    else:  # no counter file for this configuration: only the section-8d figure can be given, and it is not a utilisation
+        roofline = {"bound": "valu-issue", "achieved": None, "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s", "frac": None, "traffic": traffic,
+                    "kernel": kname, "avg_launch_ms": round(launch_ms, 4), "sources": {"note": f"{COUNTER_FILE} missing or --res differs from the profiled 2048"}}
+    roofline["algorithmic_vs_hbm"] = {"achieved_GBs": round(alg_gbs, 1), "peak_GBs": HBM_PEAK_GBS, "ratio": round(alg_gbs / HBM_PEAK_GBS, 4),
+                                      "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3),
+                                      "note": "SURVEY section 8d's figure; > 1 because the reference algorithm's node / instance bytes are served from LDS, L1 and L2, not HBM"}
+    return roofline
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` with N > 1 and no rank environment: start N rank processes (fresh children: this process never
     touches a GPU) and relay rank 0's output.  Exit code = the worst child's."""
@@ -418,31 +448,7 @@ def main():
             pass
 
     if rank == 0:
-        bytes_per_ray = 32 + 32 + 60.0 * node_f + 140.0 * inst_f
-        alg_gbs = bytes_per_ray * n / (launch_ms * 1e-3) / 1e9
-        pmc = load_json(COUNTER_FILE) or {}
-        c = pmc.get("counters_mean_per_launch", {})
-        valu = c.get("SQ_INSTS_VALU")
-        traffic = (pmc.get("hbm") or {}).get("c3_closest_bytes_per_launch")
-        kname = {-1: "k_trace_phased_lds<false, 768, 16, 6>", 5: "k_trace_phased_lds<false, 768, 16, 6>", 3: "k_trace_phased<false, 24, 6, false>"}.get(t.get_option("kernel"), f"kernel option {t.get_option('kernel')}")
-        if valu and args.res == 2048:
-            achieved = valu / (launch_ms * 1e-3) / 1e9
-            roofline = {"bound": "valu-issue", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s",
-                        "frac": round(achieved / VALU_PEAK_GINST_S, 4), "traffic": traffic, "kernel": kname, "avg_launch_ms": round(launch_ms, 4),
-                        "valu_wave_instructions_per_launch": valu,
-                        "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0), 4) if c.get("SQ_THREAD_CYCLES_VALU") else None,
-                        "hbm_physical_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                        "vmem_wave_instructions_per_launch": c.get("SQ_INSTS_VMEM_RD"),
-                        "sources": {"valu_wave_instructions_per_launch, lane_utilisation, traffic": COUNTER_FILE + " (rocprofv3 --pmc passes over this bench command, tools/capture_profiles.sh; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md)",
-                                    "avg_launch_ms": "HIP events around every timed launch, this run",
-                                    "peak": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction; profiles/r02_valu_probe.txt has the measured per-opcode rates",
-                                    "node / instance counts": counts_source}}
-        else:  # no counter file for this configuration: only the section-8d figure can be given, and it is not a utilisation
-            roofline = {"bound": "valu-issue", "achieved": None, "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s", "frac": None, "traffic": traffic,
-                        "kernel": kname, "avg_launch_ms": round(launch_ms, 4), "sources": {"note": f"{COUNTER_FILE} missing or --res differs from the profiled 2048"}}
-        roofline["algorithmic_vs_hbm"] = {"achieved_GBs": round(alg_gbs, 1), "peak_GBs": HBM_PEAK_GBS, "ratio": round(alg_gbs / HBM_PEAK_GBS, 4),
-                                          "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3),
-                                          "note": "SURVEY section 8d's figure; > 1 because the reference algorithm's node / instance bytes are served from LDS, L1 and L2, not HBM"}
+        roofline = make_roofline(launch_ms, n, node_f, inst_f, counts_source, load_json(COUNTER_FILE) or {}, t.get_option("kernel"), args.res == 2048)
         out = {
             "metric": "Mrays/s closest_hit (1M-tri TLAS)", "value": round(world * n * args.steps / elapsed / 1e6, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
