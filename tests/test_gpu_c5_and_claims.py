@@ -264,3 +264,17 @@ def test_pinned_host_buffers(rc, oracle):
             t.host_unregister(rays)
         assert t.trace(rays).tobytes() == want.tobytes()
     t.free()
+
+
+def test_option_clamps(rc):
+    """rc_set_option validates what it stores: blocks_per_cu is bounded by what the stack spill area is sized for, claim
+    sizes below 16 rays are raised, the kernel selector stays in range, claim_shards is a power of two <= 16."""
+    t = rc.TLAS(0)
+    for name, given, stored in (("blocks_per_cu", 100, 8), ("blocks_per_cu", -3, 0), ("pool", 3, 16), ("pool", 0, 0), ("pool", 1 << 30, 1 << 20),
+                                ("kernel", 99, 6), ("kernel", -7, -1), ("claim_shards", 5, 4), ("claim_shards", 1000, 16), ("refill", 0, 1), ("refill", 999, 64),
+                                ("sched_thr", 0, 1), ("sched_thr", 65, 64)):
+        t.set_option(name, given)
+        assert t.get_option(name) == stored, (name, given, t.get_option(name))
+    with pytest.raises(rc.RaycoreError):
+        t.set_option("no_such_option", 1)
+    t.free()
