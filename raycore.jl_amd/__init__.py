@@ -8,7 +8,7 @@ from ._capi import HIT_DT, LIB_PATH, RAY_DT, SYMBOLS, TRIANGLE_DT, RaycoreError,
 from .api import (BLAS4, CONTACT_DT, CollisionResult, ContactPair, collide_instances, collide_instances_any, EMPTY_TRIANGLE, RAYHIT_DT, INVALID_HANDLE, any_hit4, build_blas4, closest_hit4, Bounds3, Ray, RayHit, StaticTLAS, TLAS, TLAS_from_items,  # noqa: F401
                   TLAS_from_meshes, TLASHandle, Triangle, adapt, any_hit, closest_hit, generate_ray_grid,
                   get_centroid, get_illumination, hits_from_grid, mat4_to_mat3x4, sync, trace_rays, view_factors,
-                  world_bound)
+                  world_bound, expand_faceviews)
 
 
 def device_count():

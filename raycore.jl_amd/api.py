@@ -668,6 +668,41 @@ def view_factors(accel, rays_per_triangle=10000, seed=0):
     return out
 
 
+def expand_faceviews(positions, position_faces, **attributes):
+    """GeometryBasics.expand_faceviews as build_and_append_blas! uses it (src/instanced-bvh.jl:581-590): a mesh whose attributes are
+    indexed by their own face arrays (a cube: 8 positions, 6 normals, one metadata value per face) becomes a mesh with ONE index set,
+    which is what `add_mesh` / `rc_add_mesh` take.  Every face corner is the tuple of its indices into all attributes; each distinct
+    tuple becomes one vertex, numbered in order of first appearance.
+
+    attributes: name=(values, faces) with faces (nf, 3) indices into values, or name=(values, None) for one value per FACE (the
+    `face_meta` convention, :595: after expansion it is per vertex).  Returns (positions, faces, {name: per-vertex values})."""
+    pf = np.asarray(position_faces, dtype=np.int64).reshape(-1, 3)
+    nf = len(pf)
+    cols = [pf.reshape(-1)]
+    names, values = [], []
+    for name, (vals, faces) in attributes.items():
+        vals = np.asarray(vals)
+        if faces is None:
+            if len(vals) != nf:
+                raise ValueError(f"{name}: one value per face expected")
+            idx = np.repeat(np.arange(nf, dtype=np.int64), 3)
+        else:
+            idx = np.asarray(faces, dtype=np.int64).reshape(-1)
+            if len(idx) != 3 * nf:
+                raise ValueError(f"{name}: faces must have one index triple per position face")
+        cols.append(idx); names.append(name); values.append(vals)
+    corners = np.stack(cols, axis=1)                                  # (3 nf, 1 + n_attributes) index tuples
+    uniq, first, inverse = np.unique(corners, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")                          # first-appearance order, as GeometryBasics numbers the merged vertices
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    new_faces = rank[np.asarray(inverse).reshape(-1)].reshape(nf, 3).astype(np.uint32)
+    tuples = uniq[order]
+    out_pos = np.asarray(positions, dtype=np.float32).reshape(-1, 3)[tuples[:, 0]]
+    out_attr = {name: vals[tuples[:, k + 1]] for k, (name, vals) in enumerate(zip(names, values))}
+    return out_pos, new_faces, out_attr
+
+
 def TLAS_from_items(items, metadata_fn, device=0):
     """TLAS(items, metadata_fn; backend) (src/instanced-bvh.jl:2276-2324): one BLAS + one identity instance per
     item, instance_id = item index, metadata = metadata_fn(item_idx, face_idx) (1-based); returns the adapted accel."""

@@ -144,8 +144,8 @@ struct rc_scene {
     DevBuf<uint4> tlas_ranges;  // same for the TLAS; kept, because refit_tlas! reuses the topology
     DevBuf<RcPrim> prim_tmp;
     // global spill areas of the traversal stacks: one per stream that has launched on this scene (launches on one stream are
-    // ordered and share theirs; launches on different streams may overlap and must not), at most kMaxOverflowRegions
-    static constexpr int kMaxOverflowRegions = 4;
+    // ordered and share theirs; launches on different streams may overlap and must not), at most kMaxOverflowRegions (a ninth stream waits for the oldest)
+    static constexpr int kMaxOverflowRegions = 8;  // each is allocated on first use by a new stream
     std::vector<std::pair<hipStream_t, DevBuf<uint32_t>>> overflow_regions;
     uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared (rc_prepare_launch)
     DevBuf<uint32_t> counters;        // kCounterSlots slots of claim counters (self-resetting, rc_claim_chunk), the sticky status word, dev statistics

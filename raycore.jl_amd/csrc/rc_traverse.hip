@@ -367,7 +367,7 @@ void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
         for (; idx < s->overflow_regions.size(); ++idx)
             if (s->overflow_regions[idx].first == stream) break;
         if (idx == s->overflow_regions.size()) {
-            if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // a fifth stream: wait for the oldest region's stream, then take it over
+            if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // one stream too many: wait for the oldest region's stream, then take it over
                 if (hipStreamSynchronize(s->overflow_regions[0].first) != hipSuccess) {  // the caller may have destroyed that stream since
                     (void)hipGetLastError();
                     RC_HIP(hipDeviceSynchronize());

@@ -182,3 +182,19 @@ def test_update_mesh_replaces_geometry(rc, oracle):
     s.build()
     st = t.adapt()
     assert st.all_blas_nodes.tobytes() == s.blas_nodes.tobytes() and st.all_blas_triangles.tobytes() == s.triangles.tobytes()
+
+
+def test_face_view_mesh_through_expand_faceviews(rc, oracle):
+    """A mesh with per-attribute index sets (cube: 8 positions, 6 per-face normals, one metadata value per face) goes through the host
+    mirror's expand_faceviews (GeometryBasics' role in build_and_append_blas!, src/instanced-bvh.jl:581-590) and rc_add_mesh: the
+    triangles come back with the face's normal on all three corners and the face's metadata, and match the oracle's mesh path."""
+    from test_expand_faceviews import cube
+    p, pf, normals, nf = cube()
+    meta = np.arange(101, 113, dtype=np.uint32)
+    pos, faces, attr = rc.expand_faceviews(p, pf, normals=(normals, nf), face_meta=(meta, None))
+    t, s = both(rc, oracle, [(pos, faces, attr["normals"], None, attr["face_meta"])])
+    got, want = t.adapt().all_blas_triangles, s.triangles
+    assert got.tobytes() == want.tobytes() and len(got) == 12
+    hit, tri, dist, bary, inst = rc.closest_hit(t, rc.Ray((0.3, 0.6, 5.0), (0, 0, -1)))   # the z = 1 side, from above
+    assert hit and abs(dist - 4.0) < 1e-6 and tri.metadata in (111, 112)
+    assert np.array_equal(tri.normals, np.tile(np.array([0, 0, 1], np.float32), (3, 1)))
