@@ -320,6 +320,34 @@ def main():
             del dv
         extras["blas_build_device"] = builds
         torch.cuda.empty_cache()
+        # Dynamic scenes (rows a15 / f2; test/test_tlas_stress.jl:284-327 moves 5 000 instances per frame): update_transforms! + sync!
+        # = upload of the transforms, inverses, instance boxes, TLAS refit in place, traversal records -- host wall time per frame --
+        # and the device-resident form (descriptors rewritten in HBM by the caller, rc_refit_device: no PCIe traffic).
+        g = np.random.default_rng(5)
+        n_inst = 5000
+        xf = np.tile(sc.IDENTITY3x4, (n_inst, 1)).astype(np.float32)
+        xf[:, [3, 7, 11]] = (g.random((n_inst, 3)) * 40).astype(np.float32)
+        td = rc.TLAS(local_rank)
+        hnd = td.push(sc.fan_sphere(16, 9), xf)
+        td.sync()
+        frames = []
+        for f in range(12):
+            xf[:, 3] += 0.01
+            f0 = time.perf_counter()
+            td.update_transforms(hnd, xf)
+            td.sync()
+            td.wait_for_gpu()
+            frames.append(time.perf_counter() - f0)
+            assert td.last_sync_action == "refit"
+        dev = []
+        for f in range(12):
+            f0 = time.perf_counter()
+            td.refit_device(recompute_inverse=True)
+            td.wait_for_gpu()
+            dev.append(time.perf_counter() - f0)
+        extras["tlas_refit_5000_instances"] = {"update_transforms_plus_sync_ms": round(min(frames) * 1e3, 3), "refit_device_ms": round(min(dev) * 1e3, 3),
+                                               "refit_device_kernels_ms": round(td.last_kernel_ms(), 3)}
+        td.free()
 
 
     def extra_bvh4_and_collision():
