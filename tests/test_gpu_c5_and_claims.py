@@ -278,3 +278,41 @@ def test_option_clamps(rc):
     with pytest.raises(rc.RaycoreError):
         t.set_option("no_such_option", 1)
     t.free()
+
+
+def test_trace_launches_are_hipgraph_capturable(rc, oracle):
+    """A frame of primary trace -> shadow-ray generation -> any_hit, captured into a hipGraph and replayed: the claim counters reset
+    themselves inside the kernels and a launch leaves no host-side state behind, so a replay is as good as a fresh launch (after one
+    warm-up launch on the capture stream: the first use of a stream allocates its stack spill region, which a capture cannot do)."""
+    import torch
+    sc = rc.scenes
+    cfg = sc.config_c3(lattice=(3, 3, 2))
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    rays = sc.c3_primary_rays(cfg, 320, 200)
+    n = len(rays)
+    want = o.trace(rays, nthreads=8)
+    light = np.array([10, 10, 10], np.float32)
+    want_occ = o.trace(o.shadow_rays(rays, want, light, 1e-3), mode="any", nthreads=8)
+    dr = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+    dh, dsh, docc = (torch.empty(n * 32, dtype=torch.uint8, device="cuda") for _ in range(3))
+    s = torch.cuda.Stream()
+
+    def frame(stream):
+        t.trace_device(dr.data_ptr(), dh.data_ptr(), n, stream=stream)
+        t.shadow_rays_device(dr.data_ptr(), dh.data_ptr(), n, light, dsh.data_ptr(), bias=1e-3, stream=stream)
+        t.trace_device(dsh.data_ptr(), docc.data_ptr(), n, mode="any", stream=stream)
+
+    with torch.cuda.stream(s):
+        frame(s.cuda_stream)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        frame(torch.cuda.current_stream().cuda_stream)
+    for rep in range(4):
+        dh.zero_(); docc.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert_hits_equal(dh.cpu().numpy().view(rc.HIT_DT), want, f"replay {rep} primary")
+        assert np.array_equal(docc.cpu().numpy().view(rc.HIT_DT)["hit"], want_occ["hit"]), rep
+    assert t.get_option("claim_drift") == 0
+    t.free()
