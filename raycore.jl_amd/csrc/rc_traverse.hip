@@ -546,7 +546,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
         total_threads = blocks * kBigBlock;
     }
     if (s->opt.kernel == 5 || s->opt.kernel == 6) {  // two 768-thread workgroups per CU
-        blocks = (uint32_t)std::min<uint64_t>((n + kMidBlock - 1) / kMidBlock, (uint64_t)s->n_cus * 2);
+        blocks = (uint32_t)std::min<uint64_t>((n + kMidBlock - 1) / kMidBlock, (uint64_t)s->n_cus * (s->opt.blocks_per_cu == 1 ? 1 : 2));
         total_threads = blocks * kMidBlock;
     }
     rc_prepare_launch(s, stream);
