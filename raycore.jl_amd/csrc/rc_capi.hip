@@ -546,7 +546,7 @@ static void populate_pages(void* p, size_t bytes) {
 // the kernel overlap: a 4 M-ray batch takes about one direction's transfer time (2.4 ms at 56 GB/s) plus one chunk's latency instead
 // of upload + kernel + download back to back.  The chunks are traced by the same kernels, so the results do not change.
 static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
-    // at most 48 chunks (each launch takes its own counter slot; 64 rotate)
+    // at most 48 chunks of at least 512 Ki rays
     const uint64_t kChunk = std::max<uint64_t>(1ull << 19, ((n + 47) / 48 + 63) & ~63ull);
     const uint64_t n_chunks = (n + kChunk - 1) / kChunk;
     s->ray_stage.reserve(n);
@@ -648,6 +648,7 @@ static int trace_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint6
     return guarded([&] {
         use_device(s);
         require_synced(s);
+        if (n && (!d_rays || !d_hits)) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
         rc_launch_trace(s, reinterpret_cast<const RcRay*>(d_rays), reinterpret_cast<RcHit*>(d_hits), n, any, (hipStream_t)stream);
     });
 }
@@ -716,6 +717,7 @@ static int trace4_device(rc_scene* s, uint32_t blas_id, const rc_ray* d_rays, rc
     return guarded([&] {
         use_device(s);
         Blas& b = blas4_of(s, blas_id);
+        if (n && (!d_rays || !d_hits)) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
         rc_launch_trace4(s, b, reinterpret_cast<const RcRay*>(d_rays), reinterpret_cast<RcHit*>(d_hits), n, any, (hipStream_t)stream);
     });
 }
@@ -984,7 +986,7 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
 }
 
 int rc_generate_ray_grid_device(rc_scene* s, const float viewdir[3], uint32_t grid, rc_ray* d_rays, void* stream) {
-    if (!s || !viewdir) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!s || !viewdir || (grid && !d_rays)) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {
         use_device(s);
         require_synced(s);
@@ -993,7 +995,7 @@ int rc_generate_ray_grid_device(rc_scene* s, const float viewdir[3], uint32_t gr
 }
 
 int rc_get_illumination_device(rc_scene* s, const float viewdir[3], uint32_t grid, uint64_t ray_begin, uint64_t ray_end, float* d_counts, void* stream) {
-    if (!s || !viewdir) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!s || !viewdir || !d_counts) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {
         use_device(s);
         require_synced(s);

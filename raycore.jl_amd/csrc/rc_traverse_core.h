@@ -427,6 +427,33 @@ __device__ inline void stage_partial_top(float2* tl, const SceneView& v, uint32_
     }
 }
 
+// safe_invdir (src/instanced-bvh.jl:1742-1748) of three components with the division written out.  hipcc's correctly rounded 1.0f / x is
+// v_div_scale x 2, v_rcp, six fma / mul steps, v_div_fmas, v_div_fixup; for a denominator in [1e-5, 2^60) (the clamp guarantees the lower
+// end) neither v_div_scale scales nor v_div_fixup changes anything and 1.0f * r is r, so the same rcp + six fma give the same bits in 7
+// instead of 11 VALU instructions -- an instance entry does three of these.  Any lane outside that range (huge, inf or NaN direction
+// components) sends the whole wave down the generic division.
+__device__ inline float rcp_rn_normal(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = r;
+    const float e2 = __builtin_fmaf(-d, q, 1.0f);
+    q = __builtin_fmaf(e2, r, q);
+    const float e3 = __builtin_fmaf(-d, q, 1.0f);
+    return __builtin_fmaf(e3, r, q);
+}
+__device__ inline float3_ safe_inv3(const float3_ d) {
+    const float ooeps = 1.0e-5f;
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    const bool tame = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az) < 0x1p60f && ax == ax && ay == ay && az == az;
+    if (__builtin_expect(__ballot(!tame) == 0ull, 1)) {
+        const float cx = ax > ooeps ? d.x : __builtin_copysignf(ooeps, d.x), cy = ay > ooeps ? d.y : __builtin_copysignf(ooeps, d.y),
+                    cz = az > ooeps ? d.z : __builtin_copysignf(ooeps, d.z);
+        return mk3(rcp_rn_normal(cx), rcp_rn_normal(cy), rcp_rn_normal(cz));
+    }
+    return mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
+}
+
 template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS, bool PARTIAL_LDS = false>
 __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
                                     const LdsTop top = LdsTop()) {
@@ -569,7 +596,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         m2.x * wo.x + m2.y * wo.y + m2.z * wo.z + m2.w);
                 d = mk3(m0.x * wd.x + m0.y * wd.y + m0.z * wd.z, m1.x * wd.x + m1.y * wd.y + m1.z * wd.z,
                         m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
-                inv = mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
+                inv = safe_inv3(d);
                 ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
             }
         }
@@ -606,7 +633,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         const RcRay r = src(my_ray);
                         wo = mk3(r.ox, r.oy, r.oz);  // init (:1904-1927); check_direction (src/ray.jl:39-49)
                         wd = mk3(r.dx == 0.0f ? 0.0f : r.dx, r.dy == 0.0f ? 0.0f : r.dy, r.dz == 0.0f ? 0.0f : r.dz);
-                        winv = mk3(safe_inv1(wd.x), safe_inv1(wd.y), safe_inv1(wd.z));
+                        winv = safe_inv3(wd);
                         inv = winv;  // (o, d are the instance-local ray: set at the first instance entry)
                         ox = mk3(-wo.x * inv.x, -wo.y * inv.y, -wo.z * inv.z);
                         tmin = ANY ? 0.0f : r.tmin;
