@@ -208,6 +208,21 @@ def main():
                 scene.trace_device(dr.data_ptr(), dh.data_ptr(), len(rs), mode=mode, stream=stream.cuda_stream)
                 best = min(best, scene.last_kernel_ms())
             return round(len(rs) / best / 1e3, 1)
+        def in_flight(scene, rs, n_streams=4, batches=32):
+            """Rate with n_streams launches of the same batch in flight (one stream and one output each): what a caller that pipelines
+            mid-size batches sees -- the tail of one launch (waves waiting for their longest rays) overlaps the bulk of the next."""
+            dr = torch.from_numpy(rs.view(np.uint8).reshape(-1)).cuda()
+            sts = [torch.cuda.Stream() for _ in range(n_streams)]
+            outs = [torch.empty(len(rs) * 32, dtype=torch.uint8, device="cuda") for _ in range(n_streams)]
+            rate = 0.0
+            for _ in range(2):
+                torch.cuda.synchronize()
+                p0 = time.perf_counter()
+                for i in range(batches):
+                    scene.trace_device(dr.data_ptr(), outs[i % n_streams].data_ptr(), len(rs), stream=sts[i % n_streams].cuda_stream)
+                torch.cuda.synchronize()
+                rate = round(len(rs) * batches / (time.perf_counter() - p0) / 1e6, 1)
+            return rate
         # Throughput with consecutive batches overlapped on two streams (fill / drain of one launch hidden behind the next; each
         # stream has its own stack spill region, each launch its own counters).  Not the headline: per-launch attribution is lost.
         def pipelined(kernel_opt):
@@ -236,7 +251,9 @@ def main():
         t2.add_geometry(*cfg2["blas"][0])
         t2.push_instances(1, cfg2["instances"][0][1], cfg2["instances"][0][2])
         t2.sync()
-        extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(t2, rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"]), "closest", reps=5)
+        rays2 = rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"])
+        extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(t2, rays2, "closest", reps=5)
+        extras["c2_100k_blas_1M_coherent_closest_4_in_flight_mrays_s"] = in_flight(t2, rays2)
         t2.free()
         # Top levels beyond the 256 instances the full LDS kernel takes (kernel 6: TLAS / BLAS tops in LDS, the rest from memory):
         # the C3 BLAS on bigger lattices, same 4 M-ray pinhole camera
@@ -265,8 +282,9 @@ def main():
             tb.push_instances(1)
             tb.sync()
             del dv
-            rate = timed(tb, rc.generate_ray_grid(tb, (0.3, 0.2, 1.0), 1000), "closest", reps=5)
-            ref[str(nt)] = {"mrays_s": rate, "ms_per_1M_rays": round(1e3 / rate, 3), "reference_rx7900xtx_ms": ref_ms}
+            rg = rc.generate_ray_grid(tb, (0.3, 0.2, 1.0), 1000)
+            rate = timed(tb, rg, "closest", reps=5)
+            ref[str(nt)] = {"mrays_s": rate, "ms_per_1M_rays": round(1e3 / rate, 3), "mrays_s_4_in_flight": in_flight(tb, rg), "reference_rx7900xtx_ms": ref_ms}
             tb.free()
         extras["random_geometry_1M_rays_closest"] = ref
         torch.cuda.empty_cache()
