@@ -934,6 +934,7 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "claim_shards") { int64_t p2 = 1; while (p2 * 2 <= value && p2 * 2 <= kClaimShards) p2 *= 2; s->opt.claim_shards = p2; }  // a power of two
     else if (k == "host_pipeline") s->opt.host_pipeline = value != 0;
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (k == "timeline_ptr") s->opt.timeline_ptr = value;  // dev instrumentation: the caller owns the buffer and its size (8 x u64 per wave of the launch)
     else if (k == "debug_set_overflow") {  // test hook: raise the sticky stack-overflow word as a kernel would (no LBVH is deep enough to do it for real)
         if (!s->counters.p) return fail(RC_ERR_INVALID_ARGUMENT, "debug_set_overflow: no launch has run on this scene yet");
         const uint32_t one = value ? 1u : 0u;

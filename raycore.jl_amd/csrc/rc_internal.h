@@ -96,6 +96,7 @@ struct TraceOptions {
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
     int64_t host_pipeline = 1; // host-buffer trace calls of >= 1 Mi rays overlap upload / trace / download in chunks
     int64_t claim_shards = 16; // phased kernels: chunk counters in use (a power of two <= kClaimShards)
+    int64_t timeline_ptr = 0;  // dev: device address of 8 x u64 per wave (n_cus x 24 waves) that kernel 5 fills with its waves' event times; 0 = off
 };
 
 struct rc_scene {

@@ -111,7 +111,7 @@ constexpr int kBigBlock = 1024;
 constexpr size_t kBigStackBytes = (size_t)kLdsStack * kBigBlock * 4;
 constexpr size_t kBigLdsBytes = kBigStackBytes + kLdsTopBytes;
 
-template <bool ANY, int BLOCK, int LDS_N, int MINW>
+template <bool ANY, int BLOCK, int LDS_N, int MINW, bool TIMELINE = false>
 __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr size_t stack_bytes = (size_t)LDS_N * BLOCK * 4;
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     const LdsTop top(smem + stack_bytes);
     if (a.v.n_tlas_nodes) stage_lds_top<BLOCK>(top, a.v, a.blas_k, a.lds_blas_base);
     __syncthreads();
-    PersistArgs p{a.n_rays, a.claim, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, 0u};
-    phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
+    PersistArgs p{a.n_rays, a.claim, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, 0u, a.timeline};
+    phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, true, false, TIMELINE>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
 // ---- kernel 6: kernel 5's shape for top levels that do not fit (more than 256 instances): only the breadth-first tops of the TLAS and
@@ -490,6 +490,10 @@ static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hip
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
             attr_set = true;
         }
+        if (a.timeline) {  // dev: the same kernel with per-wave event times written to the caller's buffer (option "timeline_ptr")
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
+            hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
+        } else
         hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
     } else if (s->opt.kernel == 6) {
         bool& attr_set = s->lds_attr_set[6 + (ANY ? 1 : 0)];
@@ -557,6 +561,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.refill = (int)s->opt.refill;
     a.sched_thr = s->opt.kernel == 2 ? 32 : (int)s->opt.sched_thr;  // kernel 2's vote threshold is its own (lanes that must wait for a batch), tuned at 32
     a.stats = rc_stats_words(s);
+    a.timeline = reinterpret_cast<unsigned long long*>(s->opt.timeline_ptr);
     if ((s->opt.kernel == 5 || s->opt.kernel == 4) && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
     if (s->opt.kernel == 6) {  // a plan made for the full-LDS kernels (<= 256 instances) has no TLAS renumbering: tlas_k = 0, its blas_k still fits
         a.tlas_k = s->tlas_top_k; a.blas_k = s->opt.blas_top ? s->blas_top_k : 0; a.lds_blas_base = s->tlas_top_k;

@@ -80,6 +80,7 @@ struct TraceArgs {
     int sched_thr;                     // scheduled kernel: run a leaf/entry batch once this many lanes wait for it
     unsigned long long* stats;         // optional instrumentation (dev builds), else nullptr
     uint32_t blas_k = 0, lds_blas_base = 0, tlas_k = 0;
+    unsigned long long* timeline = nullptr;  // dev (option "timeline_ptr"): per-wave event record of kernel 5
 };
 
 // Address-space-qualified pointers keep the two halves of the stack on their own instruction paths
@@ -361,6 +362,7 @@ struct PersistArgs {
     uint32_t blas_k = 0;               // TLAS_LDS kernels: BLAS nodes 1..blas_k are staged in the planes at entry lds_blas_base + node - 1
     uint32_t lds_blas_base = 0;
     uint32_t tlas_k = 0;               // PARTIAL_LDS kernels: TLAS nodes 1..tlas_k are staged at entry node - 1 (the rest comes from memory)
+    unsigned long long* timeline = nullptr;  // TIMELINE builds (dev): 8 words per wave, see the end of phased_trace
 };
 
 // TLAS_LDS / INST_LDS: the block has staged the top level in LDS before the call (LdsTop below; layout and sizes in rc_internal.h):
@@ -454,7 +456,8 @@ __device__ inline float3_ safe_inv3(const float3_ d) {
     return mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
 }
 
-template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS, bool PARTIAL_LDS = false>
+template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS, bool PARTIAL_LDS = false,
+          bool TIMELINE = false>
 __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
                                     const LdsTop top = LdsTop()) {
     const float2* const tl = top.tl;
@@ -486,6 +489,9 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0};
     unsigned long long st_t0 = STATS ? wall_clock64() : 0ull, st_tx = 0ull;
     int thr_eff = __builtin_amdgcn_readfirstlane(a.int_thr);  // wave-uniform: keeps the loop-exit compare on the scalar unit
+    // TIMELINE (dev, tools/timeline_probe.py): per-wave event times and scalar counts, cheap enough not to move the schedule
+    unsigned long long tl_t0 = TIMELINE ? wall_clock64() : 0ull, tl_tx = 0ull, tl_t16 = 0ull, tl_t4 = 0ull;
+    uint32_t tl_outer = 0, tl_outer_x = 0, tl_live_x = 0, tl_int = 0, tl_int_x = 0;
 
     for (;;) {
         // ---- interior phase: intersect_internal_node (:1807-1832) + push far / descend near / pop (:1946-1960, 1991-1993)
@@ -494,6 +500,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             const int n_int = __popcll(__ballot(is_int));
             if (n_int == 0) break;
             if (STATS) { st_iter[1] += 1; st_lane[1] += is_int ? 1 : 0; }
+            if (TIMELINE) { tl_int += 1; if (tl_tx) tl_int_x += 1; }
             if (is_int) {
                 float4 na, nb, nc;
                 u2v ch;
@@ -606,6 +613,16 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             const int n_free = __popcll(__ballot(fin || !live));
             const bool can_refill = !(exhausted && pool_next == pool_end);
             if (STATS && !can_refill && st_tx == 0) st_tx = wall_clock64();
+            if (TIMELINE) {
+                tl_outer += 1;
+                if (!can_refill) {
+                    const uint32_t n_live = 64u - (uint32_t)n_free;
+                    if (tl_tx == 0) tl_tx = wall_clock64();
+                    tl_outer_x += 1; tl_live_x += n_live;
+                    if (n_live < 16u && tl_t16 == 0) tl_t16 = wall_clock64();
+                    if (n_live < 4u && tl_t4 == 0) tl_t4 = wall_clock64();
+                }
+            }
             if (!can_refill) {  // drain: no more rays to hand out, so the interior loop's exit threshold follows the lanes still alive
                 const int half_live = (64 - n_free) / 2;
                 thr_eff = __builtin_amdgcn_readfirstlane(half_live < a.int_thr ? (half_live > 1 ? half_live : 1) : a.int_thr);
@@ -651,6 +668,11 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 }
             }
         }
+    }
+    if (TIMELINE && lane == 0 && a.timeline) {  // [t0, tx (claims dry + own pool empty), t(<16 live), t(<4 live), t_end, outer | outer after tx << 32, interior iterations | after tx << 32, sum of live lanes after tx]
+        unsigned long long* w = a.timeline + (size_t)(gtid >> 6) * 8u;
+        w[0] = tl_t0; w[1] = tl_tx; w[2] = tl_t16; w[3] = tl_t4; w[4] = wall_clock64();
+        w[5] = tl_outer | ((unsigned long long)tl_outer_x << 32); w[6] = tl_int | ((unsigned long long)tl_int_x << 32); w[7] = tl_live_x;
     }
     if (STATS) {
         const unsigned long long t_end = wall_clock64();
