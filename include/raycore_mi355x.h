@@ -160,7 +160,10 @@ int rc_export_prims(rc_scene* scene, rc_prim* out, uint32_t capacity, uint32_t* 
 int rc_trace_closest(rc_scene* scene, const rc_ray* rays, rc_hit* hits, uint64_t n);
 int rc_trace_any(rc_scene* scene, const rc_ray* rays, rc_hit* hits, uint64_t n);
 /* Device-buffer form: d_rays / d_hits are device pointers on the scene's device; the launch is enqueued
- * on `stream` (a hipStream_t, NULL = the null stream) and is asynchronous. */
+ * on `stream` (a hipStream_t, NULL = the null stream) and is asynchronous.  Launches on different streams
+ * may be in flight together (each has its own work counters); for batches of about a million rays that is
+ * worth 1.4x: the end of a launch -- waves waiting for their longest rays -- leaves most of the machine to
+ * the next one (mid-size batches). */
 int rc_trace_closest_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream);
 int rc_trace_any_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream);
 
@@ -169,7 +172,9 @@ int rc_trace_any_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, u
  * "blocks_per_cu", "lds_stack", "refill", "sched_thr", "pool", "claim_shards" (scheduling knobs of the
  * persistent kernels), "blas_top" (1 = a scene with a single BLAS keeps that BLAS's top internal
  * nodes in LDS; takes effect at the next structural rc_sync), "onesweep_min" (key count from which
- * the builds sort with Onesweep radix passes instead of a merge sort), "stats" (dev counters).
+ * the builds sort with Onesweep radix passes instead of a merge sort), "stats" (dev counters),
+ * "timeline_ptr" (dev: device address of 8 x u64 per wave that kernel 5 fills with its waves' event
+ * times, tools/timeline_probe.py; 0 = off).
  * Read-only: "n_cus", "blas_top_k", "tlas_top_k", "stat0".."statf". */
 int rc_set_option(rc_scene* scene, const char* name, int64_t value);
 int rc_get_option(rc_scene* scene, const char* name, int64_t* value);
