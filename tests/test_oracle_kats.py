@@ -188,6 +188,37 @@ def test_kernel_full_trace(oracle):  # test/test_instanced_bvh.jl:994-1042
     assert list(h["instance_id"][:2] + 1) == [1, 2]
 
 
+def test_kernel_metadata_three_meshes(oracle):  # test/test_instanced_bvh.jl:918-952
+    s = oracle.Scene()
+    for off in ((0, 0, 0), (5, 0, 0), (0, 5, 0)):
+        s.add_instance(s.add_blas(UNIT_TRI + np.tile(off, 3).astype(np.float32), meta=[0]))  # "metadata from mesh is 0 by default"
+    s.build()
+    o = [[0.25, 0.25, 1.0], [5.25, 0.25, 1.0], [0.25, 5.25, 1.0], [10.0, 10.0, 1.0]]
+    h = s.trace(oracle.make_rays(o, [0, 0, -1]))
+    assert list(h["hit"]) == [1, 1, 1, 0]
+    assert list(s.blas_prims["meta"][h["primitive_id"][:3]]) == [0, 0, 0]
+
+
+def test_kernel_dynamic_transform(oracle):  # test/test_instanced_bvh.jl:1044-1088: the scene after update_transform!(x = 10) + sync!
+    before, after = single_tri_scene(oracle), single_tri_scene(oracle, xforms=(xlat4(10, 0, 0),))
+    at_origin, at_ten = oracle.make_rays([[0.25, 0.25, 1.0]], [0, 0, -1]), oracle.make_rays([[10.25, 0.25, 1.0]], [0, 0, -1])
+    assert before.trace(at_origin)["hit"][0] == 1
+    assert after.trace(at_origin)["hit"][0] == 0
+    h = after.trace(at_ten)
+    assert h["hit"][0] == 1 and h["t"][0] == pytest.approx(1.0)
+
+
+def test_kernel_dynamic_add_instance(oracle):  # test/test_instanced_bvh.jl:1090-1131: before and after the second push! + sync!
+    rays = oracle.make_rays([[0.25, 0.25, 1.0], [5.25, 0.25, 1.0]], [0, 0, -1])
+    one = oracle.Scene()
+    one.add_instance(one.add_blas(UNIT_TRI))
+    assert list(one.build().trace(rays)["hit"]) == [1, 0]
+    two = oracle.Scene()
+    for off in ((0, 0, 0), (5, 0, 0)):
+        two.add_instance(two.add_blas(UNIT_TRI + np.tile(off, 3).astype(np.float32)))
+    assert list(two.build().trace(rays)["hit"]) == [1, 1]
+
+
 def test_kernel_64_ray_batch(oracle):  # test/test_instanced_bvh.jl:1133-1159
     s = single_tri_scene(oracle)
     o = [[0.25 + 0.5 * (i % 8) / 7, 0.25 + 0.5 * ((i // 8) % 8) / 7, 1.0] for i in range(64)]
