@@ -51,7 +51,7 @@ def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_
     c = pmc.get("counters_mean_per_launch", {})
     valu = c.get("SQ_INSTS_VALU")
     traffic = (pmc.get("hbm") or {}).get("c3_closest_bytes_per_launch")
-    kname = {-1: "k_trace_phased_lds<false, 768, 16, 6>", 5: "k_trace_phased_lds<false, 768, 16, 6>", 3: "k_trace_phased<false, 24, 6, false>"}.get(kernel_option, f"kernel option {kernel_option}")
+    kname = {-1: "k_trace_phased_lds<false, 768, 16, 6, false>", 5: "k_trace_phased_lds<false, 768, 16, 6, false>", 3: "k_trace_phased<false, 24, 6, false>"}.get(kernel_option, f"kernel option {kernel_option}")
     if valu and profiled_config:
         achieved = valu / (launch_ms * 1e-3) / 1e9
         roofline = {"bound": "valu-issue", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s",
