@@ -280,6 +280,23 @@ def test_option_clamps(rc):
     t.free()
 
 
+def test_device_entry_points_reject_null_buffers(rc):
+    """The device-pointer entry points are asynchronous: a NULL ray / hit / output pointer must be refused on the host (an error code
+    and a message), not handed to a kernel."""
+    from raycore_jl_amd._capi import lib
+    import ctypes as C
+    t = build_product(rc, rc.scenes.config_c3(lattice=(2, 2, 1)))
+    L = lib()
+    for fn in (L.rc_trace_closest_device, L.rc_trace_any_device):
+        assert fn(t._h, None, None, 64, None) == 1  # RC_ERR_INVALID_ARGUMENT
+        assert fn(t._h, None, None, 0, None) == 0  # an empty batch needs no buffers
+    view = (C.c_float * 3)(0.0, 0.0, 1.0)
+    assert L.rc_generate_ray_grid_device(t._h, view, 8, None, None) != 0
+    assert L.rc_get_illumination_device(t._h, view, 8, 0, 64, None, None) != 0
+    assert b"NULL" in L.rc_last_error()
+    t.free()
+
+
 def test_trace_launches_are_hipgraph_capturable(rc, oracle):
     """A frame of primary trace -> shadow-ray generation -> any_hit, captured into a hipGraph and replayed: the claim counters reset
     themselves inside the kernels and a launch leaves no host-side state behind, so a replay is as good as a fresh launch (after one
