@@ -280,6 +280,34 @@ def test_option_clamps(rc):
     t.free()
 
 
+def test_drivers_against_closed_forms(rc):
+    """The HIP drivers against answers that come from neither implementation (tests/test_oracle_analytic_drivers.py has the
+    derivations): view_factors' uniform-hemisphere sampling => solid angle of a square over 2 pi; get_illumination => the grid points
+    inside a rectangle facing the view direction."""
+    a, h, eps, rays = 1.0, 1.0, 1e-3, 400_000
+    src = np.array([[-eps, -eps, 0, eps, -eps, 0, 0, eps, 0]], np.float32)
+    p = [(-a, -a, h), (a, -a, h), (a, a, h), (-a, a, h)]
+    target = np.array([(p[0], p[2], p[1]), (p[0], p[3], p[2])], np.float32).reshape(-1, 9)
+    t = rc.TLAS(0)
+    t.add_geometry(np.concatenate([src, target]), np.array([1, 2, 3], np.uint32))
+    t.push_instances(1)
+    t.sync()
+    row = rc.view_factors(t, rays, seed=11)[0].astype(np.int64)
+    want = 4.0 * np.arctan(a * a / ((h - 0.01) * np.sqrt(2 * a * a + (h - 0.01) ** 2))) / (2 * np.pi)
+    assert row[0] == 0 and abs(row[1:].sum() / rays - want) < 5 * np.sqrt(want * (1 - want) / rays)
+    t.free()
+    grid = 220
+    t = rc.TLAS(0)
+    t.add_geometry(np.array([[0, 0, 0, 1, 0, 0, 1, 2, 0], [0, 0, 0, 1, 2, 0, 0, 2, 0]], np.float32), np.array([1, 2], np.uint32))
+    t.push_instances(1)
+    t.sync()
+    counts = rc.get_illumination(t, (0, 0, -1), grid)
+    n_long = sum(1 for i in range(1, grid + 1) if abs((i - (grid + 1) / 2) * (2.2 / grid)) <= 1.0)
+    n_short = sum(1 for i in range(1, grid + 1) if abs((i - (grid + 1) / 2) * (1.2 / grid)) <= 0.5)
+    assert abs(int(counts.sum()) - n_long * n_short) <= max(n_long, n_short)
+    t.free()
+
+
 def test_device_entry_points_reject_null_buffers(rc):
     """The device-pointer entry points are asynchronous: a NULL ray / hit / output pointer must be refused on the host (an error code
     and a message), not handed to a kernel."""
