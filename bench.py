@@ -502,7 +502,7 @@ def main():
             "config": {"workload": "C3: TLAS of 256 rotated/scaled instances of one 4096-triangle BLAS (1 048 576 triangles), "
                                    f"{n} pinhole primary rays per GPU per step, closest_hit",
                        "triangles": int(n_tris), "rays_per_step_per_gpu": n, "hit_fraction": round(hit_frac, 4),
-                       "kernel": {-1: "auto (phased persistent, top level in LDS)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased", 4: "phased + top level in LDS, 1024-thread workgroups", 5: "phased + top level in LDS"}[t.get_option("kernel")], "parallelism": f"replicas x{world} (rays sharded, no collective)"},
+                       "kernel": {-1: "auto (phased persistent, top level in LDS)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased", 4: "phased + top level in LDS, 1024-thread workgroups", 5: "phased + top level in LDS", 6: "phased + tops of the TLAS / BLAS in LDS"}.get(t.get_option("kernel"), "option"), "parallelism": f"replicas x{world} (rays sharded, no collective)"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "extras": extras,
