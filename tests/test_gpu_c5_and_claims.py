@@ -308,6 +308,32 @@ def test_drivers_against_closed_forms(rc):
     t.free()
 
 
+def test_timeline_instrumentation_keeps_results(rc):
+    """Option "timeline_ptr" (dev, tools/timeline_probe.py): kernel 5 built with per-wave event stamps writes 8 words per wave into the
+    caller's buffer and returns the same hits."""
+    import torch
+    cfg = rc.scenes.config_c3(lattice=(3, 3, 2))
+    t = build_product(rc, cfg)
+    rays = rc.scenes.c3_primary_rays(cfg, 512, 512)
+    n = len(rays)
+    dr = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+    a, b = (torch.empty(n * 32, dtype=torch.uint8, device="cuda") for _ in range(2))
+    t.set_option("kernel", 5)
+    t.trace_device(dr.data_ptr(), a.data_ptr(), n)
+    waves = t.get_option("n_cus") * 24
+    buf = torch.zeros(waves * 8, dtype=torch.int64, device="cuda")
+    t.set_option("timeline_ptr", buf.data_ptr())
+    t.trace_device(dr.data_ptr(), b.data_ptr(), n)
+    t.set_option("timeline_ptr", 0)
+    torch.cuda.synchronize()
+    assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes()
+    w = buf.cpu().numpy().reshape(-1, 8)
+    ran = w[w[:, 4] != 0]
+    assert len(ran) == min(waves, (n + 767) // 768 * 12)
+    assert (ran[:, 4] >= ran[:, 0]).all() and ((ran[:, 1] == 0) | (ran[:, 1] >= ran[:, 0])).all()  # end after start, dry time after start
+    t.free()
+
+
 def test_device_entry_points_reject_null_buffers(rc):
     """The device-pointer entry points are asynchronous: a NULL ray / hit / output pointer must be refused on the host (an error code
     and a message), not handed to a kernel."""
