@@ -305,6 +305,8 @@ def test_drivers_against_closed_forms(rc):
     n_long = sum(1 for i in range(1, grid + 1) if abs((i - (grid + 1) / 2) * (2.2 / grid)) <= 1.0)
     n_short = sum(1 for i in range(1, grid + 1) if abs((i - (grid + 1) / 2) * (1.2 / grid)) <= 0.5)
     assert abs(int(counts.sum()) - n_long * n_short) <= max(n_long, n_short)
+    pts, centre = rc.get_centroid(t, (0, 0, -1), grid_size=64)  # hit points of a symmetric grid over the rectangle: their mean is its centre
+    assert len(pts) > 1000 and np.allclose(centre, (0.5, 1.0, 0.0), atol=2e-2) and np.abs(pts[:, 2]).max() < 1e-5
     t.free()
 
 
