@@ -136,13 +136,17 @@ template <typename T> void put_dev(FILE* f, const T* d, size_t n, std::vector<un
     RC_HIP(hipMemcpy(tmp.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
     put(f, tmp.data(), tmp.size());
 }
-template <typename T> void get_dev(FILE* f, DevBuf<T>& d, size_t n, std::vector<unsigned char>& tmp) {
+// `check(host copy)` runs before the upload: a scene file is untrusted input, and the kernels index with what it holds
+template <typename T, typename Check> void get_dev(FILE* f, DevBuf<T>& d, size_t n, std::vector<unsigned char>& tmp, Check&& check) {
     d.reserve(n ? n : 1);
     if (!n) return;
     tmp.resize(n * sizeof(T));
     get(f, tmp.data(), tmp.size());
+    check(reinterpret_cast<const T*>(tmp.data()));
     RC_HIP(hipMemcpy(d.p, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
 }
+template <typename T> void get_dev(FILE* f, DevBuf<T>& d, size_t n, std::vector<unsigned char>& tmp) { get_dev(f, d, n, tmp, [](const T*) {}); }
+void bad_file(const char* what) { throw RcError(RC_ERR_INVALID_ARGUMENT, std::string("scene file: ") + what); }
 }  // namespace
 
 extern "C" {
@@ -881,12 +885,24 @@ int rc_scene_load(int device, const char* path, rc_scene** out) {
             get(fc.f, b.root_min, 12);
             get(fc.f, b.root_max, 12);
             get_dev(fc.f, b.prims, b.n_prims, tmp);
-            get_dev(fc.f, b.nodes, b.n_nodes, tmp);
+            get_dev(fc.f, b.nodes, b.n_nodes, tmp, [&](const RcNode* nd) {  // internal nodes 1..n-1 point at nodes, leaves n..2n-1 at a sorted primitive
+                for (uint32_t i = 0; i < b.n_nodes; ++i) {
+                    const bool leaf = nd[i].child0 == RC_INVALID_NODE;
+                    if (leaf != (i + 1 >= b.n_prims)) bad_file("node kinds do not follow the LBVH numbering");
+                    if (leaf ? (nd[i].child1 < 1 || nd[i].child1 > b.n_prims)
+                             : (nd[i].child0 < 1 || nd[i].child0 > b.n_nodes || nd[i].child1 < 1 || nd[i].child1 > b.n_nodes))
+                        bad_file("node child index out of range");
+                }
+            });
             if (b.has_attrs) {
                 get_dev(fc.f, b.m_normals, 3 * (size_t)b.n_mesh_verts, tmp);
                 if (b.has_uvs) get_dev(fc.f, b.m_uvs, 2 * (size_t)b.n_mesh_verts, tmp);
-                get_dev(fc.f, b.m_indices, 3 * (size_t)b.n_mesh_faces, tmp);
-                get_dev(fc.f, b.src_face, b.n_prims, tmp);
+                get_dev(fc.f, b.m_indices, 3 * (size_t)b.n_mesh_faces, tmp, [&](const uint32_t* ix) {
+                    for (size_t i = 0; i < 3 * (size_t)b.n_mesh_faces; ++i) if (ix[i] >= b.n_mesh_verts) bad_file("face index out of range");
+                });
+                get_dev(fc.f, b.src_face, b.n_prims, tmp, [&](const uint32_t* sf) {
+                    for (uint32_t i = 0; i < b.n_prims; ++i) if (sf[i] >= b.n_mesh_faces) bad_file("source face out of range");
+                });
             }
         }
         s->dirty = true;  // the TLAS and the flat arrays are rebuilt by the next rc_sync

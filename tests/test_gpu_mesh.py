@@ -142,6 +142,17 @@ def test_scene_save_load_roundtrip(rc, oracle, tmp_path):
     (tmp_path / "junk.rcs").write_bytes(b"not a scene file at all, definitely")
     with pytest.raises(rc.RaycoreError):
         rc.TLAS.load(tmp_path / "junk.rcs")
+    # a file is untrusted input: indices the kernels would follow are checked before anything is uploaded
+    data = bytearray(path.read_bytes())
+    _, n_blas, n_inst, _, n_handles, _ = np.frombuffer(data, np.uint32, 6, 8)
+    off = 32 + 12 * int(n_handles) + 108 * int(n_inst)            # first geometry: header (6 u32), root box (6 f32), primitives (40 B), nodes (64 B)
+    n_prims = int(np.frombuffer(data, np.uint32, 1, off)[0])
+    child0_of_root = off + 24 + 24 + 40 * n_prims + 48
+    assert 1 <= int(np.frombuffer(data, np.uint32, 1, child0_of_root)[0]) <= 2 * n_prims - 1
+    data[child0_of_root:child0_of_root + 4] = np.uint32(0x7FFFFFFF).tobytes()
+    (tmp_path / "bad_child.rcs").write_bytes(bytes(data))
+    with pytest.raises(rc.RaycoreError, match="child index"):
+        rc.TLAS.load(tmp_path / "bad_child.rcs")
 
 
 def test_scene_save_load_keeps_the_lds_plan(rc, tmp_path):
