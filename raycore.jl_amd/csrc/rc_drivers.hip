@@ -115,6 +115,16 @@ __global__ __launch_bounds__(kMidBlock, 6) void k_illumination_lds(SceneView v, 
     phased_trace<false, kMidStack, false, GridSource, HistogramSink, kMidBlock, true, true>(v, p, reinterpret_cast<uint32_t*>(smem), GridSource{g, ray_begin},
                                                                                             HistogramSink{v.inst, v.prims, v.n_prims, counts}, top);
 }
+// Larger top levels (the shape of trace kernel 6): only the breadth-first tops of the TLAS and of a single BLAS are staged.
+__global__ __launch_bounds__(kMidBlock, 6) void k_illumination_partial(SceneView v, PersistArgs p, GridParams g, uint64_t ray_begin, float* counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsTop top;
+    top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
+    stage_partial_top<kMidBlock>(top.tl, v, p.tlas_k, p.blas_k, p.lds_blas_base);
+    __syncthreads();
+    phased_trace<false, kMidStack, false, GridSource, HistogramSink, kMidBlock, false, false, true>(v, p, reinterpret_cast<uint32_t*>(smem), GridSource{g, ray_begin},
+                                                                                                     HistogramSink{v.inst, v.prims, v.n_prims, counts}, top);
+}
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------------
 __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -262,6 +272,18 @@ __global__ __launch_bounds__(kMidBlock, 6) void k_view_factors_lds(SceneView v, 
     stage_lds_top<kMidBlock>(top, v, p.blas_k, p.lds_blas_base);
     __syncthreads();
     phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorSink, kMidBlock, true, true>(
+        v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, order, k0, k1, src_begin, ray_begin, n_ray},
+        ViewFactorSink{v.inst, v.prims, order, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags}, top);
+}
+__global__ __launch_bounds__(kMidBlock, 6) void k_view_factors_partial(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin,
+                                                                        uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
+                                                                        uint64_t col_stride, uint32_t row_offset, uint32_t flags, const uint32_t* order) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsTop top;
+    top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
+    stage_partial_top<kMidBlock>(top.tl, v, p.tlas_k, p.blas_k, p.lds_blas_base);
+    __syncthreads();
+    phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorSink, kMidBlock, false, false, true>(
         v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, order, k0, k1, src_begin, ray_begin, n_ray},
         ViewFactorSink{v.inst, v.prims, order, v.n_prims, src_begin, n_ray, matrix, row_stride, col_stride, row_offset, flags}, top);
 }
@@ -422,14 +444,22 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
     if (ray_end <= ray_begin) return;
     check_buffer_range(s);
     GridParams g = grid_params(s, viewdir, grid);
-    const bool lds = rc_lds_driver_ok(s);
+    const bool partial = rc_partial_driver_ok(s);
+    const bool lds = partial || rc_lds_driver_ok(s);
     const uint32_t bs = lds ? (uint32_t)kMidBlock : (uint32_t)kBlock;
     uint32_t blocks = lds ? rc_lds_driver_blocks(s, ray_end - ray_begin) : rc_persistent_blocks(s, ray_end - ray_begin);
     rc_prepare_launch(s, stream);
     SceneView v = rc_scene_view(s, blocks * bs);
     PersistArgs p = rc_persist_args(s, ray_end - ray_begin, blocks * bs, stream);
     RC_HIP(hipEventRecord(s->ev0, stream));
-    if (lds) {
+    if (partial) {
+        rc_partial_driver_args(s, p);
+        if (!s->lds_attr_set[8]) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_illumination_partial), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartialLdsBytes));
+            s->lds_attr_set[8] = true;
+        }
+        hipLaunchKernelGGL(k_illumination_partial, dim3(blocks), dim3(kMidBlock), kPartialLdsBytes, stream, v, p, g, ray_begin, d_counts);
+    } else if (lds) {
         rc_lds_driver_args(s, p);
         if (!s->lds_attr_set[4]) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_illumination_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
@@ -466,14 +496,23 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
         }
         order = s->vf_order.p;
     }
-    const bool lds = rc_lds_driver_ok(s);
+    const bool partial = rc_partial_driver_ok(s);
+    const bool lds = partial || rc_lds_driver_ok(s);
     const uint32_t bs = lds ? (uint32_t)kMidBlock : (uint32_t)kBlock;
     uint32_t blocks = lds ? rc_lds_driver_blocks(s, total) : rc_persistent_blocks(s, total);
     rc_prepare_launch(s, stream);
     SceneView v = rc_scene_view(s, blocks * bs);
     PersistArgs p = rc_persist_args(s, total, blocks * bs, stream);
     RC_HIP(hipEventRecord(s->ev0, stream));
-    if (lds) {
+    if (partial) {
+        rc_partial_driver_args(s, p);
+        if (!s->lds_attr_set[9]) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_view_factors_partial), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartialLdsBytes));
+            s->lds_attr_set[9] = true;
+        }
+        hipLaunchKernelGGL(k_view_factors_partial, dim3(blocks), dim3(kMidBlock), kPartialLdsBytes, stream, v, p, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
+                           ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags, order);
+    } else if (lds) {
         rc_lds_driver_args(s, p);
         if (!s->lds_attr_set[5]) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_view_factors_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));

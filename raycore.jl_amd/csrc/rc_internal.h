@@ -176,7 +176,7 @@ struct rc_scene {
     DevBuf<uint32_t> collide_counts;  // collide_instances' per-leaf counts / prefix sums (the reference's `cache`)
     DevBuf<uint2> contact_stage;
 
-    bool lds_attr_set[8] = {false, false, false, false, false, false, false, false};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any), illumination, view factors
+    bool lds_attr_set[10] = {};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any), illumination, view factors, [6, 7] kernel 6, [8, 9] the partial-LDS drivers
 
     TraceOptions opt;
 };

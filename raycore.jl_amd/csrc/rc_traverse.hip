@@ -461,6 +461,14 @@ bool rc_lds_driver_ok(rc_scene* s) {
 uint32_t rc_lds_driver_blocks(rc_scene* s, uint64_t n_items) {
     return (uint32_t)std::min<uint64_t>((n_items + kMidBlock - 1) / kMidBlock, (uint64_t)s->n_cus * 2);
 }
+// ... and the partial-LDS variants under the conditions of trace kernel 6: a larger top level with something to stage
+bool rc_partial_driver_ok(rc_scene* s) {
+    return s->opt.kernel != 3 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes && s->tlas_top_k + s->blas_top_k > 0 &&
+           (uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u < (1ull << 32);
+}
+void rc_partial_driver_args(rc_scene* s, rc::PersistArgs& p) {
+    p.tlas_k = s->tlas_top_k; p.blas_k = s->opt.blas_top ? s->blas_top_k : 0; p.lds_blas_base = s->tlas_top_k;
+}
 void rc_lds_driver_args(rc_scene* s, rc::PersistArgs& p) {
     if (s->opt.blas_top) { p.blas_k = s->blas_top_k; p.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
 }

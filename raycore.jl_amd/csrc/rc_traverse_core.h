@@ -698,5 +698,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads);  // rc_traverse.hip
 rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads, hipStream_t stream);
 bool rc_lds_driver_ok(rc_scene* s);
+bool rc_partial_driver_ok(rc_scene* s);
+void rc_partial_driver_args(rc_scene* s, rc::PersistArgs& p);
 uint32_t rc_lds_driver_blocks(rc_scene* s, uint64_t n_items);
 void rc_lds_driver_args(rc_scene* s, rc::PersistArgs& p);

@@ -574,6 +574,29 @@ def test_ray_grid_and_illumination_parity(rc, oracle):
         assert got.sum() == np.count_nonzero(metas <= len(got))  # metadata outside 1..N is dropped (src/kernels.jl:123)
 
 
+def test_drivers_on_a_large_top_level(rc, oracle):
+    """More than 256 instances: get_illumination and view_factors run the partial-LDS driver kernels (tops of the TLAS and of the single
+    BLAS staged, the shape of trace kernel 6); same counts as the oracle and as the plain 256-thread kernels."""
+    sc = rc.scenes
+    g = np.random.default_rng(5)
+    n_inst = 400
+    xf = np.tile(sc.IDENTITY3x4, (n_inst, 1)).astype(np.float32)
+    xf[:, [3, 7, 11]] = g.uniform(-6, 6, size=(n_inst, 3)).astype(np.float32)
+    verts = sc.fan_sphere(6, 4, radius=0.6)  # 36 triangles per instance
+    n = len(verts)
+    cfg = {"blas": [(verts, np.arange(1, n + 1, dtype=np.uint32))], "instances": [(1, xf.reshape(n_inst, 3, 4), np.arange(n_inst, dtype=np.uint32))]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    assert t.get_option("tlas_top_k") > 0 and t.get_option("blas_top_k") > 0
+    want_i = o.get_illumination((0.2, -0.1, -1.0), 300, nthreads=8)
+    want_v = o.view_factors(64, seed=99, nthreads=8)
+    for kernel in (-1, 3):
+        t.set_option("kernel", kernel)
+        assert np.array_equal(rc.get_illumination(t, (0.2, -0.1, -1.0), 300), want_i), kernel
+        assert np.array_equal(rc.view_factors(t, rays_per_triangle=64, seed=99), want_v), kernel
+    assert want_i.sum() > 1000 and want_v.sum() > 100
+    t.free()
+
+
 def test_illumination_hot_counters(rc, oracle):
     """Most rays land on two large triangles: the histogram's wave-level aggregation (equal targets among the lanes that finish
     together become one atomic) must still give the reference's counts exactly."""
