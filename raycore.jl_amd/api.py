@@ -145,6 +145,9 @@ class TLAS:
 
     def free(self):  # free!, :383-399
         if getattr(self, "_h", None):
+            for a in list(getattr(self, "_registered", {}).values()):  # arrays still pinned through host_register
+                lib().rc_host_unregister(self._h, ptr(a))
+            self._registered = {}
             lib().rc_scene_destroy(self._h)
             self._h = None
 
@@ -193,9 +196,11 @@ class TLAS:
         self._prims_cache = None
         return blas_id.value + 1
 
-    def add_mesh(self, verts, faces, normals, uvs=None, face_meta=None):
+    def add_mesh(self, verts, faces, normals, uvs=None, face_meta=None, metadata_per_face=None):
         """build_and_append_blas! on a decomposed mesh (:581-608): verts / normals (nv, 3), faces (nf, 3) 0-based, uvs (nv, 2) or
-        None, face_meta per vertex (as after expand_faceviews, :595) or None.  Returns the 1-based BLAS index."""
+        None, face_meta per vertex (as after expand_faceviews, :595) or None.  `metadata_per_face` (nf words) is the
+        TLAS(items, metadata_fn) convention instead -- metadata_fn(mesh_idx, face_idx) for every face (:2300-2306) -- which a per-vertex
+        array cannot carry when faces share their first vertex (the two triangles of a quad).  Returns the 1-based BLAS index."""
         v = np.ascontiguousarray(np.asarray(verts, dtype=np.float32).reshape(-1, 3))
         nrm = np.ascontiguousarray(np.asarray(normals, dtype=np.float32).reshape(-1, 3))
         f = np.ascontiguousarray(np.asarray(faces, dtype=np.uint32).reshape(-1, 3))
@@ -204,7 +209,15 @@ class TLAS:
         if len(nrm) != len(v) or (uv is not None and len(uv) != len(v)) or (fm is not None and len(fm) != len(v)):
             raise ValueError("normals / uvs / face_meta must have one entry per vertex")
         blas_id = C.c_uint32()
-        check(lib().rc_add_mesh(self._h, ptr(v), ptr(nrm), ptr(uv), len(v), ptr(f), len(f), ptr(fm), C.byref(blas_id)))
+        if metadata_per_face is not None:
+            if fm is not None:
+                raise ValueError("face_meta (per vertex) and metadata_per_face (per face) are alternatives")
+            pf = np.ascontiguousarray(metadata_per_face, dtype=np.uint32)
+            if len(pf) != len(f):
+                raise ValueError("metadata_per_face must have one entry per face")
+            check(lib().rc_add_mesh_face_metadata(self._h, ptr(v), ptr(nrm), ptr(uv), len(v), ptr(f), len(f), ptr(pf), C.byref(blas_id)))
+        else:
+            check(lib().rc_add_mesh(self._h, ptr(v), ptr(nrm), ptr(uv), len(v), ptr(f), len(f), ptr(fm), C.byref(blas_id)))
         self._prims_cache = None
         return blas_id.value + 1
 
@@ -402,13 +415,18 @@ class TLAS:
         return ms.value
 
     def host_register(self, array):
-        """Page-lock a numpy array (rays, a reused `out=` hit array, triangle soup) so the host-buffer calls move it by DMA at the full
-        PCIe rate; undo with host_unregister before the array is freed."""
+        """Page-lock a numpy array (rays, a reused `out=` hit array, triangle soup, a view-factor matrix) so the host-buffer calls move
+        it by DMA at the full PCIe rate; undo with host_unregister.  The accel keeps a reference to the array while it is registered (an
+        array collected while pinned would leave a stale pinned range behind); free() unregisters what is left."""
         check(lib().rc_host_register(self._h, ptr(array), array.nbytes))
+        if not hasattr(self, "_registered"):
+            self._registered = {}
+        self._registered[array.ctypes.data] = array
         return array
 
     def host_unregister(self, array):
         check(lib().rc_host_unregister(self._h, ptr(array)))
+        getattr(self, "_registered", {}).pop(array.ctypes.data, None)
 
     def intern_metadata(self, values):
         """Metadata words for `values`: the values themselves when they are all uint32-representable integers and the accel is still
@@ -617,7 +635,8 @@ RAYHIT_DT = np.dtype([("hit", "?"), ("point", "<f4", 3), ("metadata", "<u4")])  
 def hits_from_grid(accel, viewdir, grid_size=32):
     """hits_from_grid (src/kernels.jl:58-72): a grid_size x grid_size array of RayHit records (RAYHIT_DT, indexed [i, j] like
     the Julia Matrix); point = sum_mul(bary, prim.vertices) in the primitive's local space, metadata = prim.metadata
-    (a miss carries the zero triangle: point 0, metadata 0)."""
+    (a miss carries the zero triangle: point 0, metadata 0).  Always the one structured array: on an accel whose metadata type is
+    not UInt32 the `metadata` field holds the interned words, and `typed_hit_metadata(accel, hits)` maps them to the values."""
     t = _owner(accel)
     rays = generate_ray_grid(t._static, viewdir, grid_size)
     hits = t.trace(rays)
@@ -632,20 +651,24 @@ def hits_from_grid(accel, viewdir, grid_size=32):
         # sum_mul (src/math.jl:52): a[1]*b[1] + a[2]*b[2] + a[3]*b[3], left to right, in Float32
         out["point"][m] = (w[:, None] * p["v"][:, 0] + u[:, None] * p["v"][:, 1]) + v[:, None] * p["v"][:, 2]
         out["metadata"][m] = p["meta"]
-    out = out.reshape(grid_size, grid_size, order="F")
-    if t._meta_table is not None:  # RayHit{TMetadata}: the typed values ride along as an object array of the same shape
-        typed = np.empty(out.shape, dtype=object)
-        for idx in np.ndindex(out.shape):
-            typed[idx] = t.typed_metadata(out["metadata"][idx]) if out["hit"][idx] else None
-        return out, typed
-    return out
+    return out.reshape(grid_size, grid_size, order="F")
+
+
+def typed_hit_metadata(accel, hits):
+    """RayHit{TMetadata}.metadata for an accel with a non-UInt32 metadata type: an object array shaped like `hits` holding the values
+    the interned words stand for (None where the ray missed).  In UInt32 mode it is `hits["metadata"]` itself."""
+    t = _owner(accel)
+    if t._meta_table is None:
+        return hits["metadata"]
+    typed = np.empty(hits.shape, dtype=object)
+    for idx in np.ndindex(hits.shape):
+        typed[idx] = t.typed_metadata(hits["metadata"][idx]) if hits["hit"][idx] else None
+    return typed
 
 
 def get_centroid(accel, viewdir, grid_size=32):
     """get_centroid (src/kernels.jl:106-110): the hit points and their mean."""
     hits = hits_from_grid(accel, viewdir, grid_size)
-    if isinstance(hits, tuple):
-        hits = hits[0]
     pts = hits["point"][hits["hit"]]
     return pts, (pts.mean(axis=0) if len(pts) else np.full(3, np.nan, np.float32))
 

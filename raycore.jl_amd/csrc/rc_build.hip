@@ -167,7 +167,7 @@ __global__ void k_gather_u32(const uint32_t* in, const uint32_t* perm, uint32_t 
 
 // build_and_append_blas! after the mesh decomposition (src/instanced-bvh.jl:591-600): face i -> three vertices by index;
 // metadata = face_meta[first vertex of the face] (per-vertex after expand_faceviews, :595) or the face index.
-__global__ void k_expand_mesh(const float* verts, const uint32_t* indices, const uint32_t* vertex_meta, uint32_t nf, float* soup, uint32_t* meta) {
+__global__ void k_expand_mesh(const float* verts, const uint32_t* indices, const uint32_t* vertex_meta, bool meta_per_face, uint32_t nf, float* soup, uint32_t* meta) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nf) return;
     const uint32_t i0 = indices[3 * (size_t)i], i1 = indices[3 * (size_t)i + 1], i2 = indices[3 * (size_t)i + 2];
@@ -175,7 +175,8 @@ __global__ void k_expand_mesh(const float* verts, const uint32_t* indices, const
     o[0] = verts[3 * (size_t)i0]; o[1] = verts[3 * (size_t)i0 + 1]; o[2] = verts[3 * (size_t)i0 + 2];
     o[3] = verts[3 * (size_t)i1]; o[4] = verts[3 * (size_t)i1 + 1]; o[5] = verts[3 * (size_t)i1 + 2];
     o[6] = verts[3 * (size_t)i2]; o[7] = verts[3 * (size_t)i2 + 1]; o[8] = verts[3 * (size_t)i2 + 2];
-    meta[i] = vertex_meta ? vertex_meta[i0] : (i + 1);
+    // face_meta[first vertex of the face] (push! path, :595), or one word per face (TLAS(items, metadata_fn), :2300-2306), or the face index
+    meta[i] = vertex_meta ? vertex_meta[meta_per_face ? i : i0] : (i + 1);
 }
 
 // normals (9 floats) + uv (6 floats) of every primitive of one BLAS: build_triangle (:555-566).  Soup geometry has no mesh
@@ -692,9 +693,9 @@ uint32_t rc_ingest_faces(rc_scene* s, const float* d_verts, const uint32_t* d_me
     return last[0] + last[1];
 }
 
-void rc_expand_mesh(rc_scene* s, const float* d_verts, const uint32_t* d_indices, const uint32_t* d_vertex_meta, uint32_t nf, float* d_soup, uint32_t* d_meta) {
+void rc_expand_mesh(rc_scene* s, const float* d_verts, const uint32_t* d_indices, const uint32_t* d_vertex_meta, bool meta_per_face, uint32_t nf, float* d_soup, uint32_t* d_meta) {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_expand_mesh, dim3(grid_for(nf)), dim3(kBlock), 0, s->stream, d_verts, d_indices, d_vertex_meta, nf, d_soup, d_meta);
+    hipLaunchKernelGGL(k_expand_mesh, dim3(grid_for(nf)), dim3(kBlock), 0, s->stream, d_verts, d_indices, d_vertex_meta, meta_per_face, nf, d_soup, d_meta);
     RC_HIP(hipGetLastError());
 }
 
@@ -740,7 +741,7 @@ void rc_build_blas(rc_scene* s, uint32_t n, Blas& out, bool keep_face_map) {
     out.nodes.reserve(2 * (size_t)n - 1);
     out.n_prims = n;
     out.n_nodes = 2 * n - 1;
-    RC_HIP(hipEventRecord(s->ev0, s->stream));
+    rc_timing_scene_begin(s, s->stream);
     {
         const unsigned nb = std::min(grid_for(n), 1024u);
         s->bounds_partials.reserve((size_t)nb * 6);
@@ -757,12 +758,11 @@ void rc_build_blas(rc_scene* s, uint32_t n, Blas& out, bool keep_face_map) {
     emit_tree(s, out.nodes.p, n, s->range_tmp);
     hipLaunchKernelGGL(k_blas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, out.nodes.p, out.prims.p, n);
     run_refit(s, out.nodes.p, out.prims.p, n, 0, s->range_tmp);
-    RC_HIP(hipEventRecord(s->ev1, s->stream));
+    rc_timing_scene_end(s, s->stream);
     RcNode root;
     RC_HIP(hipMemcpyAsync(&root, out.nodes.p, sizeof(RcNode), hipMemcpyDeviceToHost, s->stream));
     RC_HIP(hipStreamSynchronize(s->stream));
     RC_HIP(hipGetLastError());
-    RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
     host_root_aabb(root, false, out.root_min, out.root_max);
 }
 

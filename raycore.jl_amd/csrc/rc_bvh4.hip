@@ -457,20 +457,18 @@ void rc_launch_trace4(rc_scene* s, const Blas& b, const RcRay* d_rays, RcHit* d_
     uint64_t want = (n + kBlock - 1) / kBlock, cap = (uint64_t)s->n_cus * 6;
     const uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     const uint32_t total_threads = blocks * kBlock;
-    rc_prepare_launch(s, stream);
+    RcLaunchGuard launch(s, stream);
     Trace4Args a;
     a.nodes = b.nodes4.p; a.n_nodes = b.n_nodes4; a.root_word = b.root_word4; a.n_prims = b.n_prims;
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
     if (n >= (1ull << 38)) throw RcError(1, "ray batches of 2^38 rays or more are not supported by the BVH4 kernels");
-    rc_claim_begin(s, stream, n, total_threads / 64u, a.claim);
+    rc_claim_fill(s, n, total_threads / 64u, a.claim);
     a.refill = (int)s->opt.refill;
     a.int_thr = (int)s->opt.sched_thr;
     a.overflow = s->cur_overflow; a.total_threads = total_threads;
     a.status = rc_status_word(s);
-    RC_HIP(hipEventRecord(s->ev0, stream));
+    launch.start();
     if (any_hit) hipLaunchKernelGGL((k_trace4<true, 24>), dim3(blocks), dim3(kBlock), 0, stream, a);
     else hipLaunchKernelGGL((k_trace4<false, 24>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    RC_HIP(hipEventRecord(s->ev1, stream));
-    RC_HIP(hipGetLastError());
-    rc_claim_commit(s, stream);
+    launch.finish();
 }

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -109,6 +110,34 @@ void check_status(rc_scene* s, hipStream_t stream) {
     }
 }
 
+// A staging context for one host-buffer trace call (CallCtx, rc_internal.h): the first one runs on the scene's own stream, the others
+// on streams of their own; a call that finds all kMaxCallCtx busy waits for one.
+struct CtxLease {
+    rc_scene* s;
+    CallCtx* c = nullptr;
+    explicit CtxLease(rc_scene* scene) : s(scene) {
+        std::unique_lock<std::mutex> lk(s->ctx_mu);
+        for (;;) {
+            for (auto& p : s->call_ctx) if (!p->busy) { c = p.get(); break; }
+            if (c) break;
+            if ((int)s->call_ctx.size() < rc_scene::kMaxCallCtx) {
+                std::unique_ptr<CallCtx> fresh(new CallCtx());
+                if (s->call_ctx.empty()) fresh->stream = s->stream;
+                else { RC_HIP(hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking)); fresh->own_stream = true; }
+                s->call_ctx.push_back(std::move(fresh));
+                c = s->call_ctx.back().get();
+                break;
+            }
+            s->ctx_cv.wait(lk);
+        }
+        c->busy = true;
+    }
+    ~CtxLease() {
+        { std::lock_guard<std::mutex> lk(s->ctx_mu); c->busy = false; }
+        s->ctx_cv.notify_one();
+    }
+};
+
 void export_nodes(rc_scene* s, const RcNode* d, uint32_t n, rc_bvh_node* out, uint32_t capacity, uint32_t* count) {
     if (count) *count = n;
     if (!out || n == 0) return;
@@ -137,7 +166,18 @@ template <typename T> void put_dev(FILE* f, const T* d, size_t n, std::vector<un
     put(f, tmp.data(), tmp.size());
 }
 // `check(host copy)` runs before the upload: a scene file is untrusted input, and the kernels index with what it holds
+void bad_file(const char* what);
+// bytes left between the read position and the end of the file: every count a header states is checked against it BEFORE anything is
+// allocated for it (a scene file is untrusted input; a forged count must not drive a multi-gigabyte allocation)
+size_t bytes_left(FILE* f) {
+    const long here = ftell(f);
+    if (here < 0 || fseek(f, 0, SEEK_END) != 0) bad_file("cannot seek");
+    const long end = ftell(f);
+    if (end < here || fseek(f, here, SEEK_SET) != 0) bad_file("cannot seek");
+    return (size_t)(end - here);
+}
 template <typename T, typename Check> void get_dev(FILE* f, DevBuf<T>& d, size_t n, std::vector<unsigned char>& tmp, Check&& check) {
+    if (n > bytes_left(f) / sizeof(T)) bad_file("truncated (an array is longer than the rest of the file)");
     d.reserve(n ? n : 1);
     if (!n) return;
     tmp.resize(n * sizeof(T));
@@ -146,6 +186,8 @@ template <typename T, typename Check> void get_dev(FILE* f, DevBuf<T>& d, size_t
     RC_HIP(hipMemcpy(d.p, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
 }
 template <typename T> void get_dev(FILE* f, DevBuf<T>& d, size_t n, std::vector<unsigned char>& tmp) { get_dev(f, d, n, tmp, [](const T*) {}); }
+}  // namespace
+namespace {
 void bad_file(const char* what) { throw RcError(RC_ERR_INVALID_ARGUMENT, std::string("scene file: ") + what); }
 }  // namespace
 
@@ -176,6 +218,14 @@ int rc_scene_create(int device, rc_scene** out) {
         RC_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         RC_HIP(hipEventCreate(&s->ev0));
         RC_HIP(hipEventCreate(&s->ev1));
+        static std::atomic<uint64_t> next_uid{1};
+        s->uid = next_uid.fetch_add(1);
+        // claim counters, status word and statistics start at zero, and are zero before anything can launch: a launch on any stream --
+        // or the replay of a captured one -- never meets uninitialised counters (a memset enqueued by the first launch would order only that launch's stream)
+        s->counters.reserve((size_t)kCounterSlots * kCounterSlotWords);
+        RC_HIP(hipMemsetAsync(s->counters.p, 0, sizeof(uint32_t) * (size_t)kCounterSlots * kCounterSlotWords, s->stream));
+        RC_HIP(hipStreamSynchronize(s->stream));
+        s->slots.assign(kCounterSlots + 1, rc_scene::LaunchSlot());
     });
     if (rc != RC_OK) { delete s; return rc; }
     *out = s;
@@ -188,8 +238,11 @@ int rc_scene_destroy(rc_scene* s) {
     (void)hipDeviceSynchronize();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    if (s->stream_switch_ev) (void)hipEventDestroy(s->stream_switch_ev);
-    for (auto& slot : s->claim_slots) if (slot.done) (void)hipEventDestroy(slot.done);
+    for (int i = 0; i < kCounterSlots && i < (int)s->slots.size(); ++i) {  // (the last entry aliases ev0 / ev1)
+        if (s->slots[i].t0) (void)hipEventDestroy(s->slots[i].t0);
+        if (s->slots[i].t1) (void)hipEventDestroy(s->slots[i].t1);
+    }
+    for (auto& c : s->call_ctx) if (c && c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return RC_OK;
@@ -238,8 +291,9 @@ int rc_add_blas_device(rc_scene* s, const float* d_verts, const uint32_t* d_meta
 }
 
 // build_and_append_blas! body for a decomposed mesh (src/instanced-bvh.jl:581-600): upload, expand by index, filter, build
+// face_meta: one word per VERTEX (read at each face's first vertex, :595) or, with meta_per_face, one word per FACE (:2300-2306)
 static void build_mesh_blas(rc_scene* s, const float* verts, const float* normals, const float* uvs, uint32_t nv, const uint32_t* indices, uint32_t nf,
-                            const uint32_t* face_meta, Blas& b) {
+                            const uint32_t* face_meta, bool meta_per_face, Blas& b) {
     if ((nv && (!verts || !normals)) || (nf && !indices)) throw RcError(RC_ERR_INVALID_ARGUMENT, "verts / normals / indices is NULL");
     for (size_t i = 0; i < 3 * (size_t)nf; ++i)
         if (indices[i] >= nv) throw RcError(RC_ERR_INVALID_ARGUMENT, "face index out of range");
@@ -257,14 +311,15 @@ static void build_mesh_blas(rc_scene* s, const float* verts, const float* normal
         RC_HIP(hipMemcpyAsync(b.m_uvs.p, uvs, sizeof(float) * 2 * (size_t)nv, hipMemcpyHostToDevice, s->stream));
         b.has_uvs = true;
     }
-    if (face_meta && nv) {
-        d_vmeta.reserve(nv);
-        RC_HIP(hipMemcpyAsync(d_vmeta.p, face_meta, sizeof(uint32_t) * (size_t)nv, hipMemcpyHostToDevice, s->stream));
+    const size_t n_meta = meta_per_face ? nf : nv;
+    if (face_meta && n_meta) {
+        d_vmeta.reserve(n_meta);
+        RC_HIP(hipMemcpyAsync(d_vmeta.p, face_meta, sizeof(uint32_t) * n_meta, hipMemcpyHostToDevice, s->stream));
     }
     if (nf) RC_HIP(hipMemcpyAsync(b.m_indices.p, indices, sizeof(uint32_t) * 3 * (size_t)nf, hipMemcpyHostToDevice, s->stream));
     s->vert_stage.reserve(9 * (size_t)(nf ? nf : 1));
     s->meta_stage.reserve(nf ? nf : 1);
-    rc_expand_mesh(s, d_verts.p, b.m_indices.p, face_meta ? d_vmeta.p : nullptr, nf, s->vert_stage.p, s->meta_stage.p);
+    rc_expand_mesh(s, d_verts.p, b.m_indices.p, face_meta && n_meta ? d_vmeta.p : nullptr, meta_per_face, nf, s->vert_stage.p, s->meta_stage.p);
     const uint32_t valid = rc_ingest_faces(s, s->vert_stage.p, s->meta_stage.p, nf, true);
     if (valid == 0) throw RcError(RC_ERR_EMPTY_GEOMETRY, "Geometry has no valid triangles");  // :601
     rc_build_blas(s, valid, b, true);  // synchronises the stream: the temporaries above may go
@@ -278,7 +333,19 @@ int rc_add_mesh(rc_scene* s, const float* verts, const float* normals, const flo
     return guarded([&] {
         use_device(s);
         Blas b;
-        build_mesh_blas(s, verts, normals, uvs, nv, indices, nf, face_meta, b);
+        build_mesh_blas(s, verts, normals, uvs, nv, indices, nf, face_meta, false, b);
+        s->blas.push_back(std::move(b));
+        if (blas_id) *blas_id = (uint32_t)s->blas.size() - 1;
+    });
+}
+
+int rc_add_mesh_face_metadata(rc_scene* s, const float* verts, const float* normals, const float* uvs, uint32_t nv, const uint32_t* indices, uint32_t nf,
+                              const uint32_t* metadata_per_face, uint32_t* blas_id) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        Blas b;
+        build_mesh_blas(s, verts, normals, uvs, nv, indices, nf, metadata_per_face, true, b);
         s->blas.push_back(std::move(b));
         if (blas_id) *blas_id = (uint32_t)s->blas.size() - 1;
     });
@@ -294,7 +361,7 @@ int rc_update_geometry_mesh(rc_scene* s, uint32_t handle, const float* verts, co
         if (r.count == 0) throw RcError(RC_ERR_INVALID_HANDLE, "Handle has no instances");
         const uint32_t blas_idx = s->instances[r.first].blas_index;  // :814-816
         Blas b;
-        build_mesh_blas(s, verts, normals, uvs, nv, indices, nf, face_meta, b);
+        build_mesh_blas(s, verts, normals, uvs, nv, indices, nf, face_meta, false, b);
         s->blas[blas_idx - 1] = std::move(b);
         s->dirty = true;
     });
@@ -549,12 +616,12 @@ static void populate_pages(void* p, size_t bytes) {
 // (16 MiB each way), each transfer direction on its own host thread and non-blocking stream, so the two directions of the link and
 // the kernel overlap: a 4 M-ray batch takes about one direction's transfer time (2.4 ms at 56 GB/s) plus one chunk's latency instead
 // of upload + kernel + download back to back.  The chunks are traced by the same kernels, so the results do not change.
-static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
+static void trace_host_pipelined(rc_scene* s, CallCtx& cx, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
     // at most 48 chunks of at least 512 Ki rays
     const uint64_t kChunk = std::max<uint64_t>(1ull << 19, ((n + 47) / 48 + 63) & ~63ull);
     const uint64_t n_chunks = (n + kChunk - 1) / kChunk;
-    s->ray_stage.reserve(n);
-    s->hit_stage.reserve(n);
+    cx.rays.reserve(n);
+    cx.hits.reserve(n);
     populate_pages(hits, sizeof(RcHit) * n);
     std::vector<hipEvent_t> ev_begin(n_chunks), ev_end(n_chunks);
     for (uint64_t c = 0; c < n_chunks; ++c) { RC_HIP(hipEventCreate(&ev_begin[c])); RC_HIP(hipEventCreate(&ev_end[c])); }
@@ -568,7 +635,7 @@ static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, 
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         for (uint64_t c = 0; c < n_chunks && e == hipSuccess && !abort_all.load(); ++c) {
             uint64_t off, cnt; span(c, off, cnt);
-            e = hipMemcpyAsync(s->ray_stage.p + off, reinterpret_cast<const RcRay*>(rays) + off, sizeof(RcRay) * cnt, hipMemcpyHostToDevice, st);
+            e = hipMemcpyAsync(cx.rays.p + off, reinterpret_cast<const RcRay*>(rays) + off, sizeof(RcRay) * cnt, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e == hipSuccess) uploaded.store(c + 1, std::memory_order_release);
         }
@@ -584,7 +651,7 @@ static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, 
             if (launched.load(std::memory_order_acquire) <= c) break;  // aborted before this chunk was launched
             uint64_t off, cnt; span(c, off, cnt);
             e = hipEventSynchronize(ev_end[c]);
-            if (e == hipSuccess) e = hipMemcpyAsync(reinterpret_cast<RcHit*>(hits) + off, s->hit_stage.p + off, sizeof(RcHit) * cnt, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(reinterpret_cast<RcHit*>(hits) + off, cx.hits.p + off, sizeof(RcHit) * cnt, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
         }
         if (e != hipSuccess) { copy_error.store((int)e); abort_all.store(true); }
@@ -597,9 +664,9 @@ static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, 
             while (uploaded.load(std::memory_order_acquire) <= c && !abort_all.load()) std::this_thread::yield();
             if (abort_all.load()) break;
             uint64_t off, cnt; span(c, off, cnt);
-            RC_HIP(hipEventRecord(ev_begin[c], s->stream));
-            rc_launch_trace(s, s->ray_stage.p + off, s->hit_stage.p + off, cnt, any, s->stream);
-            RC_HIP(hipEventRecord(ev_end[c], s->stream));
+            RC_HIP(hipEventRecord(ev_begin[c], cx.stream));
+            rc_launch_trace(s, cx.rays.p + off, cx.hits.p + off, cnt, any, cx.stream);
+            RC_HIP(hipEventRecord(ev_end[c], cx.stream));
             launched.store(c + 1, std::memory_order_release);
         }
     } catch (const RcError& e) {
@@ -607,7 +674,7 @@ static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, 
     }
     up.join();
     down.join();
-    (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamSynchronize(cx.stream);
     float total_ms = 0.f;
     uint32_t overflow = 0;
     const uint64_t done = launched.load();
@@ -619,8 +686,7 @@ static void trace_host_pipelined(rc_scene* s, const rc_ray* rays, rc_hit* hits, 
         (void)hipEventDestroy(ev_begin[c]); (void)hipEventDestroy(ev_end[c]);
     }
     if (s->counters.p && hipMemcpy(&overflow, rc_status_word(s), 4, hipMemcpyDeviceToHost) == hipSuccess && overflow) (void)hipMemset(rc_status_word(s), 0, 4);
-    s->last_ms = total_ms;  // the chunks' kernel time, transfers excluded (as for the single-launch path)
-    s->pipelined_ms = total_ms; s->pipelined_seq = s->launch_seq;
+    rc_timing_fixed(s, total_ms);  // the chunks' kernel time, transfers excluded (as for the single-launch path)
     if (launch_code) throw RcError(launch_code, launch_error);
     if (copy_error.load()) throw RcError(RC_ERR_HIP, std::string("host-buffer transfer failed: ") + hipGetErrorString((hipError_t)copy_error.load()));
     if (overflow) throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels)");
@@ -633,15 +699,16 @@ static int trace_host(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n,
         require_synced(s);
         if (n == 0) return;
         if (!rays || !hits) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
-        if (n >= 3 * (1ull << 20) && s->opt.host_pipeline) { trace_host_pipelined(s, rays, hits, n, any); return; }
-        s->ray_stage.reserve(n);
-        s->hit_stage.reserve(n);
+        CtxLease lease(s);  // this call's own stream and staging buffers: host-buffer trace calls are re-entrant on a synced scene
+        CallCtx& cx = *lease.c;
+        if (n >= 3 * (1ull << 20) && s->opt.host_pipeline) { trace_host_pipelined(s, cx, rays, hits, n, any); return; }
+        cx.rays.reserve(n);
+        cx.hits.reserve(n);
         if (n >= (1ull << 16)) populate_pages(hits, sizeof(RcHit) * n);
-        RC_HIP(hipMemcpyAsync(s->ray_stage.p, rays, sizeof(RcRay) * n, hipMemcpyHostToDevice, s->stream));
-        rc_launch_trace(s, s->ray_stage.p, s->hit_stage.p, n, any, s->stream);
-        RC_HIP(hipMemcpyAsync(hits, s->hit_stage.p, sizeof(RcHit) * n, hipMemcpyDeviceToHost, s->stream));
-        check_status(s, s->stream);
-        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
+        RC_HIP(hipMemcpyAsync(cx.rays.p, rays, sizeof(RcRay) * n, hipMemcpyHostToDevice, cx.stream));
+        rc_launch_trace(s, cx.rays.p, cx.hits.p, n, any, cx.stream);
+        RC_HIP(hipMemcpyAsync(hits, cx.hits.p, sizeof(RcHit) * n, hipMemcpyDeviceToHost, cx.stream));
+        check_status(s, cx.stream);
     });
 }
 int rc_trace_closest(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace_host(s, rays, hits, n, 0); }
@@ -676,11 +743,10 @@ int rc_blas4_build(rc_scene* s, uint32_t blas_id, uint32_t* n_nodes) {
         use_device(s);
         if (blas_id >= s->blas.size()) throw RcError(RC_ERR_INVALID_ARGUMENT, "blas_id out of range");
         Blas& b = s->blas[blas_id];
-        RC_HIP(hipEventRecord(s->ev0, s->stream));
+        rc_timing_scene_begin(s, s->stream);
         rc_build_blas4(s, b);
-        RC_HIP(hipEventRecord(s->ev1, s->stream));
+        rc_timing_scene_end(s, s->stream);
         RC_HIP(hipStreamSynchronize(s->stream));
-        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
         if (n_nodes) *n_nodes = b.n_nodes4;
     });
 }
@@ -704,13 +770,14 @@ static int trace4_host(rc_scene* s, uint32_t blas_id, const rc_ray* rays, rc_hit
         Blas& b = blas4_of(s, blas_id);
         if (n == 0) return;
         if (!rays || !hits) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
-        s->ray_stage.reserve(n);
-        s->hit_stage.reserve(n);
-        RC_HIP(hipMemcpyAsync(s->ray_stage.p, rays, sizeof(RcRay) * n, hipMemcpyHostToDevice, s->stream));
-        rc_launch_trace4(s, b, s->ray_stage.p, s->hit_stage.p, n, any, s->stream);
-        RC_HIP(hipMemcpyAsync(hits, s->hit_stage.p, sizeof(RcHit) * n, hipMemcpyDeviceToHost, s->stream));
-        check_status(s, s->stream);
-        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
+        CtxLease lease(s);
+        CallCtx& cx = *lease.c;
+        cx.rays.reserve(n);
+        cx.hits.reserve(n);
+        RC_HIP(hipMemcpyAsync(cx.rays.p, rays, sizeof(RcRay) * n, hipMemcpyHostToDevice, cx.stream));
+        rc_launch_trace4(s, b, cx.rays.p, cx.hits.p, n, any, cx.stream);
+        RC_HIP(hipMemcpyAsync(hits, cx.hits.p, sizeof(RcHit) * n, hipMemcpyDeviceToHost, cx.stream));
+        check_status(s, cx.stream);
     });
 }
 int rc_trace_closest4(rc_scene* s, uint32_t blas_id, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace4_host(s, blas_id, rays, hits, n, 0); }
@@ -746,6 +813,7 @@ int rc_collide_instances(rc_scene* s, rc_contact_pair* out, uint64_t capacity, u
     return guarded([&] {
         use_device(s);
         require_synced(s);
+        std::lock_guard<std::mutex> one_at_a_time(s->host_call_mu);
         uint64_t total = rc_collide_instances_launch(s, nullptr, 0, s->stream);
         if (count) *count = total;
         if (!out || total == 0) return;
@@ -754,7 +822,6 @@ int rc_collide_instances(rc_scene* s, rc_contact_pair* out, uint64_t capacity, u
         total = rc_collide_instances_launch(s, s->contact_stage.p, total, s->stream);
         RC_HIP(hipMemcpyAsync(out, s->contact_stage.p, sizeof(uint2) * total, hipMemcpyDeviceToHost, s->stream));
         check_status(s, s->stream);
-        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
     });
 }
 
@@ -865,10 +932,13 @@ int rc_scene_load(int device, const char* path, rc_scene** out) {
         if (memcmp(magic, kSceneMagic, 8) != 0 || hdr[0] != kSceneVersion) throw RcError(RC_ERR_INVALID_ARGUMENT, "not a raycore-mi355x scene file (or wrong version)");
         const uint32_t n_blas = hdr[1], n_inst = hdr[2], n_handles = hdr[4];
         s->next_handle_id = hdr[3];
+        if ((size_t)n_handles > bytes_left(fc.f) / 12 || (size_t)n_inst > bytes_left(fc.f) / sizeof(RcInstanceDesc) || (size_t)n_blas > bytes_left(fc.f) / 48)
+            bad_file("truncated (the header's counts exceed the file)");
         for (uint32_t i = 0; i < n_handles; ++i) {
             uint32_t rec[3];
             get(fc.f, rec, sizeof(rec));
             if ((uint64_t)rec[1] + rec[2] > n_inst) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene file: handle range out of bounds");
+            if (rec[0] == 0 || rec[0] >= s->next_handle_id || s->handle_to_range.count(rec[0])) bad_file("handle id out of range or repeated");
             s->handle_to_range[rec[0]] = HandleRange{rec[1], rec[2]};
         }
         s->instances.resize(n_inst);
@@ -886,13 +956,24 @@ int rc_scene_load(int device, const char* path, rc_scene** out) {
             get(fc.f, b.root_max, 12);
             get_dev(fc.f, b.prims, b.n_prims, tmp);
             get_dev(fc.f, b.nodes, b.n_nodes, tmp, [&](const RcNode* nd) {  // internal nodes 1..n-1 point at nodes, leaves n..2n-1 at a sorted primitive
+                // The links must form a TREE: a traversal pushes one child and descends into the other, so a node that points at
+                // itself or at an ancestor would make a ray loop for ever (the lane stack stops growing at 128 entries, the descent
+                // does not stop) -- a hung GPU.  With 2n - 1 nodes, 2(n - 1) child links, every non-root node referenced exactly once
+                // and the root never, every node is reached from the root along exactly one finite path.
+                std::vector<unsigned char> refs(b.n_nodes, 0);
                 for (uint32_t i = 0; i < b.n_nodes; ++i) {
                     const bool leaf = nd[i].child0 == RC_INVALID_NODE;
                     if (leaf != (i + 1 >= b.n_prims)) bad_file("node kinds do not follow the LBVH numbering");
                     if (leaf ? (nd[i].child1 < 1 || nd[i].child1 > b.n_prims)
                              : (nd[i].child0 < 1 || nd[i].child0 > b.n_nodes || nd[i].child1 < 1 || nd[i].child1 > b.n_nodes))
                         bad_file("node child index out of range");
+                    if (!leaf)
+                        for (uint32_t c : {nd[i].child0, nd[i].child1})
+                            if (++refs[c - 1] > 1) bad_file("node links do not form a tree (a node has two parents)");
                 }
+                if (refs[0] != 0) bad_file("node links do not form a tree (the root is somebody's child)");
+                for (uint32_t i = 1; i < b.n_nodes; ++i)
+                    if (refs[i] != 1) bad_file("node links do not form a tree (an unreferenced node)");
             });
             if (b.has_attrs) {
                 get_dev(fc.f, b.m_normals, 3 * (size_t)b.n_mesh_verts, tmp);
@@ -930,9 +1011,9 @@ int rc_refit_device(rc_scene* s, int recompute_inverse) {
     return guarded([&] {
         use_device(s);
         require_synced(s);
-        RC_HIP(hipEventRecord(s->ev0, s->stream));
+        rc_timing_scene_begin(s, s->stream);
         rc_refit_tlas(s, true, recompute_inverse != 0);
-        RC_HIP(hipEventRecord(s->ev1, s->stream));
+        rc_timing_scene_end(s, s->stream);
     });
 }
 
@@ -952,6 +1033,8 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (k == "timeline_ptr") s->opt.timeline_ptr = value;  // dev instrumentation: the caller owns the buffer and its size (8 x u64 per wave of the launch)
     else if (k == "debug_set_overflow") {  // test hook: raise the sticky stack-overflow word as a kernel would (no LBVH is deep enough to do it for real)
+        const char* hooks = getenv("RC_ENABLE_DEBUG_HOOKS");  // not part of the product's interface: only a process that asks for the hooks gets them
+        if (!hooks || hooks[0] != '1') return fail(RC_ERR_INVALID_ARGUMENT, "unknown option debug_set_overflow (test hook: set RC_ENABLE_DEBUG_HOOKS=1)");
         if (!s->counters.p) return fail(RC_ERR_INVALID_ARGUMENT, "debug_set_overflow: no launch has run on this scene yet");
         const uint32_t one = value ? 1u : 0u;
         (void)hipSetDevice(s->device);
@@ -1027,13 +1110,13 @@ int rc_get_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, floa
     return guarded([&] {
         use_device(s);
         require_synced(s);
+        std::lock_guard<std::mutex> one_at_a_time(s->host_call_mu);
         uint32_t np = s->n_flat_prims;
         s->f32_stage.reserve(np ? np : 1);
         RC_HIP(hipMemsetAsync(s->f32_stage.p, 0, sizeof(float) * (np ? np : 1), s->stream));
         rc_launch_illumination(s, viewdir, grid, 0, (uint64_t)grid * grid, s->f32_stage.p, s->stream);
         if (np) RC_HIP(hipMemcpyAsync(out_counts, s->f32_stage.p, sizeof(float) * np, hipMemcpyDeviceToHost, s->stream));
         check_status(s, s->stream);
-        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
     });
 }
 
@@ -1060,7 +1143,6 @@ int rc_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint
         rc_launch_view_factors(s, rays_per_triangle, seed, 0, (uint32_t)np, 0, rays_per_triangle, m.p, 1, np, 0, 0, s->stream);
         RC_HIP(hipMemcpyAsync(out_matrix, m.p, sizeof(uint32_t) * np * np, hipMemcpyDeviceToHost, s->stream));
         check_status(s, s->stream);
-        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
     });
 }
 
@@ -1122,10 +1204,7 @@ int rc_last_kernel_ms(rc_scene* s, float* ms) {
     if (!s || !ms) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {
         use_device(s);
-        if (s->pipelined_seq == s->launch_seq && s->launch_seq != 0) { *ms = s->pipelined_ms; return; }  // last call was a chunked host-buffer trace
-        RC_HIP(hipEventSynchronize(s->ev1));
-        RC_HIP(hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1));
-        *ms = s->last_ms;
+        *ms = rc_timing_read(s);
     });
 }
 

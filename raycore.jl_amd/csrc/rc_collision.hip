@@ -69,10 +69,10 @@ uint64_t rc_collide_instances_launch(rc_scene* s, uint2* d_out, uint64_t capacit
     const uint32_t n = s->n_static_instances;
     if (n == 0) return 0;
     s->collide_counts.reserve(n);
-    rc_prepare_launch(s, stream);
+    RcLaunchGuard launch(s, stream);  // (the scratch below is the scene's: collision queries on one scene are one at a time anyway)
     uint32_t* status = rc_status_word(s);
     const uint32_t blocks = (n + 127) / 128;
-    RC_HIP(hipEventRecord(s->ev0, stream));
+    launch.start();
     hipLaunchKernelGGL((k_collide<false>), dim3(blocks), dim3(128), 0, stream, s->tlas_nodes.p, n, s->collide_counts.p, (uint2*)nullptr, status);
     size_t tmp = 0;
     RC_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp, s->collide_counts.p, s->collide_counts.p, (int)n, stream));
@@ -85,7 +85,6 @@ uint64_t rc_collide_instances_launch(rc_scene* s, uint2* d_out, uint64_t capacit
         if (capacity < total) throw RcError(1, "contact buffer too small: need " + std::to_string(total) + " pairs");
         hipLaunchKernelGGL((k_collide<true>), dim3(blocks), dim3(128), 0, stream, s->tlas_nodes.p, n, s->collide_counts.p, d_out, status);
     }
-    RC_HIP(hipEventRecord(s->ev1, stream));
-    RC_HIP(hipGetLastError());
+    launch.finish();
     return total;
 }

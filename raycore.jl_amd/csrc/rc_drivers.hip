@@ -448,10 +448,10 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
     const bool lds = partial || rc_lds_driver_ok(s);
     const uint32_t bs = lds ? (uint32_t)kMidBlock : (uint32_t)kBlock;
     uint32_t blocks = lds ? rc_lds_driver_blocks(s, ray_end - ray_begin) : rc_persistent_blocks(s, ray_end - ray_begin);
-    rc_prepare_launch(s, stream);
+    RcLaunchGuard launch(s, stream);
     SceneView v = rc_scene_view(s, blocks * bs);
-    PersistArgs p = rc_persist_args(s, ray_end - ray_begin, blocks * bs, stream);
-    RC_HIP(hipEventRecord(s->ev0, stream));
+    PersistArgs p = rc_persist_args(s, ray_end - ray_begin, blocks * bs);
+    launch.start();
     if (partial) {
         rc_partial_driver_args(s, p);
         if (!s->lds_attr_set[8]) {
@@ -468,9 +468,7 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
         hipLaunchKernelGGL(k_illumination_lds, dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, v, p, g, ray_begin, d_counts);
     } else
     hipLaunchKernelGGL(k_illumination, dim3(blocks), dim3(kBlock), 0, stream, v, p, g, ray_begin, d_counts);
-    RC_HIP(hipEventRecord(s->ev1, stream));
-    RC_HIP(hipGetLastError());
-    rc_claim_commit(s, stream);
+    launch.finish();
 }
 
 void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end,
@@ -481,6 +479,7 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     if (src_begin >= src_end || ray_begin >= ray_end) return;
     check_buffer_range(s);
     uint64_t total = (uint64_t)(src_end - src_begin) * (ray_end - ray_begin);
+    RcLaunchGuard launch(s, stream);  // also covers the one-off construction of the metadata order below
     const uint32_t* order = nullptr;
     if (flags & 2u) {  // RC_VF_SOURCES_BY_METADATA: the flat primitives' indices sorted by (metadata, index), cached until the next rebuild
         if (!s->vf_order_valid) {
@@ -500,10 +499,9 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     const bool lds = partial || rc_lds_driver_ok(s);
     const uint32_t bs = lds ? (uint32_t)kMidBlock : (uint32_t)kBlock;
     uint32_t blocks = lds ? rc_lds_driver_blocks(s, total) : rc_persistent_blocks(s, total);
-    rc_prepare_launch(s, stream);
     SceneView v = rc_scene_view(s, blocks * bs);
-    PersistArgs p = rc_persist_args(s, total, blocks * bs, stream);
-    RC_HIP(hipEventRecord(s->ev0, stream));
+    PersistArgs p = rc_persist_args(s, total, blocks * bs);
+    launch.start();
     if (partial) {
         rc_partial_driver_args(s, p);
         if (!s->lds_attr_set[9]) {
@@ -523,9 +521,7 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     } else
     hipLaunchKernelGGL(k_view_factors, dim3(blocks), dim3(kBlock), 0, stream, v, p, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
                        ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags, order);
-    RC_HIP(hipEventRecord(s->ev1, stream));
-    RC_HIP(hipGetLastError());
-    rc_claim_commit(s, stream);
+    launch.finish();
 }
 
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream) {

@@ -2,7 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -99,14 +102,32 @@ struct TraceOptions {
     int64_t timeline_ptr = 0;  // dev: device address of 8 x u64 per wave (n_cus x 24 waves) that kernel 5 fills with its waves' event times; 0 = off
 };
 
+// Where the duration of an operation can be read back (rc_last_kernel_ms): the event pair of a launch slot (valid while the slot has not
+// been reused: `seq`), the scene's own pair (slot kSceneTimingSlot: builds, refits, BVH4 collapse), or a value computed by the call
+// itself (slot -1: the chunked host-buffer trace sums its chunks' kernel times).
+struct TimingRef {
+    int slot = -2;  // -2 = nothing timed yet
+    uint64_t seq = 0;
+    float fixed_ms = 0.f;
+};
+
+// Staging of one host-buffer trace call in flight (rc_trace_closest / rc_trace_any / rc_trace_*4): its own stream and device copies of
+// the caller's rays and hits, so that calls from several host threads on one synced scene do not share anything (SURVEY.md 8b:
+// "trace calls are re-entrant on a synced scene"; the reference's drivers call closest_hit from Threads.@threads, src/kernels.jl:64,82).
+struct CallCtx {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool busy = false;
+    DevBuf<RcRay> rays;
+    DevBuf<RcHit> hits;
+};
+
 struct rc_scene {
     int device = 0;
     int n_cus = 0;
+    uint64_t uid = 0;                  // process-unique (a destroyed scene's address may be reused; thread-local timing references name the uid)
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float last_ms = 0.f;
-    float pipelined_ms = 0.f;          // kernel time of the last chunked host-buffer trace, valid while pipelined_seq == launch_seq
-    uint64_t pipelined_seq = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // the scene's own timing pair (LaunchSlot kSceneTimingSlot)
 
     // mutable TLAS state (src/instanced-bvh.jl:261-310)
     std::vector<Blas> blas;
@@ -144,23 +165,38 @@ struct rc_scene {
     DevBuf<uint4> range_tmp;    // compact topology of the BLAS being built (k_topology -> k_refit): per internal node its sorted-leaf range, child0, parent; then one parent word per leaf
     DevBuf<uint4> tlas_ranges;  // same for the TLAS; kept, because refit_tlas! reuses the topology
     DevBuf<RcPrim> prim_tmp;
+    // ---- launch bookkeeping: everything below is touched only with launch_mu held (RcLaunchGuard, rc_traverse.hip) ----
+    // The ENQUEUE of launches on one scene is serialised (microseconds); the kernels themselves overlap freely on their streams.
+    std::mutex launch_mu;
     // global spill areas of the traversal stacks: one per stream that has launched on this scene (launches on one stream are
-    // ordered and share theirs; launches on different streams may overlap and must not), at most kMaxOverflowRegions (a ninth stream waits for the oldest)
+    // ordered and share theirs; launches on different streams may overlap and must not), at most kMaxOverflowRegions (a ninth stream
+    // waits for the oldest unpinned region's stream and takes it over).  A region used by a launch that was captured into a hipGraph is
+    // pinned: the graph keeps its address.
     static constexpr int kMaxOverflowRegions = 8;  // each is allocated on first use by a new stream
-    std::vector<std::pair<hipStream_t, DevBuf<uint32_t>>> overflow_regions;
-    uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared (rc_prepare_launch)
-    DevBuf<uint32_t> counters;        // kCounterSlots slots of claim counters (self-resetting, rc_claim_chunk), the sticky status word, dev statistics
-    uint64_t launch_seq = 0;
-    struct ClaimSlot {                // ordering of launches that share a slot of chunk counters (rc_claim_begin / rc_claim_commit, rc_traverse.hip)
-        hipEvent_t done = nullptr;    // recorded after the slot's last launch once the scene has seen more than one stream
-        bool has_event = false;
+    struct OverflowRegion { hipStream_t stream = nullptr; bool pinned = false; DevBuf<uint32_t> buf; };
+    std::vector<OverflowRegion> overflow_regions;
+    uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared
+    DevBuf<uint32_t> counters;        // kCounterSlots slots of claim counters (self-resetting, rc_claim_chunk), the sticky status word, dev statistics; zeroed at rc_scene_create
+    uint64_t launch_seq = 0;          // eager launches so far; slot = launch_seq % kEagerSlots
+    uint64_t graph_seq = 0;           // captured launches so far; slot = kEagerSlots + graph_seq % (kCounterSlots - kEagerSlots)
+    int cur_slot = 0;                 // slot of the launch being prepared
+    struct LaunchSlot {               // per counter slot: the events of its latest launch
+        hipEvent_t t0 = nullptr, t1 = nullptr;  // timing pair; t1 also orders the slot's next user when that one runs on another stream
+        hipStream_t stream = nullptr;
+        bool recorded = false;
+        uint64_t seq = 0;
     };
-    std::vector<ClaimSlot> claim_slots;
-    hipStream_t last_launch_stream = nullptr;
-    bool any_launch = false, multi_stream = false;
-    hipEvent_t stream_switch_ev = nullptr;
-    DevBuf<RcRay> ray_stage;
-    DevBuf<RcHit> hit_stage;
+    std::vector<LaunchSlot> slots;    // kCounterSlots + 1: the last entry is the scene's own pair (ev0 / ev1)
+    uint64_t timing_seq = 0;
+    TimingRef last_timing;            // most recent timed operation on the scene by any thread
+
+    // host-buffer trace calls in flight (ctx_mu): a small pool of staging contexts; a call beyond kMaxCallCtx waits for one to come free
+    static constexpr int kMaxCallCtx = 4;
+    std::mutex ctx_mu;
+    std::condition_variable ctx_cv;
+    std::vector<std::unique_ptr<CallCtx>> call_ctx;
+    std::mutex host_call_mu;          // the other host-buffer entry points (illumination, view factors, collisions, exports) run one at a time
+
     DevBuf<float> f32_stage;
     DevBuf<float> vert_stage;
     DevBuf<uint32_t> meta_stage;
@@ -184,7 +220,7 @@ struct rc_scene {
 // rc_build.hip
 uint32_t rc_ingest_faces(rc_scene* s, const float* d_verts, const uint32_t* d_meta, uint32_t n, bool keep_face_map = false);  // -> s->prim_tmp (+ s->slot_face)
 void rc_build_blas(rc_scene* s, uint32_t n, Blas& out, bool keep_face_map = false);  // builds from s->prim_tmp
-void rc_expand_mesh(rc_scene* s, const float* d_verts, const uint32_t* d_indices, const uint32_t* d_vertex_meta, uint32_t nf, float* d_soup, uint32_t* d_meta);
+void rc_expand_mesh(rc_scene* s, const float* d_verts, const uint32_t* d_indices, const uint32_t* d_vertex_meta, bool meta_per_face, uint32_t nf, float* d_soup, uint32_t* d_meta);
 void rc_ensure_flat_attrs(rc_scene* s);  // fills s->flat_attrs for the current flat primitive array
 void rc_launch_export_triangles(rc_scene* s, void* d_out, hipStream_t stream);  // 136-byte Triangle{UInt32} records
 void rc_launch_reflection_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float bias, RcRay* d_out, hipStream_t stream);
@@ -218,24 +254,41 @@ void rc_launch_compact_hits(rc_scene* s, const RcHit* d_hits, uint64_t n, uint32
 
 // rc_traverse.hip helpers shared with rc_drivers.hip
 namespace rc { struct SceneView; struct RcClaim; }
-void rc_prepare_launch(rc_scene* s, hipStream_t stream);
-// Claim bookkeeping of a persistent launch: rc_claim_begin fills the kernel's RcClaim for the counter slot this launch uses (and
-// orders the launch behind the slot's previous user when that one ran on another stream); rc_claim_commit, called once the launch
-// has been enqueued, leaves the event a later user of the slot on another stream waits for.
-void rc_claim_begin(rc_scene* s, hipStream_t stream, uint64_t n_items, uint32_t total_waves, rc::RcClaim& out);
-void rc_claim_commit(rc_scene* s, hipStream_t stream);
-// One slot of chunk counters per launch, rotated over kCounterSlots, so that launches of one scene in flight on different streams
-// never share a counter: from word kShardBase of a slot on, kClaimShards counters kShardStrideWords apart.  A returning atomic on
+// One slot of chunk counters per launch, so that launches of one scene in flight on different streams never share a counter: from word
+// kShardBase of a slot on, kClaimShards counters kShardStrideWords apart.  Eager launches rotate over slots 0 .. kEagerSlots - 1 (a
+// launch that reuses a slot from another stream first waits for the event its previous user left there); launches that are being
+// captured into a hipGraph rotate over the remaining slots, which eager launches never touch -- a graph bakes its slot in, and a
+// replay must not meet an eager launch on the same counters.  A returning atomic on
 // ONE address costs 12.6 ns on MI355X however many waves issue it (tools/atomic_probe.hip): 6144 waves claiming their first rays
 // wait up to 77 us, and the 32 768 claims of a 4 M-ray launch keep a single counter busy for 0.41 ms.  Sixteen counters 256 bytes
 // apart run at 0.9 ns per claim.  The counters zero themselves at the end of every launch (rc_claim_chunk).  Words [4] and [8..] of SLOT 0 are the scene's
 // sticky stack-overflow status (set by any launch, read and cleared by check_status / rc_wait: a later launch cannot clear an
 // earlier launch's report) and the dev statistics (zeroed per launch only while the "stats" option is on).
-constexpr int kCounterSlots = 64, kCounterSlotWords = 2048, kCounterSlotUsedWords = 1088;
+constexpr int kCounterSlots = 64, kEagerSlots = 48, kCounterSlotWords = 2048, kCounterSlotUsedWords = 1088;
+constexpr int kSceneTimingSlot = kCounterSlots;
 constexpr int kClaimShards = 16, kShardBase = 64, kShardStrideWords = 64;
-inline uint32_t* rc_counter_slot(rc_scene* s) { return s->counters.p + (size_t)(s->launch_seq % kCounterSlots) * kCounterSlotWords; }  // slot of the most recent launch
+inline uint32_t* rc_counter_slot(rc_scene* s) { return s->counters.p + (size_t)s->cur_slot * kCounterSlotWords; }  // slot of the launch being prepared (launch_mu held)
 inline uint32_t* rc_status_word(rc_scene* s) { return s->counters.p + 4; }
 inline unsigned long long* rc_stats_words(rc_scene* s) { return reinterpret_cast<unsigned long long*>(s->counters.p + 8); }
+// Serialises the enqueue of one launch on a scene and does its bookkeeping.  Construction takes launch_mu, picks the stack spill region
+// of `stream` and the launch's counter slot, and orders the launch behind the slot's previous user; start() records the slot's first
+// timing event, finish() the second (both skipped while `stream` is being captured) and makes the launch the calling thread's -- and the
+// scene's -- latest timed operation.  Everything between construction and destruction runs with the lock held.
+struct RcLaunchGuard {
+    rc_scene* s;
+    hipStream_t stream;
+    std::unique_lock<std::mutex> lock;
+    bool capturing = false;
+    RcLaunchGuard(rc_scene* scene, hipStream_t stream);
+    void start();
+    void finish();
+};
+void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcClaim& out);  // the RcClaim of the launch being prepared
+// timing of operations that are not launches through RcLaunchGuard (builds, refits: mutations, externally serialised)
+void rc_timing_scene_begin(rc_scene* s, hipStream_t stream);
+void rc_timing_scene_end(rc_scene* s, hipStream_t stream);
+void rc_timing_fixed(rc_scene* s, float ms);
+float rc_timing_read(rc_scene* s);  // the calling thread's latest timed operation on the scene, else the scene's latest
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items);
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream);
 void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float* d_points, float* d_normals, hipStream_t stream);

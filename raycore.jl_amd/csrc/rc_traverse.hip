@@ -360,59 +360,116 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_phased(TraceArgs a) {
 
 }  // namespace
 
-// Scratch shared by every traversal launch: the lane-stack spill area of the launch's stream and the counter / status words.
-void rc_prepare_launch(rc_scene* s, hipStream_t stream) {
-    {
-        size_t idx = 0;
-        for (; idx < s->overflow_regions.size(); ++idx)
-            if (s->overflow_regions[idx].first == stream) break;
+// ---- launch bookkeeping (RcLaunchGuard, rc_internal.h) ------------------------------------------------------------------------------
+namespace {
+struct TlTiming { uint64_t uid = 0; TimingRef ref; };
+thread_local TlTiming tl_timing;  // the calling thread's latest timed operation (rc_last_kernel_ms reports it while its slot has not been reused)
+
+void note_timing(rc_scene* s, const TimingRef& ref) {
+    s->last_timing = ref;
+    tl_timing.uid = s->uid;
+    tl_timing.ref = ref;
+}
+}  // namespace
+
+RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream(st), lock(scene->launch_mu) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    capturing = cap == hipStreamCaptureStatusActive;
+    // the lane-stack spill area of the launch's stream
+    size_t idx = 0;
+    for (; idx < s->overflow_regions.size(); ++idx)
+        if (s->overflow_regions[idx].stream == stream) break;
+    const size_t region_words = (size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock;  // the largest grid any option can ask for: rc_set_option clamps blocks_per_cu to 8 blocks of 256 threads per CU
+    if (idx == s->overflow_regions.size() || s->overflow_regions[idx].buf.cap < region_words) {
+        if (capturing)  // hipMalloc is not allowed while a stream is being captured
+            throw RcError(1, "a launch is being captured into a hipGraph on a stream this scene has not launched on yet: run one eager launch on the capture stream first (INTEGRATION.md, hipGraph capture)");
         if (idx == s->overflow_regions.size()) {
-            if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // one stream too many: wait for the oldest region's stream, then take it over
-                if (hipStreamSynchronize(s->overflow_regions[0].first) != hipSuccess) {  // the caller may have destroyed that stream since
+            if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // one stream too many: wait for the oldest unpinned region's stream, then take it over
+                size_t victim = 0;
+                while (victim < idx && s->overflow_regions[victim].pinned) ++victim;
+                if (victim == idx) throw RcError(1, "every stack spill region of this scene belongs to a captured hipGraph launch: at most 8 capture streams per scene");
+                if (hipStreamSynchronize(s->overflow_regions[victim].stream) != hipSuccess) {  // the caller may have destroyed that stream since
                     (void)hipGetLastError();
                     RC_HIP(hipDeviceSynchronize());
                 }
-                std::rotate(s->overflow_regions.begin(), s->overflow_regions.begin() + 1, s->overflow_regions.end());
+                std::rotate(s->overflow_regions.begin() + victim, s->overflow_regions.begin() + victim + 1, s->overflow_regions.end());
                 idx -= 1;
-                s->overflow_regions[idx].first = stream;
+                s->overflow_regions[idx].stream = stream;
             } else {
-                s->overflow_regions.emplace_back(stream, DevBuf<uint32_t>());
+                s->overflow_regions.emplace_back();
+                s->overflow_regions.back().stream = stream;
             }
         }
-        // sized for the largest grid any option can ask for: rc_set_option clamps blocks_per_cu to 8 blocks of 256 threads per CU
-        s->overflow_regions[idx].second.reserve((size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock);
-        s->cur_overflow = s->overflow_regions[idx].second.p;
+        s->overflow_regions[idx].buf.reserve(region_words);
     }
-    if (!s->counters.p) {
-        // first launch of the scene: counters, status and statistics start at zero.  Enqueued on the launch's stream (a plain hipMemset
-        // is not ordered with a non-blocking stream and may land after the kernel has started claiming); a launch on any other stream
-        // is ordered behind it by the stream-switch event below.
-        s->counters.reserve((size_t)kCounterSlots * kCounterSlotWords);
-        RC_HIP(hipMemsetAsync(s->counters.p, 0, sizeof(uint32_t) * (size_t)kCounterSlots * kCounterSlotWords, stream));
-        s->claim_slots.assign(kCounterSlots, rc_scene::ClaimSlot());
+    if (capturing) s->overflow_regions[idx].pinned = true;
+    s->cur_overflow = s->overflow_regions[idx].buf.p;
+    // the launch's slot of chunk counters; a launch that reuses an eager slot from another stream waits for the slot's previous user
+    if (capturing) {
+        s->cur_slot = kEagerSlots + (int)(s->graph_seq % (uint64_t)(kCounterSlots - kEagerSlots));
+        s->graph_seq += 1;
+    } else {
+        s->launch_seq += 1;
+        s->cur_slot = (int)(s->launch_seq % (uint64_t)kEagerSlots);
+        rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
+        if (slot.recorded && slot.stream != stream) RC_HIP(hipStreamWaitEvent(stream, slot.t1, 0));
     }
-    // Launches on one stream are ordered.  From the moment a second stream launches on this scene, every launch leaves an event in its
-    // counter slot and a launch that reuses a slot (kCounterSlots launches later) from another stream waits for it first.
-    if (s->any_launch && stream != s->last_launch_stream && !s->multi_stream) {
-        s->multi_stream = true;
-        if (!s->stream_switch_ev) RC_HIP(hipEventCreateWithFlags(&s->stream_switch_ev, hipEventDisableTiming));
-        // everything launched before the switch had no slot events: order the new stream behind the old one once
-        if (hipEventRecord(s->stream_switch_ev, s->last_launch_stream) == hipSuccess) {
-            RC_HIP(hipStreamWaitEvent(stream, s->stream_switch_ev, 0));
-        } else {  // the previous stream no longer exists: whatever ran on it is ordered by a device-wide wait
-            (void)hipGetLastError();
-            RC_HIP(hipDeviceSynchronize());
-        }
-    }
-    s->any_launch = true;
-    s->last_launch_stream = stream;
-    s->launch_seq += 1;
     if (s->opt.stats) RC_HIP(hipMemsetAsync(rc_stats_words(s), 0, 16 * sizeof(unsigned long long), stream));
 }
 
-void rc_claim_begin(rc_scene* s, hipStream_t stream, uint64_t n_items, uint32_t total_waves, rc::RcClaim& out) {
-    rc_scene::ClaimSlot& slot = s->claim_slots[s->launch_seq % kCounterSlots];
-    if (s->multi_stream && slot.has_event) RC_HIP(hipStreamWaitEvent(stream, slot.done, 0));
+void RcLaunchGuard::start() {
+    if (capturing) return;
+    rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
+    if (!slot.t0) { RC_HIP(hipEventCreate(&slot.t0)); RC_HIP(hipEventCreate(&slot.t1)); }
+    RC_HIP(hipEventRecord(slot.t0, stream));
+}
+
+void RcLaunchGuard::finish() {
+    RC_HIP(hipGetLastError());
+    if (capturing) return;  // a captured launch has no events of its own: the graph orders it, and its duration is the replay's business
+    rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
+    RC_HIP(hipEventRecord(slot.t1, stream));
+    slot.stream = stream;
+    slot.recorded = true;
+    slot.seq = ++s->timing_seq;
+    note_timing(s, TimingRef{s->cur_slot, slot.seq, 0.f});
+}
+
+void rc_timing_scene_begin(rc_scene* s, hipStream_t stream) { RC_HIP(hipEventRecord(s->ev0, stream)); }
+void rc_timing_scene_end(rc_scene* s, hipStream_t stream) {
+    RC_HIP(hipEventRecord(s->ev1, stream));
+    std::lock_guard<std::mutex> g(s->launch_mu);
+    rc_scene::LaunchSlot& slot = s->slots[kSceneTimingSlot];
+    slot.t0 = s->ev0; slot.t1 = s->ev1; slot.stream = stream; slot.recorded = true;
+    slot.seq = ++s->timing_seq;
+    note_timing(s, TimingRef{kSceneTimingSlot, slot.seq, 0.f});
+}
+void rc_timing_fixed(rc_scene* s, float ms) {
+    std::lock_guard<std::mutex> g(s->launch_mu);
+    note_timing(s, TimingRef{-1, ++s->timing_seq, ms});
+}
+float rc_timing_read(rc_scene* s) {
+    hipEvent_t a = nullptr, b = nullptr;
+    {
+        std::lock_guard<std::mutex> g(s->launch_mu);
+        TimingRef ref = s->last_timing;
+        if (tl_timing.uid == s->uid) {
+            const TimingRef& mine = tl_timing.ref;
+            if (mine.slot == -1 || (mine.slot >= 0 && s->slots[mine.slot].seq == mine.seq)) ref = mine;  // else: the slot has been reused since
+        }
+        if (ref.slot == -2) return 0.f;
+        if (ref.slot == -1) return ref.fixed_ms;
+        if (s->slots[ref.slot].seq != ref.seq) return 0.f;
+        a = s->slots[ref.slot].t0; b = s->slots[ref.slot].t1;
+    }
+    float ms = 0.f;
+    RC_HIP(hipEventSynchronize(b));
+    RC_HIP(hipEventElapsedTime(&ms, a, b));
+    return ms;
+}
+
+void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcClaim& out) {
     out.counters = rc_counter_slot(s) + kShardBase;
     uint32_t shards = (uint32_t)s->opt.claim_shards, shift = 0;
     while (shards > 1 && shards > total_waves) shards >>= 1;  // every shard needs a wave: chunks dealt to a shard nobody drains would never be traced
@@ -425,14 +482,6 @@ void rc_claim_begin(rc_scene* s, hipStream_t stream, uint64_t n_items, uint32_t 
     out.total_waves = total_waves;
 }
 
-void rc_claim_commit(rc_scene* s, hipStream_t stream) {
-    if (!s->multi_stream) return;
-    rc_scene::ClaimSlot& slot = s->claim_slots[s->launch_seq % kCounterSlots];
-    if (!slot.done) RC_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
-    RC_HIP(hipEventRecord(slot.done, stream));
-    slot.has_event = true;
-}
-
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     rc::SceneView v;
     v.tlas_nodes = s->tlas_nodes.p; v.blas_nodes = s->flat_nodes.p; v.inst = s->inst_recs.p; v.prims = s->flat_prims.p;
@@ -442,12 +491,11 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     return v;
 }
 
-// Arguments of a persistent launch on `stream` with `total_threads` threads (after rc_prepare_launch); the caller commits the claim
-// (rc_claim_commit) once the kernel has been enqueued.
-rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads, hipStream_t stream) {
+// Arguments of a persistent launch with `total_threads` threads (inside an RcLaunchGuard).
+rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads) {
     rc::PersistArgs p;
     p.n_items = n_items;
-    rc_claim_begin(s, stream, n_items, total_threads / 64u, p.claim);
+    rc_claim_fill(s, n_items, total_threads / 64u, p.claim);
     p.refill = (int)s->opt.refill;
     p.int_thr = (int)s->opt.sched_thr;
     p.stats = rc_stats_words(s);
@@ -480,19 +528,19 @@ uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items) {
 }
 
 template <bool ANY>
-static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hipStream_t stream) {
+static void launch_variant(rc_scene* s, int64_t kernel, const TraceArgs& a, uint32_t blocks, hipStream_t stream) {
     const int64_t lds = s->opt.lds_stack;
     const bool stats = s->opt.stats != 0;
 #define RC_LAUNCH_P(L, W) hipLaunchKernelGGL((k_trace_persistent<ANY, L, W, false>), dim3(blocks), dim3(kBlock), 0, stream, a)
 #define RC_LAUNCH_S(L, W) hipLaunchKernelGGL((k_trace_simple<ANY, L, W>), dim3(blocks), dim3(kBlock), 0, stream, a)
-    if (s->opt.kernel == 4) {
+    if (kernel == 4) {
         bool& attr_set = s->lds_attr_set[ANY ? 1 : 0];  // per scene = per device: the attribute belongs to the function on one device
         if (!attr_set) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kBigBlock, kLdsStack, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes));
             attr_set = true;
         }
         hipLaunchKernelGGL((k_trace_phased_lds<ANY, kBigBlock, kLdsStack, 4>), dim3(blocks), dim3(kBigBlock), kBigLdsBytes, stream, a);
-    } else if (s->opt.kernel == 5) {
+    } else if (kernel == 5) {
         bool& attr_set = s->lds_attr_set[2 + (ANY ? 1 : 0)];
         if (!attr_set) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
@@ -503,25 +551,25 @@ static void launch_variant(rc_scene* s, const TraceArgs& a, uint32_t blocks, hip
             hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
         } else
         hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
-    } else if (s->opt.kernel == 6) {
+    } else if (kernel == 6) {
         bool& attr_set = s->lds_attr_set[6 + (ANY ? 1 : 0)];
         if (!attr_set) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_partial<ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartialLdsBytes));
             attr_set = true;
         }
         hipLaunchKernelGGL((k_trace_phased_partial<ANY>), dim3(blocks), dim3(kMidBlock), kPartialLdsBytes, stream, a);
-    } else if (s->opt.kernel == 3) {
+    } else if (kernel == 3) {
         if (stats) hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else if (lds == 16) hipLaunchKernelGGL((k_trace_phased<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else if (lds == 20) hipLaunchKernelGGL((k_trace_phased<ANY, 20, 7, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else if (lds == 17) hipLaunchKernelGGL((k_trace_phased<ANY, 16, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else if (lds == 13) hipLaunchKernelGGL((k_trace_phased<ANY, 12, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    } else if (s->opt.kernel == 2) {
+    } else if (kernel == 2) {
         if (stats) hipLaunchKernelGGL((k_trace_sched<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else if (lds == 16) hipLaunchKernelGGL((k_trace_sched<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
         else hipLaunchKernelGGL((k_trace_sched<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
-    } else if (s->opt.kernel == 0) {
+    } else if (kernel == 0) {
         if (lds == 12) RC_LAUNCH_S(12, 8); else if (lds == 16) RC_LAUNCH_S(16, 8); else if (lds == 32) RC_LAUNCH_S(32, 4); else RC_LAUNCH_S(24, 6);
     } else if (stats) {
         hipLaunchKernelGGL((k_trace_persistent<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
@@ -539,44 +587,38 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
 
 void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream) {
     if (n == 0) return;
+    RcLaunchGuard launch(s, stream);  // serialises the enqueue: trace calls on one scene may come from several host threads
     uint64_t want = (n + kBlock - 1) / kBlock, cap = (uint64_t)s->n_cus * rc_blocks_per_cu(s);
     uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     uint32_t total_threads = blocks * kBlock;
-    struct KernelOptionGuard {  // the fall-back rules below rewrite opt.kernel for this launch only, also when the launch throws
-        rc_scene* s; int64_t saved;
-        ~KernelOptionGuard() { s->opt.kernel = saved; }
-    } kernel_guard{s, s->opt.kernel};
-    const int64_t saved_kernel = s->opt.kernel;
-    if (saved_kernel < 0)  // auto: tiny batches gain nothing from refilling; a TLAS that fits the LDS planes (<= 256 instances) is read from there
-        s->opt.kernel = (n < (uint64_t)total_threads * 5 / 4) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 6);  // measured crossover (tools/small_batch_probe.py): ~1.2 rays per resident lane
-    if (s->opt.kernel == 4 && (s->n_tlas_nodes > (uint32_t)kTlasLdsNodes || s->n_static_instances > (uint32_t)kTlasLdsInst)) s->opt.kernel = 3;
-    if (s->opt.kernel == 5 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes) s->opt.kernel = 3;
-    if (s->opt.kernel == 6 && s->tlas_top_k + s->blas_top_k == 0) s->opt.kernel = 3;  // nothing to stage
-    if (s->opt.kernel >= 3 && ((uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32) || n >= (1ull << 38))) s->opt.kernel = 1;  // buffer offsets and chunk ids are 32-bit
-    if (s->opt.kernel == 4) {  // one 1024-thread workgroup per CU
+    int64_t kernel = s->opt.kernel;  // the fall-back rules below choose for this launch only
+    if (kernel < 0)  // auto: tiny batches gain nothing from refilling; a TLAS that fits the LDS planes (<= 256 instances) is read from there
+        kernel = (n < (uint64_t)total_threads * 5 / 4) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 6);  // measured crossover (tools/small_batch_probe.py): ~1.2 rays per resident lane
+    if (kernel == 4 && (s->n_tlas_nodes > (uint32_t)kTlasLdsNodes || s->n_static_instances > (uint32_t)kTlasLdsInst)) kernel = 3;
+    if (kernel == 5 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes) kernel = 3;
+    if (kernel == 6 && s->tlas_top_k + s->blas_top_k == 0) kernel = 3;  // nothing to stage
+    if (kernel >= 3 && ((uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u >= (1ull << 32) || n >= (1ull << 38))) kernel = 1;  // buffer offsets and chunk ids are 32-bit
+    if (kernel == 4) {  // one 1024-thread workgroup per CU
         blocks = (uint32_t)std::min<uint64_t>((n + kBigBlock - 1) / kBigBlock, (uint64_t)s->n_cus);
         total_threads = blocks * kBigBlock;
     }
-    if (s->opt.kernel == 5 || s->opt.kernel == 6) {  // two 768-thread workgroups per CU
+    if (kernel == 5 || kernel == 6) {  // two 768-thread workgroups per CU
         blocks = (uint32_t)std::min<uint64_t>((n + kMidBlock - 1) / kMidBlock, (uint64_t)s->n_cus * (s->opt.blocks_per_cu == 1 ? 1 : 2));
         total_threads = blocks * kMidBlock;
     }
-    rc_prepare_launch(s, stream);
     TraceArgs a;
     a.v = rc_scene_view(s, total_threads);
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
-    rc_claim_begin(s, stream, n, total_threads / 64u, a.claim);
+    rc_claim_fill(s, n, total_threads / 64u, a.claim);
     a.refill = (int)s->opt.refill;
-    a.sched_thr = s->opt.kernel == 2 ? 32 : (int)s->opt.sched_thr;  // kernel 2's vote threshold is its own (lanes that must wait for a batch), tuned at 32
+    a.sched_thr = kernel == 2 ? 32 : (int)s->opt.sched_thr;  // kernel 2's vote threshold is its own (lanes that must wait for a batch), tuned at 32
     a.stats = rc_stats_words(s);
     a.timeline = reinterpret_cast<unsigned long long*>(s->opt.timeline_ptr);
-    if ((s->opt.kernel == 5 || s->opt.kernel == 4) && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
-    if (s->opt.kernel == 6) {  // a plan made for the full-LDS kernels (<= 256 instances) has no TLAS renumbering: tlas_k = 0, its blas_k still fits
+    if ((kernel == 5 || kernel == 4) && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
+    if (kernel == 6) {  // a plan made for the full-LDS kernels (<= 256 instances) has no TLAS renumbering: tlas_k = 0, its blas_k still fits
         a.tlas_k = s->tlas_top_k; a.blas_k = s->opt.blas_top ? s->blas_top_k : 0; a.lds_blas_base = s->tlas_top_k;
     }
-    RC_HIP(hipEventRecord(s->ev0, stream));
-    if (any_hit) launch_variant<true>(s, a, blocks, stream); else launch_variant<false>(s, a, blocks, stream);
-    RC_HIP(hipEventRecord(s->ev1, stream));
-    RC_HIP(hipGetLastError());
-    rc_claim_commit(s, stream);
+    launch.start();
+    if (any_hit) launch_variant<true>(s, kernel, a, blocks, stream); else launch_variant<false>(s, kernel, a, blocks, stream);
+    launch.finish();
 }

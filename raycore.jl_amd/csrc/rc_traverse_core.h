@@ -27,7 +27,7 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
     uint32_t* status;         // [0] = stack overflow flag
 };
 
-// How a persistent kernel's waves claim work (host side: rc_claim_begin / rc_claim_commit, rc_traverse.hip).  A claim is one chunk
+// How a persistent kernel's waves claim work (host side: RcLaunchGuard / rc_claim_fill, rc_traverse.hip).  A claim is one chunk
 // of `pool` consecutive items (large claims keep a wave on neighbouring rays: coherent fetches).  The chunks are dealt out by
 // n_shards counters -- in round c of a shard's counter the shards share chunks c * n .. c * n + n - 1, which of them a shard gets
 // rotating with c: with a fixed assignment a shard would own one column band of a 2048-ray-wide image, and bands differ in cost by
@@ -696,7 +696,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
 }  // namespace rc
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads);  // rc_traverse.hip
-rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads, hipStream_t stream);
+rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads);
 bool rc_lds_driver_ok(rc_scene* s);
 bool rc_partial_driver_ok(rc_scene* s);
 void rc_partial_driver_args(rc_scene* s, rc::PersistArgs& p);

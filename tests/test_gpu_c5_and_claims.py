@@ -147,14 +147,19 @@ def test_claim_counters_are_never_reset_and_never_drift(rc, oracle):
     t.free()
 
 
-def test_status_word_is_not_cleared_by_later_launches(rc, oracle):
+def test_status_word_is_not_cleared_by_later_launches(rc, oracle, monkeypatch):
     """The scene's stack-overflow word is sticky: kernels only set it, check_status / rc_wait clear it when they report it.  (No
     LBVH over 30-bit Morton codes + indices is deeper than the 128 stack entries, so a real overflow cannot be built; the word is
-    set by hand and must survive further launches until rc_wait reports it once.)"""
+    set by hand -- a test hook the library only honours under RC_ENABLE_DEBUG_HOOKS=1 -- and must survive further launches until
+    rc_wait reports it once.)"""
     import ctypes
     import torch
     sc = rc.scenes
     t = rc.TLAS(0)
+    monkeypatch.delenv("RC_ENABLE_DEBUG_HOOKS", raising=False)
+    with pytest.raises(rc.RaycoreError, match="unknown option"):
+        t.set_option("debug_set_overflow", 1)  # not part of the product's interface
+    monkeypatch.setenv("RC_ENABLE_DEBUG_HOOKS", "1")
     t.push(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32), sc.IDENTITY3x4[None])
     t.sync()
     rays = sc.make_rays(np.array([[0.2, 0.2, -1.0]] * 300), np.array([[0.0, 0.0, 1.0]] * 300))
