@@ -436,6 +436,43 @@ def main():
                             "kernel_ms_rank0": round(t5.last_kernel_ms(), 3)}
             del m
             torch.cuda.empty_cache()
+        # What the API returns: a HOST N x N matrix (src/kernels.jl:74-78).  One process per GPU: every rank copies its block of rows
+        # into a matrix in shared memory over its own PCIe link (distributed.view_factors_host_matrix); the time includes creating and
+        # faulting in the 10 GB matrix.  One GPU: rc_view_factors, row chunks traced while the finished ones travel.
+        rd.view_factors_host_matrix(t5, 4, 7)
+        fence()
+        v0 = time.perf_counter()
+        hm = rd.view_factors_host_matrix(t5, rpt, 7)
+        fence()
+        vdt = time.perf_counter() - v0
+        if rank == 0:
+            vf["host_matrix_shared_memory"] = {"seconds": round(vdt, 4), "Mrays_s": round(n5 * rpt / vdt / 1e6, 1), "ranks": world,
+                                               "GBs_into_host_memory": round(4 * n5 * n5 / vdt / 1e9, 1), "counted": int(np.asarray(hm).sum(dtype=np.int64)),
+                                               "note": "end to end incl. creating + faulting in the matrix in /dev/shm; every rank writes its rows over its own PCIe link"}
+        del hm
+        if world == 1:
+            out_m = np.empty((n5, n5), dtype=np.uint32, order="F")
+            e2e = {}
+            v0 = time.perf_counter()
+            rc.view_factors(t5, rpt, 7, out=out_m)  # first call: the matrix's pages are faulted in inside the call (parallel MADV_POPULATE_WRITE)
+            e2e["fresh_matrix_s"] = round(time.perf_counter() - v0, 4)
+            for key, register in (("reused_matrix_s", False), ("reused_registered_matrix_s", True)):
+                if register:
+                    t5.host_register(out_m)
+                best = 1e30
+                for _ in range(2):
+                    v0 = time.perf_counter()
+                    rc.view_factors(t5, rpt, 7, out=out_m)
+                    best = min(best, time.perf_counter() - v0)
+                e2e[key] = round(best, 4)
+                if register:
+                    t5.host_unregister(out_m)
+            e2e["device_pipeline_ms"] = round(t5.last_kernel_ms(), 3)
+            e2e["counted"] = int(out_m.sum(dtype=np.int64))
+            e2e["pcie_floor_s_at_56_GBs"] = round(4 * n5 * n5 / 56e9, 4)
+            vf["host_matrix_e2e_s"] = e2e["reused_matrix_s"]
+            vf["host_matrix_e2e"] = e2e
+            del out_m
         t5.free()
         if rank == 0:
             extras["view_factors_c5"] = vf

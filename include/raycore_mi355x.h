@@ -15,10 +15,18 @@
  *    non-zero status into ErrorException (test/test_tlas_stress.jl:585-617 expects that type).
  *  - The caller owns every host buffer it passes.  The library owns all device memory behind the opaque
  *    rc_scene handle and frees it in rc_scene_destroy (replaces free!, src/instanced-bvh.jl:383-399).
- *  - Mutations (rc_add_*, rc_update_*, rc_delete, rc_sync) on one scene must be externally serialised; device-pointer
- *    trace / driver calls on a synced scene may be in flight on distinct HIP streams (each launch gets its own work
- *    counter; the only shared scratch is the spill area used by traversal stacks deeper than 24 entries, so scenes with
- *    such deep trees should keep their launches on one stream).  No global mutable state.
+ *  - Threading.  Mutations (rc_add_*, rc_update_*, rc_delete, rc_sync, rc_set_option, rc_blas4_build, rc_refit_device) on one scene
+ *    must be externally serialised and must not overlap queries.  QUERIES ON A SYNCED SCENE ARE RE-ENTRANT: any number of host threads
+ *    may call rc_trace_closest / rc_trace_any (each call stages through its own stream and buffers; a fifth concurrent call waits for a
+ *    staging context) and the *_device entry points (rc_trace_*_device, rc_get_illumination_device, rc_view_factors_device,
+ *    rc_trace_*4_device and the wavefront stage kernels) at once -- the reference's own drivers call closest_hit on one adapted accel
+ *    from Threads.@threads (src/kernels.jl:64,82).  Only the enqueue of a launch is serialised inside the library (microseconds); the
+ *    launches overlap on their streams, each with its own work counters and -- per stream -- its own stack spill area.  The other
+ *    host-buffer queries (rc_get_illumination, rc_view_factors*, rc_collide_instances, rc_trace_*4) are safe to call concurrently and run
+ *    one at a time per scene.  rc_compact_hits_device and rc_collide_instances_device use scene-owned scratch: keep their calls on one
+ *    scene on one stream.  rc_last_kernel_ms reports the calling thread's latest launch.  No global mutable state.
+ *  - hipGraph capture: trace / driver launches on a capturing stream are captured (no events, a counter slot of their own that eager
+ *    launches never use); the stream must have run one eager launch on the scene before (stack spill area), see INTEGRATION.md.
  *  - There is NO CPU fallback: every compute entry point runs hand-written gfx950 HIP kernels and fails
  *    with RC_ERR_NO_DEVICE when no GPU is present.
  *  - Index bases at this boundary are 0-based (C); the host wrappers add 1 where the Julia API is 1-based.
@@ -202,14 +210,38 @@ int rc_get_illumination_device(rc_scene* scene, const float viewdir[3], uint32_t
  * by ascending metadata (ties by flat index) and row = that position: when the metadata are a permutation of
  * 1..N -- the view-factor convention, src/kernels.jl:85 -- position p IS matrix row src_meta-1, so a contiguous
  * source range owns a contiguous block of FINAL rows and a multi-GPU gather / reduce needs no row permutation
- * and no second N x N buffer. */
+ * and no second N x N buffer.
+ * RC_VF_ROW_BY_METADATA_VALUE (with RC_VF_SOURCES_BY_METADATA): sources are addressed by position in the metadata order, but
+ * row = src_meta-1 as without flags -- for metadata that are not a permutation of 1..N (duplicates share a row, gaps leave rows
+ * empty) a range of matrix rows is still a contiguous range of positions, which is how the host-matrix entry points cut the job
+ * into row chunks and row blocks. */
 #define RC_VF_ROW_BY_PRIMITIVE 1u
 #define RC_VF_SOURCES_BY_METADATA 2u
+#define RC_VF_ROW_BY_METADATA_VALUE 4u
 int rc_view_factors_device(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin,
                            uint32_t src_end, uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix,
                            uint64_t row_stride, uint64_t col_stride, uint32_t row_offset, uint32_t flags, void* stream);
-/* Whole job into a host N x N column-major matrix (the Julia return value). */
+/* Whole job into a host N x N column-major matrix (the Julia return value, src/kernels.jl:74-78).  The matrix never exists on the
+ * device: row chunks (192 MB blocks) are traced on alternating streams while the finished ones travel to out_matrix as 2-D copies,
+ * so the call lasts about as long as N*N*4 bytes need over the PCIe link (C5: 10 GB, ~0.18 s; the tracing, 41 ms, hides inside).
+ * out_matrix may be pageable or registered (rc_host_register); every element is written. */
 int rc_view_factors(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix);
+/* Matrix rows [row_begin, row_end) only, into a host column-major matrix with leading dimension ld >= N (element (r, c) at
+ * out_matrix[r + ld*c]): the unit of a multi-PROCESS run -- every rank maps the same shared-memory matrix and brings its own row
+ * block home over its own PCIe link (raycore.jl_amd/distributed.py, mode "rows_host"). */
+int rc_view_factors_rows_host(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint32_t row_begin, uint32_t row_end,
+                              uint32_t* out_matrix, uint64_t ld);
+/* The same job on several devices of one process: scenes[g] is a synced scene on device g's ordinal, all built from the same
+ * geometry (view_factors shards across the GPUs of a node).
+ *   RC_VF_MODE_ROWS: scene g traces matrix rows [g N / G, (g+1) N / G) and copies its chunks straight into out_matrix -- G PCIe links
+ *     in parallel, nothing crosses xGMI, no collective.  Several scenes may share a device.
+ *   RC_VF_MODE_RAYS: scene g shoots ray indices [g R / G, (g+1) R / G) of every source into a full device accumulator; row chunks are
+ *     summed into scenes[0]'s device with RCCL (ncclReduce, ncclUint32, over xGMI; librccl.so is loaded on first use) while the next
+ *     chunk is traced, and leave from there.  Needs distinct devices.
+ * Both give the matrix rc_view_factors gives, bit for bit (Philox is keyed by ray index and source primitive). */
+#define RC_VF_MODE_ROWS 0
+#define RC_VF_MODE_RAYS 1
+int rc_view_factors_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix, int mode);
 /* The rays view_factors shoots for one source primitive (ray indices [ray_begin, ray_begin + n_rays)),
  * written to a device buffer: the body of the reference's inner loop up to the Ray constructor
  * (src/kernels.jl:89-92), exposed so ray generation can be checked on its own. */
@@ -282,6 +314,11 @@ typedef struct rc_triangle {
  * Expansion, is_degenerate_face filtering (:573-577), build_triangle (:555-566) and the LBVH build run on the device. */
 int rc_add_mesh(rc_scene* scene, const float* verts, const float* normals, const float* uvs, uint32_t nv,
                 const uint32_t* indices, uint32_t nf, const uint32_t* face_meta, uint32_t* blas_id);
+/* The same with ONE METADATA WORD PER FACE (nf words): the TLAS(items, metadata_fn) constructor evaluates metadata_fn(mesh_idx, face_idx)
+ * for every face (src/instanced-bvh.jl:2300-2306), which a per-vertex array cannot carry when faces share their first vertex (the two
+ * triangles of a quad, the fans of a sphere).  Assigned before the degenerate filter, like the face index. */
+int rc_add_mesh_face_metadata(rc_scene* scene, const float* verts, const float* normals, const float* uvs, uint32_t nv,
+                              const uint32_t* indices, uint32_t nf, const uint32_t* metadata_per_face, uint32_t* blas_id);
 /* update!(tlas, handle, new_mesh) (src/instanced-bvh.jl:808-857) for a decomposed mesh: replaces the BLAS the handle uses. */
 int rc_update_geometry_mesh(rc_scene* scene, uint32_t handle, const float* verts, const float* normals, const float* uvs, uint32_t nv,
                             const uint32_t* indices, uint32_t nf, const uint32_t* face_meta);

@@ -751,9 +751,30 @@ static void pf_drain(void) {
         pf_fn(pf_ctx, b, e);
     }
 }
+/* Optional: worker k runs on the k-th CPU this process is allowed on (rco_pool_pin(1) before the pool's first use).  A timing run on a
+ * 256-thread host should not depend on where the scheduler parks 255 freshly woken threads. */
+static int pf_pin = 0;
+void rco_pool_pin(int enable) { pf_pin = enable; }
+int rco_allowed_cpus(void) {
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) != 0) return 1;
+    return CPU_COUNT(&set);
+}
+static void pf_pin_self(int id) {
+    cpu_set_t allowed, one;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    const int n = CPU_COUNT(&allowed);
+    if (n <= 0) return;
+    int want = (id + 1) % n, seen = 0;  /* worker 0 on the second allowed CPU: the calling thread (which works too) usually sits on the first */
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+        if (!CPU_ISSET(c, &allowed)) continue;
+        if (seen++ == want) { CPU_ZERO(&one); CPU_SET(c, &one); (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one); return; }
+    }
+}
 static void* pf_worker(void* arg) {
     const int id = (int)(intptr_t)arg;
     uint64_t seen = 0;
+    if (pf_pin) pf_pin_self(id);
     pthread_mutex_lock(&pf_mutex);
     for (;;) {
         while (pf_generation == seen || id >= pf_want) {

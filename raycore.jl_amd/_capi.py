@@ -72,6 +72,8 @@ SYMBOLS = [
     ("rc_get_illumination_device", _int, [_vp, _vp, _u32, _u64, _u64, _vp, _vp]),
     ("rc_view_factors_device", _int, [_vp, _u32, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _u64, _u32, _u32, _vp]),
     ("rc_view_factors", _int, [_vp, _u32, _u64, _vp]),
+    ("rc_view_factors_rows_host", _int, [_vp, _u32, _u64, _u32, _u32, _vp, _u64]),
+    ("rc_view_factors_multi", _int, [C.POINTER(_vp), _int, _u32, _u64, _vp, _int]),
     ("rc_view_factor_rays_device", _int, [_vp, _u64, _u32, _u32, _u32, _vp, _vp]),
     ("rc_hit_points_device", _int, [_vp, _vp, _vp, _u64, _vp, _vp, _vp]),
     ("rc_shadow_rays_device", _int, [_vp, _vp, _vp, _u64, _vp, C.c_float, _vp, _vp]),
@@ -85,6 +87,7 @@ SYMBOLS = [
     ("rc_collide_instances_device", _int, [_vp, _vp, _u64, C.POINTER(_u64), _vp]),
     ("rc_collide_instances_any", _int, [_vp, _u32, _u32, _pint]),
     ("rc_add_mesh", _int, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _pu32]),
+    ("rc_add_mesh_face_metadata", _int, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _pu32]),
     ("rc_update_geometry_mesh", _int, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _u32, _vp]),
     ("rc_export_triangles", _int, [_vp, _vp, _u32, _pu32]),
     ("rc_shading_attributes_device", _int, [_vp, _vp, _u64, _vp, _vp, _vp]),

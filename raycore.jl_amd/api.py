@@ -682,12 +682,37 @@ def get_illumination(accel, viewdir, grid_size=1000):
     return out
 
 
-def view_factors(accel, rays_per_triangle=10000, seed=0):
-    """view_factors (src/kernels.jl:74-104): N x N UInt32 matrix, [src_meta, hit_meta] (column-major like Julia's Matrix)."""
+def _vf_out(n, out):
+    if out is None:
+        return np.empty((n, n), dtype=np.uint32, order="F")  # every element is written by the library
+    if out.dtype != np.uint32 or out.shape != (n, n) or not out.flags["F_CONTIGUOUS"]:
+        raise ValueError("out must be an (N, N) uint32 array in column-major (Fortran) order, like Julia's Matrix")
+    return out
+
+
+def view_factors(accel, rays_per_triangle=10000, seed=0, out=None):
+    """view_factors (src/kernels.jl:74-104): N x N UInt32 matrix, [src_meta, hit_meta] (column-major like Julia's Matrix).  Row chunks
+    are traced while the finished ones travel to the host matrix, so the call costs about the PCIe time of 4 N^2 bytes.  `out` reuses
+    a matrix (a render / solve loop saves the page faults of a fresh one)."""
     t = _owner(accel)
-    n = t.n_primitives()
-    out = np.zeros((n, n), dtype=np.uint32, order="F")
+    out = _vf_out(t.n_primitives(), out)
     check(lib().rc_view_factors(t._h, int(rays_per_triangle), int(seed), ptr(out)))
+    return out
+
+
+VF_MODE_ROWS, VF_MODE_RAYS = 0, 1
+
+
+def view_factors_multi(accels, rays_per_triangle=10000, seed=0, mode="rows", out=None):
+    """view_factors on several devices of ONE process (rc_view_factors_multi): `accels` are synced accels holding the same geometry,
+    one per device.  mode="rows": accel g traces matrix rows [gN/G, (g+1)N/G) and copies them into the host matrix over its own PCIe
+    link; mode="rays": every device shoots rays_per_triangle / G rays of every source, RCCL ncclReduce over xGMI into the first
+    device (BASELINE's north-star partition).  Same matrix either way, bit for bit."""
+    owners = [_owner(a) for a in accels]
+    n = owners[0].n_primitives()
+    out = _vf_out(n, out)
+    handles = (C.c_void_p * len(owners))(*[o._h for o in owners])
+    check(lib().rc_view_factors_multi(handles, len(owners), int(rays_per_triangle), int(seed), ptr(out), {"rows": VF_MODE_ROWS, "rays": VF_MODE_RAYS}[mode]))
     return out
 
 

@@ -243,6 +243,7 @@ int rc_scene_destroy(rc_scene* s) {
         if (s->slots[i].t1) (void)hipEventDestroy(s->slots[i].t1);
     }
     for (auto& c : s->call_ctx) if (c && c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    for (auto a : s->aux_streams) if (a) (void)hipStreamDestroy(a);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return RC_OK;
@@ -1031,6 +1032,7 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "claim_shards") { int64_t p2 = 1; while (p2 * 2 <= value && p2 * 2 <= kClaimShards) p2 *= 2; s->opt.claim_shards = p2; }  // a power of two
     else if (k == "host_pipeline") s->opt.host_pipeline = value != 0;
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (k == "vf_chunk_bytes") s->opt.vf_chunk_bytes = value < 4096 ? 4096 : (value > (int64_t(4) << 30) ? (int64_t(4) << 30) : value);
     else if (k == "timeline_ptr") s->opt.timeline_ptr = value;  // dev instrumentation: the caller owns the buffer and its size (8 x u64 per wave of the launch)
     else if (k == "debug_set_overflow") {  // test hook: raise the sticky stack-overflow word as a kernel would (no LBVH is deep enough to do it for real)
         const char* hooks = getenv("RC_ENABLE_DEBUG_HOOKS");  // not part of the product's interface: only a process that asks for the hooks gets them
@@ -1072,6 +1074,7 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
         *value = drift;
     }
     else if (k == "host_pipeline") *value = s->opt.host_pipeline;
+    else if (k == "vf_chunk_bytes") *value = s->opt.vf_chunk_bytes;
     else if (k == "blas_top_k") *value = s->blas_top_k;
     else if (k == "tlas_top_k") *value = s->tlas_top_k;
     else if (k.rfind("stat", 0) == 0 && k.size() == 5 && ((k[4] >= '0' && k[4] <= '9') || (k[4] >= 'a' && k[4] <= 'f'))) {
@@ -1130,19 +1133,33 @@ int rc_view_factors_device(rc_scene* s, uint32_t rays_per_triangle, uint64_t see
     });
 }
 
+// view_factors(tlas; rays_per_triangle) -> host Matrix{UInt32} (src/kernels.jl:74-78): row chunks traced on the device while the finished
+// ones travel to the caller's matrix (rc_multi.hip); no N x N device matrix exists.
 int rc_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix) {
+    return rc_view_factors_multi(&s, 1, rays_per_triangle, seed, out_matrix, RC_VF_MODE_ROWS);
+}
+
+int rc_view_factors_rows_host(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t row_begin, uint32_t row_end, uint32_t* out_matrix, uint64_t ld) {
     if (!s || !out_matrix) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {
         use_device(s);
         require_synced(s);
-        uint64_t np = s->n_flat_prims;
-        if (np == 0) return;
-        DevBuf<uint32_t> m;
-        m.reserve(np * np);
-        RC_HIP(hipMemsetAsync(m.p, 0, sizeof(uint32_t) * np * np, s->stream));
-        rc_launch_view_factors(s, rays_per_triangle, seed, 0, (uint32_t)np, 0, rays_per_triangle, m.p, 1, np, 0, 0, s->stream);
-        RC_HIP(hipMemcpyAsync(out_matrix, m.p, sizeof(uint32_t) * np * np, hipMemcpyDeviceToHost, s->stream));
-        check_status(s, s->stream);
+        if (ld < s->n_flat_prims) throw RcError(RC_ERR_INVALID_ARGUMENT, "leading dimension smaller than the number of primitives");
+        std::lock_guard<std::mutex> one_at_a_time(s->host_call_mu);
+        rc_timing_fixed(s, rc_view_factors_rows_to_host(s, rays_per_triangle, seed, row_begin, row_end, out_matrix, ld));
+    });
+}
+
+int rc_view_factors_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix, int mode) {
+    if (!scenes || n_scenes < 1 || !out_matrix) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        std::vector<std::unique_lock<std::mutex>> locks;  // one job at a time per scene (the scenes' auxiliary streams and blocks are the job's); in argument order
+        for (int g = 0; g < n_scenes; ++g) {
+            if (!scenes[g]) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+            for (int h = 0; h < g; ++h) if (scenes[h] == scenes[g]) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_view_factors_multi: the same scene twice");
+            locks.emplace_back(scenes[g]->host_call_mu);
+        }
+        rc_view_factors_multi_impl(scenes, n_scenes, rays_per_triangle, seed, out_matrix, mode);
     });
 }
 

@@ -251,7 +251,7 @@ struct ViewFactorSink {
             const uint4 m3 = *(reinterpret_cast<const uint4*>(inst + instance) + 3);
             const uint32_t hit_meta = prims[m3.y + prim - 1u].meta, src_meta = prims[src].meta;
             counted = hit_meta != src_meta && src_meta >= 1 && src_meta <= n_prims && hit_meta >= 1 && hit_meta <= n_prims;
-            const uint32_t row = (flags & 2u) ? pos : ((flags & 1u) ? src : src_meta - 1);
+            const uint32_t row = (flags & 4u) ? src_meta - 1 : ((flags & 2u) ? pos : ((flags & 1u) ? src : src_meta - 1));
             if (counted) index = (uint64_t)(row - row_offset) * row_stride + (uint64_t)(hit_meta - 1) * col_stride;
         }
         wave_count(matrix, index, counted);
@@ -471,6 +471,31 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
     launch.finish();
 }
 
+// RC_VF_SOURCES_BY_METADATA: the flat primitives' indices sorted by (metadata, index) -- and the sorted metadata themselves on the host --
+// cached until the next rebuild.  Built on the scene's own stream, which also owns the sort scratch.
+void rc_ensure_vf_order(rc_scene* s) {
+    std::lock_guard<std::mutex> g(s->launch_mu);
+    if (s->vf_order_valid) return;
+    const uint32_t np = s->n_flat_prims;
+    s->vf_meta_sorted.assign(np, 0u);
+    if (np) {
+        s->keys_a.reserve(np); s->keys_b.reserve(np); s->vals_a.reserve(np); s->vf_order.reserve(np);
+        hipLaunchKernelGGL(k_meta_keys, dim3((np + 255) / 256), dim3(256), 0, s->stream, s->flat_prims.p, np, s->keys_a.p, s->vals_a.p);
+        size_t tmp = 0;
+        RC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vf_order.p, (int)np, 0, 32, s->stream));
+        s->sort_tmp.reserve(tmp ? tmp : 1);
+        RC_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vf_order.p, (int)np, 0, 32, s->stream));  // stable: ties keep the flat order
+        RC_HIP(hipMemcpyAsync(s->vf_meta_sorted.data(), s->keys_b.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost, s->stream));
+        RC_HIP(hipStreamSynchronize(s->stream));  // the launches that read the order run on other streams
+    }
+    s->vf_order_valid = true;
+}
+void rc_vf_source_range(rc_scene* s, uint32_t row_begin, uint32_t row_end, uint32_t& pos_begin, uint32_t& pos_end) {
+    const auto& m = s->vf_meta_sorted;  // row r <=> metadata r + 1
+    pos_begin = (uint32_t)(std::lower_bound(m.begin(), m.end(), row_begin + 1u) - m.begin());
+    pos_end = (uint32_t)(std::lower_bound(m.begin(), m.end(), row_end + 1u) - m.begin());
+}
+
 void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end,
                             uint32_t ray_begin, uint32_t ray_end, uint32_t* d_matrix, uint64_t row_stride, uint64_t col_stride,
                             uint32_t row_offset, uint32_t flags, hipStream_t stream) {
@@ -479,22 +504,9 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     if (src_begin >= src_end || ray_begin >= ray_end) return;
     check_buffer_range(s);
     uint64_t total = (uint64_t)(src_end - src_begin) * (ray_end - ray_begin);
-    RcLaunchGuard launch(s, stream);  // also covers the one-off construction of the metadata order below
-    const uint32_t* order = nullptr;
-    if (flags & 2u) {  // RC_VF_SOURCES_BY_METADATA: the flat primitives' indices sorted by (metadata, index), cached until the next rebuild
-        if (!s->vf_order_valid) {
-            const uint32_t np = s->n_flat_prims;
-            s->keys_a.reserve(np); s->keys_b.reserve(np); s->vals_a.reserve(np); s->vf_order.reserve(np);
-            hipLaunchKernelGGL(k_meta_keys, dim3((np + 255) / 256), dim3(256), 0, stream, s->flat_prims.p, np, s->keys_a.p, s->vals_a.p);
-            size_t tmp = 0;
-            RC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vf_order.p, (int)np, 0, 32, stream));
-            s->sort_tmp.reserve(tmp ? tmp : 1);
-            RC_HIP(hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, tmp, s->keys_a.p, s->keys_b.p, s->vals_a.p, s->vf_order.p, (int)np, 0, 32, stream));  // stable: ties keep the flat order
-            RC_HIP(hipStreamSynchronize(stream));  // the scratch arrays are shared with the builds on the scene's own stream
-            s->vf_order_valid = true;
-        }
-        order = s->vf_order.p;
-    }
+    if (flags & 2u) rc_ensure_vf_order(s);  // RC_VF_SOURCES_BY_METADATA
+    const uint32_t* order = (flags & 2u) ? s->vf_order.p : nullptr;
+    RcLaunchGuard launch(s, stream);
     const bool partial = rc_partial_driver_ok(s);
     const bool lds = partial || rc_lds_driver_ok(s);
     const uint32_t bs = lds ? (uint32_t)kMidBlock : (uint32_t)kBlock;

@@ -99,6 +99,7 @@ struct TraceOptions {
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
     int64_t host_pipeline = 1; // host-buffer trace calls of >= 1 Mi rays overlap upload / trace / download in chunks
     int64_t claim_shards = 16; // phased kernels: chunk counters in use (a power of two <= kClaimShards)
+    int64_t vf_chunk_bytes = 192 << 20;  // host-matrix view factors (rc_multi.hip): device block per row chunk -- large enough for full-rate launches and 2-D copies, small enough that the exposed first trace / last copy are a few ms
     int64_t timeline_ptr = 0;  // dev: device address of 8 x u64 per wave (n_cus x 24 waves) that kernel 5 fills with its waves' event times; 0 = off
 };
 
@@ -195,6 +196,7 @@ struct rc_scene {
     std::mutex ctx_mu;
     std::condition_variable ctx_cv;
     std::vector<std::unique_ptr<CallCtx>> call_ctx;
+    hipStream_t aux_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // rc_multi.hip: two compute streams, a copy stream, a communication stream (created on first use)
     std::mutex host_call_mu;          // the other host-buffer entry points (illumination, view factors, collisions, exports) run one at a time
 
     DevBuf<float> f32_stage;
@@ -206,6 +208,7 @@ struct rc_scene {
     DevBuf<float> flat_attrs;         // 15 floats per flat primitive (normals 9, uv 6), built on demand after a rebuild
     bool flat_attrs_valid = false;
     DevBuf<uint32_t> vf_order;        // flat primitive indices by ascending metadata (RC_VF_SOURCES_BY_METADATA), built on demand after a rebuild
+    std::vector<uint32_t> vf_meta_sorted;  // the metadata in that order (host): which source positions fall into a range of matrix rows
     bool vf_order_valid = false;
     DevBuf<uint32_t> compact_flags, compact_pos;  // rc_compact_hits scratch
     DevBuf<unsigned char> compact_tmp;
@@ -290,6 +293,11 @@ void rc_timing_scene_end(rc_scene* s, hipStream_t stream);
 void rc_timing_fixed(rc_scene* s, float ms);
 float rc_timing_read(rc_scene* s);  // the calling thread's latest timed operation on the scene, else the scene's latest
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items);
+void rc_ensure_vf_order(rc_scene* s);  // builds vf_order / vf_meta_sorted if the scene has been rebuilt since
+void rc_vf_source_range(rc_scene* s, uint32_t row_begin, uint32_t row_end, uint32_t& pos_begin, uint32_t& pos_end);  // positions in the metadata order whose metadata - 1 is in [row_begin, row_end)
+// rc_multi.hip
+float rc_view_factors_rows_to_host(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t row_begin, uint32_t row_end, uint32_t* out, uint64_t ld);
+void rc_view_factors_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out, int mode);
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream);
 void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float* d_points, float* d_normals, hipStream_t stream);
 void rc_launch_shadow_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, const float light[3], float bias, RcRay* d_out, hipStream_t stream);

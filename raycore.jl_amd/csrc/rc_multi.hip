@@ -1,0 +1,342 @@
+// rc_multi.hip -- view_factors into the caller's HOST matrix, on one device or on several, behind the C ABI.
+//
+// view_factors(tlas; rays_per_triangle) returns a host Matrix{UInt32}, column-major, result[src_meta, hit_meta] (src/kernels.jl:74-104).
+// At BASELINE config C5 that matrix is 10 GB: one device traces the 204.9 M rays in 41 ms, and moving the result over one PCIe link
+// (56 GB/s on this box) takes 180 ms -- the copy, not the tracing, is what the API's caller waits for.  So:
+//
+//  * the job runs in ROW CHUNKS: a chunk's rows are traced into a small device block (column-major inside, ld = rows of the chunk)
+//    while the previous chunk's block travels to the host matrix as one 2-D copy (N pieces of rows*4 bytes, N*4 bytes apart), on
+//    alternating compute streams and one copy stream -- the tracing hides entirely inside the transfer, and no N x N device matrix
+//    (nor its 10 GB zero fill) exists;
+//  * with several devices (one process, one scene per device, built from the same geometry), mode ROWS gives every device a block of
+//    matrix rows and lets it copy its chunks straight into the caller's matrix over ITS OWN PCIe link -- G links in parallel, no xGMI
+//    traffic, no collective; mode RAYS is the partition BASELINE's north star names: every device shoots rays_per_triangle / G rays of
+//    every source into a full accumulator, row chunks are summed into device 0 by RCCL (ncclReduce, ncclUint32, called directly:
+//    librccl is loaded at first use) over xGMI while the next chunk is traced, and device 0 copies them out.
+//
+// Philox is keyed by (seed; ray index, source primitive), so every partition produces the same matrix bit for bit.
+// Reference: src/kernels.jl:74-104; SURVEY.md 8b / 8e.
+#include <dlfcn.h>
+#include <sys/mman.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+#include "../../include/raycore_mi355x.h"
+#include "rc_internal.h"
+
+namespace {
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23  // Linux 5.14+
+#endif
+// A fresh N x N matrix (zeros(UInt32, N, N), np.zeros) has no pages yet; faulting 10 GB in from inside the copy path costs seconds.
+// Ask the kernel for the range up front, in parallel slices (best effort: EINVAL on old kernels leaves the faults to the copies).
+void populate_parallel(void* p, size_t bytes) {
+    const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p) & ~(page - 1), b = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
+    const size_t total = b - a;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, total >> 28));  // one thread per 256 MB, at most 16
+    if (nt <= 1) { (void)madvise(reinterpret_cast<void*>(a), total, MADV_POPULATE_WRITE); return; }
+    std::vector<std::thread> th;
+    const size_t slice = ((total / nt) + page - 1) & ~(size_t)(page - 1);
+    for (unsigned i = 0; i < nt; ++i) {
+        const size_t off = (size_t)i * slice;
+        if (off >= total) break;
+        const size_t len = std::min(slice, total - off);
+        th.emplace_back([=] { (void)madvise(reinterpret_cast<void*>(a + off), len, MADV_POPULATE_WRITE); });
+    }
+    for (auto& t : th) t.join();
+}
+
+uint32_t chunk_rows_for(rc_scene* s, uint32_t n_cols, uint32_t rows) {  // option "vf_chunk_bytes"
+    uint64_t c = (uint64_t)s->opt.vf_chunk_bytes / ((uint64_t)n_cols * 4u);
+    if (c >= 64) c &= ~63ull;  // whole 256-byte pieces per column
+    if (c < 1) c = 1;
+    return (uint32_t)std::min<uint64_t>(c, rows);
+}
+
+void status_check(rc_scene* s) {  // after the job's streams have drained
+    uint32_t st = 0;
+    RC_HIP(hipMemcpy(&st, rc_status_word(s), 4, hipMemcpyDeviceToHost));
+    if (st) {
+        RC_HIP(hipMemset(rc_status_word(s), 0, 4));
+        throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels)");
+    }
+}
+
+// Streams, events and device blocks of one device's share of a job.
+struct DeviceJob {
+    rc_scene* s = nullptr;
+    hipStream_t compute[2] = {nullptr, nullptr}, copy = nullptr, comm = nullptr;
+    static constexpr int kBlocks = 3;
+    DevBuf<uint32_t> block[kBlocks];
+    hipEvent_t traced[kBlocks] = {}, copied[kBlocks] = {};
+    bool copied_valid[kBlocks] = {};
+    hipEvent_t t_begin = nullptr, t_end = nullptr;
+    void open(rc_scene* scene) {
+        s = scene;
+        RC_HIP(hipSetDevice(s->device));
+        // the scene's own auxiliary streams, created once: every stream that launches a traversal gets a stack spill region of its own
+        // (RcLaunchGuard), so per-call streams would churn through those
+        for (auto& a : s->aux_streams) if (!a) RC_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        compute[0] = s->aux_streams[0]; compute[1] = s->aux_streams[1]; copy = s->aux_streams[2]; comm = s->aux_streams[3];
+        for (int i = 0; i < kBlocks; ++i) {
+            RC_HIP(hipEventCreateWithFlags(&traced[i], hipEventDisableTiming));
+            RC_HIP(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+        }
+        RC_HIP(hipEventCreate(&t_begin));
+        RC_HIP(hipEventCreate(&t_end));
+    }
+    ~DeviceJob() {
+        if (!s) return;
+        (void)hipSetDevice(s->device);
+        for (auto c : compute) if (c) (void)hipStreamSynchronize(c);  // (an error path may leave work in flight that uses this job's blocks and events)
+        if (copy) (void)hipStreamSynchronize(copy);
+        if (comm) (void)hipStreamSynchronize(comm);
+        for (int i = 0; i < kBlocks; ++i) { if (traced[i]) (void)hipEventDestroy(traced[i]); if (copied[i]) (void)hipEventDestroy(copied[i]); }
+        if (t_begin) (void)hipEventDestroy(t_begin);
+        if (t_end) (void)hipEventDestroy(t_end);
+    }
+};
+
+}  // namespace
+
+// Rows [row_begin, row_end) of the view-factor matrix into a host column-major matrix with leading dimension ld (element (r, c) at
+// out[r + ld * c], all n_prims columns): chunks of rows are traced into device blocks on alternating streams -- the tail of one
+// chunk's launch overlaps the next chunk's bulk -- and each finished block leaves as one 2-D copy on the copy stream while the
+// following chunks are traced.  Blocks the calling thread until the rows are in `out`.
+float rc_view_factors_rows_to_host(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t row_begin, uint32_t row_end, uint32_t* out, uint64_t ld) {
+    RC_HIP(hipSetDevice(s->device));
+    const uint32_t n = s->n_flat_prims;
+    if (row_end > n) row_end = n;
+    if (row_begin >= row_end || n == 0) return 0.f;
+    rc_ensure_vf_order(s);
+    const uint32_t rows = row_end - row_begin, C = chunk_rows_for(s, n, rows);
+    const uint32_t n_chunks = (rows + C - 1) / C;
+    DeviceJob job;
+    job.open(s);
+    for (int i = 0; i < DeviceJob::kBlocks && (uint32_t)i < n_chunks; ++i) job.block[i].reserve((size_t)C * n);
+    auto chunk_range = [&](uint32_t k, uint32_t& r0, uint32_t& r1) { r0 = row_begin + k * C; r1 = std::min(row_end, r0 + C); };
+    auto enqueue_trace = [&](uint32_t k) {
+        uint32_t r0, r1; chunk_range(k, r0, r1);
+        const int b = (int)(k % DeviceJob::kBlocks);
+        hipStream_t cs = job.compute[k & 1];
+        if (job.copied_valid[b]) RC_HIP(hipStreamWaitEvent(cs, job.copied[b], 0));  // the block's previous chunk has left
+        if (k == 0) RC_HIP(hipEventRecord(job.t_begin, cs));
+        RC_HIP(hipMemsetAsync(job.block[b].p, 0, sizeof(uint32_t) * (size_t)(r1 - r0) * n, cs));
+        uint32_t p0, p1;
+        rc_vf_source_range(s, r0, r1, p0, p1);  // the sources whose metadata - 1 lies in [r0, r1): a contiguous range of the metadata order
+        if (p1 > p0)
+            rc_launch_view_factors(s, rays_per_triangle, seed, p0, p1, 0, rays_per_triangle, job.block[b].p, 1, (uint64_t)(r1 - r0), r0,
+                                   RC_VF_SOURCES_BY_METADATA | RC_VF_ROW_BY_METADATA_VALUE, cs);
+        RC_HIP(hipEventRecord(job.traced[b], cs));
+    };
+    auto enqueue_copy = [&](uint32_t k) {  // may block the host until the copy is done when `out` is pageable: enqueue the next chunk's trace first
+        uint32_t r0, r1; chunk_range(k, r0, r1);
+        const int b = (int)(k % DeviceJob::kBlocks);
+        RC_HIP(hipStreamWaitEvent(job.copy, job.traced[b], 0));
+        RC_HIP(hipMemcpy2DAsync(out + r0, ld * 4u, job.block[b].p, (size_t)(r1 - r0) * 4u, (size_t)(r1 - r0) * 4u, n, hipMemcpyDeviceToHost, job.copy));
+        RC_HIP(hipEventRecord(job.copied[b], job.copy));
+        job.copied_valid[b] = true;
+    };
+    enqueue_trace(0);
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        if (k + 1 < n_chunks) enqueue_trace(k + 1);
+        enqueue_copy(k);
+    }
+    RC_HIP(hipEventRecord(job.t_end, job.copy));
+    RC_HIP(hipStreamSynchronize(job.copy));
+    RC_HIP(hipStreamSynchronize(job.compute[0]));
+    RC_HIP(hipStreamSynchronize(job.compute[1]));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, job.t_begin, job.t_end) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }  // first trace to last copy, on the device's clock
+    status_check(s);
+    return ms;
+}
+
+// ---- RCCL, called directly (no torch): loaded at first use so that the library itself has no link-time dependency on it ----------------
+namespace {
+typedef struct ncclComm* ncclComm_t;
+struct Rccl {
+    void* handle = nullptr;
+    int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclUint32 = 3, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;  // one communicator set per device list, kept for the life of the process
+
+Rccl& rccl() {
+    if (g_rccl.handle) return g_rccl;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.handle) break;
+    }
+    if (!g_rccl.handle) throw RcError(RC_ERR_HIP, std::string("RC_VF_MODE_RAYS needs RCCL and librccl.so could not be loaded: ") + dlerror());
+    auto sym = [&](const char* n) { void* p = dlsym(g_rccl.handle, n); if (!p) throw RcError(RC_ERR_HIP, std::string("librccl.so lacks ") + n); return p; };
+    g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(sym("ncclCommInitAll"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+    g_rccl.Reduce = reinterpret_cast<decltype(g_rccl.Reduce)>(sym("ncclReduce"));
+    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(sym("ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+    return g_rccl;
+}
+void nccl_ok(int rc, const char* what) {
+    if (rc != 0) throw RcError(RC_ERR_HIP, std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+}
+
+void check_same_geometry(rc_scene* const* scenes, int n) {
+    for (int g = 0; g < n; ++g) {
+        rc_scene* s = scenes[g];
+        if (!s) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+        if (!s->has_static || s->dirty || s->transforms_dirty) throw RcError(RC_ERR_NOT_SYNCED, "scene has pending mutations: call rc_sync first");
+        if (s->n_flat_prims != scenes[0]->n_flat_prims || s->n_flat_nodes != scenes[0]->n_flat_nodes || s->n_static_instances != scenes[0]->n_static_instances ||
+            memcmp(s->root_min, scenes[0]->root_min, 12) != 0 || memcmp(s->root_max, scenes[0]->root_max, 12) != 0)
+            throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_view_factors_multi: the scenes must hold the same geometry (one copy per device)");
+    }
+}
+}  // namespace
+
+// ROWS: device g owns matrix rows [g N / G, (g + 1) N / G) and brings them home over its own PCIe link; one host thread per device.
+static void multi_rows(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out) {
+    const uint32_t n = scenes[0]->n_flat_prims;
+    std::vector<std::thread> th;
+    std::vector<std::string> err(n_scenes);
+    std::vector<int> code(n_scenes, 0);
+    std::vector<float> ms(n_scenes, 0.f);
+    for (int g = 0; g < n_scenes; ++g) {
+        const uint32_t r0 = (uint32_t)((uint64_t)n * g / n_scenes), r1 = (uint32_t)((uint64_t)n * (g + 1) / n_scenes);
+        th.emplace_back([=, &err, &code, &ms] {
+            try {
+                ms[g] = rc_view_factors_rows_to_host(scenes[g], rays_per_triangle, seed, r0, r1, out, n);
+            } catch (const RcError& e) { err[g] = e.what(); code[g] = e.code; }
+            catch (const std::exception& e) { err[g] = e.what(); code[g] = RC_ERR_INVALID_ARGUMENT; }
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < n_scenes; ++g)
+        if (code[g]) throw RcError(code[g], "device " + std::to_string(scenes[g]->device) + ": " + err[g]);
+    for (int g = n_scenes - 1; g >= 0; --g) rc_timing_fixed(scenes[g], ms[g]);  // on the CALLING thread (rc_last_kernel_ms is per thread); scenes[0] last
+}
+
+// RAYS: device g shoots ray indices [g R / G, (g + 1) R / G) of EVERY source into a full accumulator (row chunks stored one after the
+// other, column-major inside a chunk); chunk k is summed into device 0 by ncclReduce on the communication streams as soon as every
+// device has traced it -- while chunk k + 1 is being traced -- and leaves device 0 on its copy stream.
+static void multi_rays(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out) {
+    const uint32_t n = scenes[0]->n_flat_prims;
+    std::vector<int> devs(n_scenes);
+    for (int g = 0; g < n_scenes; ++g) devs[g] = scenes[g]->device;
+    {
+        std::vector<int> sorted = devs;
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            throw RcError(RC_ERR_INVALID_ARGUMENT, "RC_VF_MODE_RAYS reduces over RCCL, which needs one DISTINCT device per scene (use RC_VF_MODE_ROWS for several scenes on one device)");
+    }
+    std::vector<ncclComm_t> comms;
+    {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        Rccl& r = rccl();
+        auto it = g_comms.find(devs);
+        if (it == g_comms.end()) {
+            std::vector<ncclComm_t> fresh(n_scenes);
+            nccl_ok(r.CommInitAll(fresh.data(), n_scenes, devs.data()), "ncclCommInitAll");
+            it = g_comms.emplace(devs, fresh).first;
+        }
+        comms = it->second;
+    }
+    const uint32_t C = chunk_rows_for(scenes[0], n, n), n_chunks = (n + C - 1) / C;
+    std::vector<DeviceJob> jobs(n_scenes);
+    std::vector<DevBuf<uint32_t>> acc(n_scenes);
+    std::vector<std::vector<hipEvent_t>> traced(n_scenes);
+    std::vector<hipEvent_t> reduced(n_chunks, nullptr);
+    struct EventBin { std::vector<std::pair<int, hipEvent_t>> ev; ~EventBin() { for (auto& e : ev) { (void)hipSetDevice(e.first); (void)hipEventDestroy(e.second); } } } bin;
+    for (int g = 0; g < n_scenes; ++g) {
+        jobs[g].open(scenes[g]);
+        rc_ensure_vf_order(scenes[g]);
+        acc[g].reserve((size_t)n * n);
+        traced[g].resize(n_chunks);
+        for (uint32_t k = 0; k < n_chunks; ++k) { RC_HIP(hipEventCreateWithFlags(&traced[g][k], hipEventDisableTiming)); bin.ev.emplace_back(scenes[g]->device, traced[g][k]); }
+    }
+    RC_HIP(hipSetDevice(scenes[0]->device));
+    for (uint32_t k = 0; k < n_chunks; ++k) { RC_HIP(hipEventCreateWithFlags(&reduced[k], hipEventDisableTiming)); bin.ev.emplace_back(scenes[0]->device, reduced[k]); }
+    auto chunk_range = [&](uint32_t k, uint32_t& r0, uint32_t& r1) { r0 = k * C; r1 = std::min(n, r0 + C); };
+    auto enqueue_trace = [&](uint32_t k) {
+        uint32_t r0, r1; chunk_range(k, r0, r1);
+        for (int g = 0; g < n_scenes; ++g) {
+            rc_scene* s = scenes[g];
+            RC_HIP(hipSetDevice(s->device));
+            hipStream_t cs = jobs[g].compute[k & 1];
+            if (k == 0 && g == 0) RC_HIP(hipEventRecord(jobs[0].t_begin, cs));
+            uint32_t* blk = acc[g].p + (size_t)r0 * n;
+            RC_HIP(hipMemsetAsync(blk, 0, sizeof(uint32_t) * (size_t)(r1 - r0) * n, cs));
+            uint32_t p0, p1;
+            rc_vf_source_range(s, r0, r1, p0, p1);
+            const uint32_t q0 = (uint32_t)((uint64_t)rays_per_triangle * g / n_scenes), q1 = (uint32_t)((uint64_t)rays_per_triangle * (g + 1) / n_scenes);
+            if (p1 > p0 && q1 > q0)
+                rc_launch_view_factors(s, rays_per_triangle, seed, p0, p1, q0, q1, blk, 1, (uint64_t)(r1 - r0), r0, RC_VF_SOURCES_BY_METADATA | RC_VF_ROW_BY_METADATA_VALUE, cs);
+            RC_HIP(hipEventRecord(traced[g][k], cs));
+        }
+    };
+    auto enqueue_reduce = [&](uint32_t k) {
+        uint32_t r0, r1; chunk_range(k, r0, r1);
+        Rccl& r = rccl();
+        for (int g = 0; g < n_scenes; ++g) {
+            RC_HIP(hipSetDevice(scenes[g]->device));
+            RC_HIP(hipStreamWaitEvent(jobs[g].comm, traced[g][k], 0));
+        }
+        nccl_ok(r.GroupStart(), "ncclGroupStart");
+        for (int g = 0; g < n_scenes; ++g) {
+            uint32_t* blk = acc[g].p + (size_t)r0 * n;
+            nccl_ok(r.Reduce(blk, blk, (size_t)(r1 - r0) * n, kNcclUint32, kNcclSum, 0, comms[g], jobs[g].comm), "ncclReduce");
+        }
+        nccl_ok(r.GroupEnd(), "ncclGroupEnd");
+        RC_HIP(hipSetDevice(scenes[0]->device));
+        RC_HIP(hipEventRecord(reduced[k], jobs[0].comm));
+    };
+    auto enqueue_copy = [&](uint32_t k) {  // may block the host while the chunk travels (pageable `out`): the next chunk's trace and reduce are enqueued first
+        uint32_t r0, r1; chunk_range(k, r0, r1);
+        RC_HIP(hipSetDevice(scenes[0]->device));
+        RC_HIP(hipStreamWaitEvent(jobs[0].copy, reduced[k], 0));
+        RC_HIP(hipMemcpy2DAsync(out + r0, (size_t)n * 4u, acc[0].p + (size_t)r0 * n, (size_t)(r1 - r0) * 4u, (size_t)(r1 - r0) * 4u, n, hipMemcpyDeviceToHost, jobs[0].copy));
+    };
+    enqueue_trace(0);
+    enqueue_reduce(0);
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        if (k + 1 < n_chunks) { enqueue_trace(k + 1); enqueue_reduce(k + 1); }
+        enqueue_copy(k);
+    }
+    RC_HIP(hipSetDevice(scenes[0]->device));
+    RC_HIP(hipEventRecord(jobs[0].t_end, jobs[0].copy));
+    RC_HIP(hipStreamSynchronize(jobs[0].copy));
+    for (int g = 0; g < n_scenes; ++g) {
+        RC_HIP(hipSetDevice(scenes[g]->device));
+        RC_HIP(hipStreamSynchronize(jobs[g].comm));
+        RC_HIP(hipStreamSynchronize(jobs[g].compute[0]));
+        RC_HIP(hipStreamSynchronize(jobs[g].compute[1]));
+        status_check(scenes[g]);
+    }
+    RC_HIP(hipSetDevice(scenes[0]->device));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, jobs[0].t_begin, jobs[0].t_end) == hipSuccess) rc_timing_fixed(scenes[0], ms);
+}
+
+void rc_view_factors_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out, int mode) {
+    if (n_scenes < 1 || !scenes) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_view_factors_multi: no scenes");
+    if (mode != RC_VF_MODE_ROWS && mode != RC_VF_MODE_RAYS) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_view_factors_multi: mode must be RC_VF_MODE_ROWS or RC_VF_MODE_RAYS");
+    check_same_geometry(scenes, n_scenes);
+    const uint64_t n = scenes[0]->n_flat_prims;
+    if (n == 0) return;
+    struct DeviceRestore { int dev = 0; DeviceRestore() { (void)hipGetDevice(&dev); } ~DeviceRestore() { (void)hipSetDevice(dev); } } restore;  // the caller's current device is the caller's
+    populate_parallel(out, n * n * 4u);
+    if (mode == RC_VF_MODE_ROWS) multi_rows(scenes, n_scenes, rays_per_triangle, seed, out);
+    else multi_rays(scenes, n_scenes, rays_per_triangle, seed, out);
+}

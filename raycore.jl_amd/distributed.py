@@ -148,6 +148,67 @@ def view_factors_distributed(tlas, rays_per_triangle=10000, seed=0, mode="rows",
     return local.view(n, n) if me == dst else None
 
 
+def _populate(base, byte_range, n_threads):
+    """MADV_POPULATE_WRITE (Linux 5.14+) over [base + a, base + b), page aligned, split over n_threads; best effort."""
+    import ctypes
+    import threading
+    a, b = byte_range
+    a -= (base + a) % 4096
+    if b <= a:
+        return
+    try:
+        libc = ctypes.CDLL(None, use_errno=True)
+        libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    except (OSError, AttributeError):
+        return
+    step = -(-(b - a) // n_threads)
+    step += -step % 4096
+    ths = [threading.Thread(target=libc.madvise, args=(base + s, min(step, b - s), 23)) for s in range(a, b, step)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+
+
+def view_factors_host_matrix(tlas, rays_per_triangle=10000, seed=0, group=None, dst=0, n_prims=None, compute_rows=None):
+    """view_factors as the API returns it -- a HOST N x N uint32 matrix, column-major (src/kernels.jl:74-78) -- from one process per GPU:
+    rank `dst` creates the matrix in shared memory (/dev/shm), every rank maps it and brings ITS block of rows home over its own PCIe
+    link (rc_view_factors_rows_host: row chunks traced while the finished ones are copied), so G links run in parallel, nothing
+    crosses xGMI and the only collective is the barrier at the end.  This is the partition that serves the API's return value: at
+    C5 the matrix is 10 GB -- 0.18 s over one link, whatever the tracing costs -- against 23 ms per rank with eight.
+    Returns the matrix (a np.memmap, order F; the file is already unlinked) on `dst`, None elsewhere.
+    compute_rows(out, (r0, r1)): stand-in for the device call in the CPU tests (fills rows [r0, r1) of `out`)."""
+    import os
+    dist = _dist()
+    world, rank, me = _ranks(group)
+    n = int(n_prims if n_prims is not None else tlas.n_primitives())
+    name = [None]
+    if me == dst:
+        name[0] = f"/dev/shm/raycore_vf_{os.getpid()}_{np.random.default_rng().integers(1 << 62):x}"
+        with open(name[0], "wb") as f:
+            f.truncate(max(1, 4 * n * n))
+    if world > 1:
+        dist.broadcast_object_list(name, src=dst, group=group)
+    out = np.memmap(name[0], dtype=np.uint32, mode="r+", shape=(n, n), order="F")
+    try:
+        # fault the pages in before the copies arrive: every rank its own slice of the file, a few threads per rank (shared-memory pages
+        # cost ~0.15 s per GB to allocate from one thread; ctypes releases the GIL during the madvise calls)
+        _populate(out.ctypes.data, shard_range(4 * n * n, rank, world), max(1, min(8, (os.cpu_count() or 8) // max(world, 1))))
+        if world > 1:
+            dist.barrier(group=group)
+        r0, r1 = shard_range(n, rank, world)
+        if compute_rows is not None:
+            compute_rows(out, (r0, r1))
+        else:
+            check(lib().rc_view_factors_rows_host(tlas._h, int(rays_per_triangle), int(seed), r0, r1, out.ctypes.data_as(_capi.C.c_void_p), n))
+        if world > 1:
+            dist.barrier(group=group)
+    finally:
+        if me == dst:
+            os.unlink(name[0])  # the mapping keeps the pages alive
+    return out if me == dst else None
+
+
 def _view_factors_general(dist, group, world, rank, me, dst, mode, n, rpt, compute, device, meta):
     """Metadata with duplicates or gaps: rows cannot be addressed by metadata position, so rows travel in primitive order and the
     root folds them by metadata with one index_add (duplicates accumulate, as result[src_meta, :] does in the reference)."""

@@ -216,6 +216,30 @@ function Raycore.view_factors(a::MI355XStaticTLAS; rays_per_triangle = 10000, se
     check(ccall((:rc_view_factors, LIB), Cint, (Ptr{Cvoid}, UInt32, UInt64, Ptr{UInt32}), a.owner.ptr, rays_per_triangle, seed, out))
     return out
 end
+"""
+    view_factors(accels::Vector{MI355XStaticTLAS}; rays_per_triangle, seed, mode = :rows) -> Matrix{UInt32}
+
+view_factors sharded over the GPUs of one node (SURVEY.md 8e): `accels[g]` is the adapted accel of a TLAS built from the same meshes on
+device g.  `mode = :rows`: accel g traces matrix rows [gN/G, (g+1)N/G) and copies its chunks straight into the result over its own PCIe
+link (no xGMI traffic, no collective); `mode = :rays`: every device shoots rays_per_triangle / G rays of every source and the row chunks
+are summed on accels[1]'s device by RCCL `ncclReduce` over xGMI while the next chunk is traced.  Same matrix as the single-device call,
+bit for bit (Philox keyed by ray index and source primitive).
+"""
+function Raycore.view_factors(accels::Vector{MI355XStaticTLAS}; rays_per_triangle = 10000, seed::UInt64 = rand(UInt64), mode::Symbol = :rows)
+    n = counts(accels[1].owner)[4]
+    out = Matrix{UInt32}(undef, n, n)
+    ptrs = Ptr{Cvoid}[a.owner.ptr for a in accels]
+    GC.@preserve accels check(ccall((:rc_view_factors_multi, LIB), Cint, (Ptr{Ptr{Cvoid}}, Cint, UInt32, UInt64, Ptr{UInt32}, Cint),
+                                    ptrs, length(ptrs), rays_per_triangle, seed, out, mode === :rays ? 1 : 0))
+    return out
+end
+"Rows [row_begin, row_end) (0-based, end exclusive) of the matrix into `out` (column-major, any leading dimension >= N): the unit of a
+multi-process run, where every process maps the same shared-memory matrix (`Mmap.mmap` of a file in /dev/shm) and fills its own rows."
+function view_factors_rows!(out::AbstractMatrix{UInt32}, a::MI355XStaticTLAS, row_begin::Integer, row_end::Integer; rays_per_triangle = 10000, seed::UInt64)
+    check(ccall((:rc_view_factors_rows_host, LIB), Cint, (Ptr{Cvoid}, UInt32, UInt64, UInt32, UInt32, Ptr{UInt32}, UInt64),
+                a.owner.ptr, rays_per_triangle, seed, row_begin, row_end, out, stride(out, 2)))
+    return out
+end
 
 # the reference's RayHit (src/kernels.jl:1-5)
 struct RayHit{T}
@@ -464,14 +488,16 @@ function MI355XTLAS(items::AbstractVector, metadata_fn::Function; backend::MI355
     for (mi, item) in enumerate(items)
         mesh = item isa GeometryBasics.Mesh ? item : GeometryBasics.uv_normal_mesh(item)
         d = decomposed(mesh)
-        words = Vector{UInt32}(undef, d.nv)     # rc_add_mesh reads metadata per VERTEX of the face-view-expanded mesh: the face's first vertex carries it
+        # ONE WORD PER FACE (rc_add_mesh_face_metadata): faces of a face-view-expanded mesh share vertices -- the two triangles of a quad
+        # (a, b, c), (a, c, d) share their first vertex -- so a per-vertex array (what rc_add_mesh reads, the push! path's face_meta)
+        # cannot carry metadata_fn(mi, fi); the reference calls it per face (:2300-2306)
+        words = Vector{UInt32}(undef, d.nf)
         for fi in 1:d.nf
             m = metadata_fn(mi, fi)
-            w = T === UInt32 ? m : (push!(t.meta_table, m); UInt32(length(t.meta_table)))
-            words[d.indices[3 * (fi - 1) + 1] + 1] = w
+            words[fi] = T === UInt32 ? m : (push!(t.meta_table, m); UInt32(length(t.meta_table)))
         end
         blas = Ref{UInt32}(0); handle = Ref{UInt32}(0)
-        check(ccall((:rc_add_mesh, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{UInt32}, Ref{UInt32}),
+        check(ccall((:rc_add_mesh_face_metadata, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, UInt32, Ptr{UInt32}, UInt32, Ptr{UInt32}, Ref{UInt32}),
                     t.ptr, d.verts, d.normals, d.uvs === nothing ? C_NULL : d.uvs, d.nv, d.indices, d.nf, words, blas))
         check(ccall((:rc_add_instances_with_inverse, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{Float32}, Ptr{Float32}, Ptr{UInt32}, UInt32, Ref{UInt32}),
                     t.ptr, blas[], ident, ident, UInt32[mi], 1, handle))                          # identity for both matrices, :2314-2320

@@ -61,6 +61,16 @@ def _worker(rank, world, port, mode, q, variant="plain"):
             out = rd.view_factors_distributed(None, rpt, seed, mode=mode, n_prims=n, compute=compute, device=torch.device("cpu"), prim_meta=meta,
                                               group=group, dst=dst, chunks=5 if mode == "rays" else None)
             res = None if out is None else out.numpy().view(np.uint32).copy()
+        elif mode == "host_matrix":
+            def compute_rows(out, rng):
+                """Stand-in for rc_view_factors_rows_host: matrix rows [r0, r1) of the shared host matrix (column-major), from the oracle."""
+                for prim in range(n):
+                    r = int(meta[prim]) - 1
+                    if rng[0] <= r < rng[1]:
+                        out[r, :] += o.view_factor_row(rpt, int(prim), seed=seed)
+            out = rd.view_factors_host_matrix(None, rpt, seed, n_prims=n, compute_rows=compute_rows)
+            res = None if out is None else np.array(out)  # a copy: the mapping dies with the worker
+            assert out is None or (out.flags["F_CONTIGUOUS"] and not [f for f in os.listdir("/dev/shm") if f.startswith(f"raycore_vf_{os.getpid()}_")])
         elif mode == "rows_sharded":
             block, rows = rd.view_factors_distributed(None, rpt, seed, mode=mode, n_prims=n, compute=compute, device=torch.device("cpu"), prim_meta=meta)
             res = (block.numpy().view(np.uint32).copy(), rows)
@@ -172,6 +182,16 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0
+
+
+def test_host_matrix_in_shared_memory_world2(oracle):
+    """view_factors_host_matrix: rank 0 creates the N x N host matrix in /dev/shm, both ranks map it and fill their own rows (here the
+    oracle stands in for rc_view_factors_rows_host), barrier, the file is unlinked; rank 0 holds the reference's column-major matrix."""
+    import raycore_jl_amd as rc
+    results = _run(2, "host_matrix", "plain", 30)
+    o, n = _scene(oracle, rc)
+    assert results[1] is None
+    assert np.array_equal(results[0], o.view_factors(64, seed=99)) and results[0].sum() > 0
 
 
 def test_shard_range_covers_everything():

@@ -200,7 +200,9 @@ def test_generic_triangle_metadata(rc, oracle):
     assert acc_u._owner.eltype() == ("Triangle", np.uint32)
     miss = rc.closest_hit(acc, rc.Ray((9.0, 9.0, -3.0), (0.0, 0.0, 1.0)))
     assert not miss[0] and miss[4] == 0
-    grid, typed = rc.hits_from_grid(acc, (0.0, 0.0, 1.0), grid_size=16)
+    grid = rc.hits_from_grid(acc, (0.0, 0.0, 1.0), grid_size=16)   # one return type whatever the metadata type
+    assert isinstance(grid, np.ndarray) and grid.dtype == rc.RAYHIT_DT
+    typed = rc.typed_hit_metadata(acc, grid)
     assert grid["hit"].any() and all((typed[i] is not None) == bool(grid["hit"][i]) for i in np.ndindex(grid.shape))
     pts, centre = rc.get_centroid(acc, (0.0, 0.0, 1.0), grid_size=16)
     assert len(pts) == int(grid["hit"].sum()) and np.all(np.isfinite(centre))

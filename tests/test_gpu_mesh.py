@@ -153,6 +153,71 @@ def test_scene_save_load_roundtrip(rc, oracle, tmp_path):
     (tmp_path / "bad_child.rcs").write_bytes(bytes(data))
     with pytest.raises(rc.RaycoreError, match="child index"):
         rc.TLAS.load(tmp_path / "bad_child.rcs")
+    # in-range links that do not form a tree would make a ray walk in circles for ever (a hung GPU): a node that points at itself,
+    # at its parent (the root), or two parents for one node -- all refused before anything is uploaded
+    good = bytearray(path.read_bytes())
+    root_rec = off + 24 + 24 + 40 * n_prims
+    c0 = int(np.frombuffer(good, np.uint32, 1, root_rec + 48)[0])
+    c1 = int(np.frombuffer(good, np.uint32, 1, root_rec + 52)[0])
+    inner = c0 if c0 < n_prims else c1               # an internal child of the root (node indices below n are internal)
+    assert inner < n_prims
+    inner_rec = root_rec + 64 * (inner - 1)
+    for name, where, value in (("self", inner_rec + 48, inner), ("to_root", inner_rec + 52, 1), ("two_parents", root_rec + 52, c0)):
+        data = bytearray(good)
+        data[where:where + 4] = np.uint32(value).tobytes()
+        (tmp_path / f"cycle_{name}.rcs").write_bytes(bytes(data))
+        with pytest.raises(rc.RaycoreError, match="do not form a tree"):
+            rc.TLAS.load(tmp_path / f"cycle_{name}.rcs")
+    # counts in a header are checked against the file's length before anything is allocated for them
+    data = bytearray(good)
+    data[off:off + 8] = np.array([0x10000000, 0x1FFFFFFF], np.uint32).tobytes()   # n_prims = 2^28, n_nodes = 2 n - 1: consistent, and absent
+    (tmp_path / "huge.rcs").write_bytes(bytes(data))
+    with pytest.raises(rc.RaycoreError, match="truncated"):
+        rc.TLAS.load(tmp_path / "huge.rcs")
+
+
+def test_metadata_per_face_on_shared_vertices(rc, oracle):
+    """TLAS(items, metadata_fn) evaluates metadata_fn(mesh_idx, face_idx) per FACE (src/instanced-bvh.jl:2300-2306).  On a quad mesh the
+    two triangles of a quad, (a, b, c) and (a, c, d), share their FIRST vertex, so a per-vertex metadata array (rc_add_mesh's face_meta,
+    the push! path) cannot tell them apart -- the later face overwrites the earlier one's word (the Julia wrapper did exactly
+    that).  rc_add_mesh_face_metadata carries one word per face: metadata_fn = (mi, fi) -> fi comes back as fi on every primitive."""
+    k = 9
+    gx, gy = np.meshgrid(np.arange(k + 1, dtype=np.float32), np.arange(k + 1, dtype=np.float32), indexing="ij")
+    v = np.stack([gx.ravel(), gy.ravel(), np.zeros((k + 1) ** 2, np.float32)], axis=1)
+    idx = lambda i, j: i * (k + 1) + j
+    f = []
+    for i in range(k):
+        for j in range(k):
+            a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+            f += [(a, b, c), (a, c, d)]               # both start at vertex a
+    f = np.array(f, np.uint32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (len(v), 1))
+    t = rc.TLAS()
+    b = t.add_mesh(v, f, nrm, metadata_per_face=np.arange(1, len(f) + 1, dtype=np.uint32))
+    t.push_instances(b)
+    t.sync()
+    prims = t.adapt().all_blas_prims
+    assert sorted(prims["meta"].tolist()) == list(range(1, len(f) + 1))   # every face kept its own word
+    for p in prims[:: 7]:                                                  # and it is the word of THAT face: same three vertices
+        face = f[int(p["meta"]) - 1]
+        assert np.array_equal(p["v"], v[face])
+    # a ray into the middle of each triangle of quad (3, 4) reports that triangle's face index
+    q = 2 * (3 * k + 4)
+    for fi in (q, q + 1):
+        c = v[f[fi]].mean(axis=0)
+        hit, tri, dist, bary, inst = rc.closest_hit(t, rc.Ray(o=(c[0], c[1], 1.0), d=(0.0, 0.0, -1.0)))
+        assert hit and int(tri.metadata) == fi + 1
+    # the per-vertex form on the same mesh is what loses information: the quad's two faces read the same vertex
+    words = np.zeros(len(v), np.uint32)
+    for fi in range(len(f)):
+        words[f[fi][0]] = fi + 1
+    u = rc.TLAS()
+    u.push_instances(u.add_mesh(v, f, nrm, face_meta=words))
+    u.sync()
+    assert len(set(u.adapt().all_blas_prims["meta"].tolist())) == len(f) // 2
+    with pytest.raises(ValueError):
+        t.add_mesh(v, f, nrm, face_meta=words, metadata_per_face=np.arange(len(f), dtype=np.uint32))
+    t.free(); u.free()
 
 
 def test_scene_save_load_keeps_the_lds_plan(rc, tmp_path):
