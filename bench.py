@@ -13,10 +13,11 @@ touches a GPU -- and relays rank 0's line.
 
 roofline: the dominant kernel (k_trace_phased_lds) is bound by VALU ISSUE, not by memory -- the scene is LDS / L1 / L2 resident
 and physical HBM traffic is the ray-in / hit-out stream (6 % of the HBM peak).  `achieved` = VALU wave-instructions per launch
-(SQ_INSTS_VALU from the counter file named in `roofline.sources`, collected with rocprofv3 --pmc on this kernel and workload) /
-the average launch duration measured live with HIP events on the launch stream; `peak` = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
-per wave64 VALU instruction (tools/valu_probe.hip, profiles/r02_valu_probe.txt: v_mul / v_add / v_mov 604-652 G/s, the packed-f32 and
-3-operand min / max forms the slab test is made of 500-555 G/s).  `lane_utilisation` says how many of those issue slots carry a ray.
+(SQ_INSTS_VALU from the counter file named in `roofline.sources`, collected with rocprofv3 --pmc on this kernel and workload; the file
+carries a fingerprint of the kernel sources and is ignored when it does not match) / the average launch duration measured live with HIP
+events on the launch stream; `peak` = the guide's issue peak, 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction =
+1228.8 G/s.  `mix_ceiling` = what this kernel's opcode mix could reach at the cycles measured per opcode (tools/isa_mix.py);
+`lane_utilisation` = the share of issued lane slots that carry a ray; `lane_throughput_frac` = frac x lane_utilisation.
 The figure SURVEY.md section 8d prescribes -- algorithmic bytes of the REFERENCE algorithm (32 + 32 + 60 x BVHNode2 fetches + 140 x
 TLAS-leaf entries per ray, counted by the instrumented CPU oracle in the cpu_baseline leg) against the 8 TB/s HBM peak -- is kept
 as `algorithmic_vs_hbm`: it exceeds 1 because those bytes come from LDS and caches, which is why it is not `frac`.
@@ -35,15 +36,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 4.0  # one wave64 VALU instruction per SIMD per 4 cycles: 614.4 G wave-instructions / s
-COUNTER_FILE = os.path.join("profiles", "r02_pmc_c3.json")          # per-launch PMC counters of the bench kernel (tools/capture_profiles.sh)
+# The guide's execution model: a wave64 VALU instruction issues over 2 cycles on the SIMD-32 (157.3 TF f32 vector peak):
+# 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instructions / s.  (Round 2 divided by 4 cycles -- the measured cost of v_mul / v_add /
+# v_mov -- which the builder's own probe contradicts for v_fma_f32; the per-opcode measurements now enter through `mix_ceiling`.)
+VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
+COUNTER_FILE = os.path.join("profiles", "r03_pmc_c3.json")          # per-launch PMC counters of the bench kernel (tools/capture_profiles.sh)
+MIX_FILE = os.path.join("profiles", "r03_isa_mix_kernel5.json")     # dynamic opcode histogram of the bench kernel x measured cycles per opcode (tools/isa_mix.py)
+HBM_REGIME_FILE = os.path.join("profiles", "r03_hbm_regime.json")   # tools/gpu_hbm_regime.sh
 COUNTS_FILE = os.path.join("profiles", "c3_reference_counts.json")  # reference-algorithm fetch counts per ray for this workload (written by the N=1 run)
 # Fallback when the counts file is missing (same numbers, measured by the oracle in round 1)
 C3_NODE_FETCHES_PER_RAY = 33.006
 C3_INST_ENTRIES_PER_RAY = 1.922
 
 
-def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_option=-1, profiled_config=True):
+def kernel_fingerprint():
+    """sha256 over what the dominant kernel is compiled from (the traversal core, the device records, the kernel file, the compiler
+    flags).  Stored in the counter file by tools/capture_profiles.sh, recomputed by every bench run."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "raycore.jl_amd", "csrc")
+    for name in ("rc_traverse_core.h", "rc_device.h", "rc_traverse.hip"):
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    for line in open(os.path.join(csrc, "Makefile")):
+        if line.startswith("FLAGS") or line.startswith("        -W"):
+            h.update(line.encode())
+    return {"sha256_of": "raycore.jl_amd/csrc/{rc_traverse_core.h, rc_device.h, rc_traverse.hip} + the Makefile's FLAGS", "sha256": h.hexdigest()}
+
+
+def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_option=-1, profiled_config=True, mix=None, fingerprint=None):
     """The `roofline` object of the JSON line from a launch time (ms, measured live), the reference algorithm's fetch counts per ray
     and the per-launch PMC counters of the counter file.  Pure arithmetic, so a reader can recompute every number from profiles/."""
     bytes_per_ray = 32 + 32 + 60.0 * node_f + 140.0 * inst_f
@@ -52,21 +72,38 @@ def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_
     valu = c.get("SQ_INSTS_VALU")
     traffic = (pmc.get("hbm") or {}).get("c3_closest_bytes_per_launch")
     kname = {-1: "k_trace_phased_lds<false, 768, 16, 6, false>", 5: "k_trace_phased_lds<false, 768, 16, 6, false>", 3: "k_trace_phased<false, 24, 6, false>"}.get(kernel_option, f"kernel option {kernel_option}")
-    if valu and profiled_config:
+    stale = None
+    if fingerprint is not None and (pmc.get("fingerprint") or {}).get("sha256") != fingerprint.get("sha256"):
+        stale = f"stale counters: {COUNTER_FILE} was captured from other kernel sources (fingerprint mismatch); re-run tools/capture_profiles.sh"
+    if valu and profiled_config and not stale:
         achieved = valu / (launch_ms * 1e-3) / 1e9
+        frac = achieved / VALU_PEAK_GINST_S
+        lane_util = c["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0) if c.get("SQ_THREAD_CYCLES_VALU") else None
         roofline = {"bound": "valu-issue", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s",
-                    "frac": round(achieved / VALU_PEAK_GINST_S, 4), "traffic": traffic, "kernel": kname, "avg_launch_ms": round(launch_ms, 4),
+                    "frac": round(frac, 4), "traffic": traffic, "kernel": kname, "avg_launch_ms": round(launch_ms, 4),
                     "valu_wave_instructions_per_launch": valu,
-                    "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (valu * 64.0), 4) if c.get("SQ_THREAD_CYCLES_VALU") else None,
+                    "lane_utilisation": round(lane_util, 4) if lane_util else None,
+                    # of the chip's lane-instruction throughput (64 lanes x the issue peak), the share that did work for a ray
+                    "lane_throughput_frac": round(frac * lane_util, 4) if lane_util else None,
                     "hbm_physical_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                     "vmem_wave_instructions_per_launch": c.get("SQ_INSTS_VMEM_RD"),
-                    "sources": {"valu_wave_instructions_per_launch, lane_utilisation, traffic": COUNTER_FILE + " (rocprofv3 --pmc passes over this bench command, tools/capture_profiles.sh; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md: the traffic is the coalesced ray / hit stream)",
+                    "sources": {"valu_wave_instructions_per_launch, lane_utilisation, traffic": COUNTER_FILE + " (rocprofv3 --pmc passes over this bench command, tools/capture_profiles.sh; its fingerprint matches the kernel sources of this run; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md: the traffic is the coalesced ray / hit stream)",
                                 "avg_launch_ms": "HIP events around every timed launch, this run",
-                                "peak": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction; profiles/r02_valu_probe.txt has the measured per-opcode rates",
+                                "peak": "MI355X_MICROARCH.md execution model: a wave64 VALU instruction issues over 2 cycles on the SIMD-32: 256 CUs x 4 SIMDs x 2.4 GHz / 2",
                                 "node / instance counts": counts_source}}
-    else:  # no counter file for this configuration: only the section-8d figure can be given, and it is not a utilisation
+        m = (mix or {}).get("mix")
+        if m:
+            ceiling = m["mix_ceiling_G_wave_instructions_s"]
+            roofline["mix_ceiling"] = {"G_wave_instructions_s": ceiling, "frac_of_peak": round(ceiling / VALU_PEAK_GINST_S, 4),
+                                       "average_cycles_per_valu_instruction": m["average_cycles_per_valu_instruction"],
+                                       "achieved_over_mix_ceiling": round(achieved / ceiling, 4),
+                                       "note": "the issue rate this kernel's dynamic opcode mix could reach on 1024 SIMDs at the cycles measured per opcode (v_pk_*_f32 4.9, "
+                                               "v_minimum3 / v_maximum3 4.5, compares 4.9, moves 3.8 ...); none of them issues in the guide's 2 cycles",
+                                       "source": MIX_FILE + " (tools/isa_mix.py: per-phase opcode histogram of the kernel's ISA x the STATS kernel's pass counts x profiles/r02_valu_probe.txt)"}
+    else:  # no usable counter file for this configuration: only the section-8d figure can be given, and it is not a utilisation
         roofline = {"bound": "valu-issue", "achieved": None, "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s", "frac": None, "traffic": traffic,
-                    "kernel": kname, "avg_launch_ms": round(launch_ms, 4), "sources": {"note": f"{COUNTER_FILE} missing or --res differs from the profiled 2048"}}
+                    "kernel": kname, "avg_launch_ms": round(launch_ms, 4),
+                    "sources": {"note": stale or f"{COUNTER_FILE} missing or --res differs from the profiled 2048"}}
     roofline["algorithmic_vs_hbm"] = {"achieved_GBs": round(alg_gbs, 1), "peak_GBs": HBM_PEAK_GBS, "ratio": round(alg_gbs / HBM_PEAK_GBS, 4),
                                       "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3),
                                       "note": "SURVEY section 8d's figure; > 1 because the reference algorithm's node / instance bytes are served from LDS, L1 and L2, not HBM"}
@@ -311,13 +348,13 @@ def main():
         fetches = (st[3] + st[5]) / n + 1.0
         alg = (64 + 60.0 * fetches + 140.0) * n
         secs = n / (rate * 1e6)
-        prof = (load_json(os.path.join("profiles", "r02_hbm_regime.json")) or {}).get("scenes", {}).get("4000000", {})
+        prof = (load_json(HBM_REGIME_FILE) or load_json(os.path.join("profiles", "r02_hbm_regime.json")) or {}).get("scenes", {}).get("4000000", {})
         phys = prof.get("hbm_read_bytes_per_launch", 0) + prof.get("hbm_write_bytes_per_launch", 0)
         extras["hbm_regime_4M_tris_4M_incoherent_rays"] = {
             "mrays_s": rate, "node_fetches_per_ray": round(fetches, 2), "algorithmic_GBs": round(alg / secs / 1e9, 1),
             "hbm_physical_GBs": round(phys / secs / 1e9, 1) if phys else None, "hbm_physical_frac": round(phys / secs / 1e9 / HBM_PEAK_GBS, 4) if phys else None,
             "fetch_amplification": round(phys / alg, 3) if phys else None,
-            "sources": {"hbm bytes per launch": "profiles/r02_hbm_regime.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE calibrated x1 for random 64-byte gathers, profiles/r02_fetch_calibration.txt)",
+            "sources": {"hbm bytes per launch": HBM_REGIME_FILE + " (tools/gpu_hbm_regime.sh: rocprofv3 FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE calibrated x1 for random 64-byte gathers, profiles/r02_fetch_calibration.txt)",
                         "rate, node fetches": "this run"}}
         torch.cuda.empty_cache()
 
@@ -492,37 +529,61 @@ def main():
             for x, i in zip(xf, ids):
                 o.add_instance(b, x, int(i))
         o.build()
-        cores = os.cpu_count() or 1
-        o.trace(rays, nthreads=cores)  # warm: creates the oracle's worker pool, faults the result pages in
-        cdt = 1e30
-        for _ in range(5):  # 5 passes over the whole batch, best one reported (a single 0.3 s pass on 256 threads is noisy)
+        # Harness: one worker per CPU this process may run on, pinned; the result array is allocated ONCE and its pages
+        # are faulted in by the warm-up pass (a fresh 134 MB array per pass meant page faults under 256 threads inside the timed
+        # region); the per-ray fetch counters are taken in ONE untimed instrumented pass, not in the timed ones.
+        po.pool_pin(True)
+        cores = po.allowed_cpus()
+        phys = set()
+        cpu_model, pid, cid = "unknown", None, None
+        try:
+            for line in open("/proc/cpuinfo"):
+                k, _, v = line.partition(":")
+                k = k.strip()
+                if k == "model name" and cpu_model == "unknown":
+                    cpu_model = v.strip()
+                elif k == "physical id":
+                    pid = v.strip()
+                elif k == "core id":
+                    cid = v.strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+        except OSError:
+            pass
+        physical_cores = min(len(phys), cores) if phys else cores
+        ohits = np.zeros(n, dtype=rc.HIT_DT)
+        o.trace(rays, nthreads=cores, out=ohits)  # warm: creates the worker pool, faults the result pages in
+        passes = []
+        for _ in range(5):  # 5 passes over the whole batch, best one reported (a single sub-second pass on 256 threads is noisy)
             c0 = time.perf_counter()
-            ohits, cnt = o.trace(rays, nthreads=cores, counters=True)
-            cdt = min(cdt, time.perf_counter() - c0)
+            o.trace(rays, nthreads=cores, out=ohits)
+            passes.append(time.perf_counter() - c0)
+        cdt = min(passes)
+        _, cnt = o.trace(rays, nthreads=cores, counters=True)  # untimed: the reference algorithm's node / instance fetches per ray
         node_f, inst_f = float(cnt[:, 0].mean()), float(cnt[:, 1].mean())
+        del cnt
         counts_source = "instrumented oracle, this run"
         same = bool(np.array_equal(ohits["primitive_id"], hits["primitive_id"]) and np.array_equal(ohits["instance_id"], hits["instance_id"])
                     and np.array_equal(ohits["t"].view(np.uint32), hits["t"].view(np.uint32)))
         # one thread on a bounded sample (every 16th ray: the same image, 262 144 rays, a fraction of a second) -- separates the
         # algorithm's per-core rate from the harness's scaling
         sample = np.ascontiguousarray(rays[::16])
-        o.trace(sample[:4096], nthreads=1)
+        shits = np.zeros(len(sample), dtype=rc.HIT_DT)
+        o.trace(sample, nthreads=1, out=shits)
         s0 = time.perf_counter()
-        o.trace(sample, nthreads=1)
+        o.trace(sample, nthreads=1, out=shits)
         sdt = time.perf_counter() - s0
-        cpu_model = "unknown"
-        try:
-            for line in open("/proc/cpuinfo"):
-                if line.startswith("model name"):
-                    cpu_model = line.split(":", 1)[1].strip()
-                    break
-        except OSError:
-            pass
-        cpu_baseline = {"value": round(n / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
+        single = len(sample) / sdt / 1e6
+        cpu_baseline = {"value": round(n / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "physical_cores": physical_cores, "cpu_model": cpu_model, "kind": "port",
                         "sample": f"all {n} primary rays of the workload, closest_hit, C restatement of the reference algorithm "
-                                  f"(oracle/, gcc -O2, persistent pool of {cores} pthreads, dynamic 4096-ray chunks), best of 5 passes, {cdt:.2f} s per pass",
-                        "single_thread": {"value": round(len(sample) / sdt / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                                  f"(oracle/, gcc -O2, persistent pool of {cores} pinned pthreads = sched_getaffinity count, dynamic 4096-ray chunks, result array "
+                                  f"preallocated and pre-faulted, no instrumentation in the timed passes), best of 5 passes, {cdt:.3f} s per pass "
+                                  f"(all: {', '.join(f'{p:.3f}' for p in passes)})",
+                        "single_thread": {"value": round(single, 3), "unit": "Mrays/s", "cores": 1,
                                           "sample": f"every 16th ray of the batch ({len(sample)} rays), one pass, {sdt:.2f} s"},
+                        "scaling_vs_physical_cores": round(n / cdt / 1e6 / (physical_cores * single), 3),
                         "gpu_matches_bit_exact": same}
         try:
             json.dump({"workload": "C3 primary rays, 2048 x 2048", "node_fetches_per_ray": node_f, "instance_entries_per_ray": inst_f,
@@ -531,7 +592,8 @@ def main():
             pass
 
     if rank == 0:
-        roofline = make_roofline(launch_ms, n, node_f, inst_f, counts_source, load_json(COUNTER_FILE) or {}, t.get_option("kernel"), args.res == 2048)
+        roofline = make_roofline(launch_ms, n, node_f, inst_f, counts_source, load_json(COUNTER_FILE) or {}, t.get_option("kernel"), args.res == 2048,
+                                 mix=load_json(MIX_FILE), fingerprint=kernel_fingerprint())
         out = {
             "metric": "Mrays/s closest_hit (1M-tri TLAS)", "value": round(world * n * args.steps / elapsed / 1e6, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -68,6 +68,8 @@ def lib():
         L.rco_closest_hit.argtypes = [vp, vp, vp, vp]
         L.rco_any_hit.argtypes = [vp, vp, vp, vp]
         L.rco_trace_batch.argtypes = [vp, vp, vp, u64, C.c_int, C.c_int, vp]
+        L.rco_pool_pin.argtypes = [C.c_int]
+        L.rco_allowed_cpus.restype = C.c_int
         L.rco_brute_closest.argtypes = [vp, vp, vp]
         L.rco_expand_bits.restype = u32
         L.rco_expand_bits.argtypes = [u32]
@@ -116,6 +118,15 @@ def _p(a):
 def _f32(a, shape=None):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a.reshape(shape) if shape is not None else a
+
+
+def pool_pin(enable=True):
+    """Pin the worker pool's threads to the CPUs this process may run on, one each (call before the pool's first use)."""
+    lib().rco_pool_pin(1 if enable else 0)
+
+
+def allowed_cpus():
+    return int(lib().rco_allowed_cpus())
 
 
 class Scene:
@@ -214,9 +225,15 @@ class Scene:
         return out
 
     # ---- traversal ----
-    def trace(self, rays, mode="closest", nthreads=1, counters=False):
+    def trace(self, rays, mode="closest", nthreads=1, counters=False, out=None):
+        """`out`: a HIT_DT array to reuse (a timing loop must not pay for a fresh 32 B/ray array -- page faults under hundreds of threads --
+        on every pass; every record is written)."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DT)
-        hits = np.zeros(len(rays), dtype=HIT_DT)
+        if out is None:
+            hits = np.zeros(len(rays), dtype=HIT_DT)
+        else:
+            assert out.dtype == HIT_DT and len(out) == len(rays) and out.flags["C_CONTIGUOUS"]
+            hits = out
         cnt = np.zeros((len(rays), 2), dtype=np.uint32) if counters else None
         lib().rco_trace_batch(self._h, _p(rays), _p(hits), len(rays), 0 if mode == "closest" else 1, nthreads, _p(cnt))
         return (hits, cnt) if counters else hits

@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 

@@ -102,6 +102,9 @@ void rco_closest_hit(const rco_scene*, const rco_ray*, rco_hit*, uint32_t* count
 void rco_any_hit(const rco_scene*, const rco_ray*, rco_hit*, uint32_t* counters);
 /* Batch over n rays with nthreads pthreads (mirrors Threads.@threads, src/kernels.jl:64).
  * mode 0 = closest, 1 = any.  counters: NULL or n x 2 u32 (zeroed by the callee). */
+/* worker k of the thread pool pinned to the k-th allowed CPU (before the pool's first use); CPUs this process may run on */
+void rco_pool_pin(int enable);
+int rco_allowed_cpus(void);
 void rco_trace_batch(const rco_scene*, const rco_ray* rays, rco_hit* hits, uint64_t n, int mode, int nthreads,
                      uint32_t* counters);
 /* Independent check of the traversal: Moeller-Trumbore over every (instance, triangle) pair with the

@@ -1077,12 +1077,15 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "vf_chunk_bytes") *value = s->opt.vf_chunk_bytes;
     else if (k == "blas_top_k") *value = s->blas_top_k;
     else if (k == "tlas_top_k") *value = s->tlas_top_k;
-    else if (k.rfind("stat", 0) == 0 && k.size() == 5 && ((k[4] >= '0' && k[4] <= '9') || (k[4] >= 'a' && k[4] <= 'f'))) {
-        unsigned long long st[16] = {0};
+    else if (k.rfind("stat", 0) == 0 && ((k.size() == 5 && ((k[4] >= '0' && k[4] <= '9') || (k[4] >= 'a' && k[4] <= 'f'))) ||
+                                           (k.size() == 6 && k[4] >= '1' && k[4] <= '2' && k[5] >= '0' && k[5] <= '9'))) {  // "stat0".."statf", "stat16".."stat23"
+        unsigned long long st[kStatsWords] = {0};
+        const int idx = k.size() == 6 ? (k[4] - '0') * 10 + (k[5] - '0') : (k[4] <= '9' ? k[4] - '0' : k[4] - 'a' + 10);
+        if (idx >= kStatsWords) return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
         (void)hipSetDevice(s->device);
         (void)hipDeviceSynchronize();
         if (s->counters.p && hipMemcpy(st, rc_stats_words(s), sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return fail(RC_ERR_HIP, "stats read failed");
-        *value = (int64_t)st[k[4] <= '9' ? k[4] - '0' : k[4] - 'a' + 10];
+        *value = (int64_t)st[idx];
     }
     else return fail(RC_ERR_INVALID_ARGUMENT, "unknown option " + k);
     return RC_OK;

@@ -270,6 +270,7 @@ namespace rc { struct SceneView; struct RcClaim; }
 constexpr int kCounterSlots = 64, kEagerSlots = 48, kCounterSlotWords = 2048, kCounterSlotUsedWords = 1088;
 constexpr int kSceneTimingSlot = kCounterSlots;
 constexpr int kClaimShards = 16, kShardBase = 64, kShardStrideWords = 64;
+constexpr int kStatsWords = 24;  // u64 dev statistics behind the status word of slot 0 (u32 words 8 .. 55: below kShardBase)
 inline uint32_t* rc_counter_slot(rc_scene* s) { return s->counters.p + (size_t)s->cur_slot * kCounterSlotWords; }  // slot of the launch being prepared (launch_mu held)
 inline uint32_t* rc_status_word(rc_scene* s) { return s->counters.p + 4; }
 inline unsigned long long* rc_stats_words(rc_scene* s) { return reinterpret_cast<unsigned long long*>(s->counters.p + 8); }

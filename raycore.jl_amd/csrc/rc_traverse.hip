@@ -111,7 +111,7 @@ constexpr int kBigBlock = 1024;
 constexpr size_t kBigStackBytes = (size_t)kLdsStack * kBigBlock * 4;
 constexpr size_t kBigLdsBytes = kBigStackBytes + kLdsTopBytes;
 
-template <bool ANY, int BLOCK, int LDS_N, int MINW, bool TIMELINE = false>
+template <bool ANY, int BLOCK, int LDS_N, int MINW, bool TIMELINE = false, bool STATS = false>
 __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr size_t stack_bytes = (size_t)LDS_N * BLOCK * 4;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     if (a.v.n_tlas_nodes) stage_lds_top<BLOCK>(top, a.v, a.blas_k, a.lds_blas_base);
     __syncthreads();
     PersistArgs p{a.n_rays, a.claim, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, 0u, a.timeline};
-    phased_trace<ANY, LDS_N, false, ArraySource, HitWriter, BLOCK, true, true, false, TIMELINE>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
+    phased_trace<ANY, LDS_N, STATS, ArraySource, HitWriter, BLOCK, true, true, false, TIMELINE>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
 // ---- kernel 6: kernel 5's shape for top levels that do not fit (more than 256 instances): only the breadth-first tops of the TLAS and
@@ -415,7 +415,7 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
         rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
         if (slot.recorded && slot.stream != stream) RC_HIP(hipStreamWaitEvent(stream, slot.t1, 0));
     }
-    if (s->opt.stats) RC_HIP(hipMemsetAsync(rc_stats_words(s), 0, 16 * sizeof(unsigned long long), stream));
+    if (s->opt.stats) RC_HIP(hipMemsetAsync(rc_stats_words(s), 0, kStatsWords * sizeof(unsigned long long), stream));
 }
 
 void RcLaunchGuard::start() {
@@ -546,7 +546,10 @@ static void launch_variant(rc_scene* s, int64_t kernel, const TraceArgs& a, uint
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
             attr_set = true;
         }
-        if (a.timeline) {  // dev: the same kernel with per-wave event times written to the caller's buffer (option "timeline_ptr")
+        if (stats) {  // dev: the same kernel with per-phase pass / lane counters (option "stats"; tools/isa_mix.py weights the phases' static opcode histograms with them)
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
+            hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
+        } else if (a.timeline) {  // dev: the same kernel with per-wave event times written to the caller's buffer (option "timeline_ptr")
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
             hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
         } else

@@ -456,6 +456,14 @@ __device__ inline float3_ safe_inv3(const float3_ d) {
     return mk3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
 }
 
+// Analysis builds (tools/isa_mix.py, -DRC_PHASE_MARKERS): comment lines in the generated assembly that delimit the phases, so that the
+// static VALU opcode histogram of each phase can be read off the ISA.  Not compiled into the product.
+#ifdef RC_PHASE_MARKERS
+#define RC_MARK(name) asm volatile("; RC_MARK " name)
+#else
+#define RC_MARK(name) ((void)0)
+#endif
+
 template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS, bool PARTIAL_LDS = false,
           bool TIMELINE = false>
 __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
@@ -486,7 +494,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     int closest_inst = -1, cur_inst = -1;
     typename LaneStackP<LDS_N, BLOCK>::pos_t sp = st.empty();
     bool live = false;
-    unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0};
+    unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0}, st_outer = 0, st_sub[4] = {0, 0, 0, 0};  // st_sub: passes with an exit lane / an entry lane / a result to write / rays to start
     unsigned long long st_t0 = STATS ? wall_clock64() : 0ull, st_tx = 0ull;
     int thr_eff = __builtin_amdgcn_readfirstlane(a.int_thr);  // wave-uniform: keeps the loop-exit compare on the scalar unit
     // TIMELINE (dev, tools/timeline_probe.py): per-wave event times and scalar counts, cheap enough not to move the schedule
@@ -496,6 +504,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     for (;;) {
         // ---- interior phase: intersect_internal_node (:1807-1832) + push far / descend near / pop (:1946-1960, 1991-1993)
         for (;;) {
+            RC_MARK("interior_begin");
             const bool is_int = node < n_level;  // sentinels and INVALID are >= 0xFFFFFFFE, never below a leaf threshold
             const int n_int = __popcll(__ballot(is_int));
             if (n_int == 0) break;
@@ -535,12 +544,14 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 if (far_ok) st.push(sp, far_c);
                 node = near_ok ? near_c : st.pop(sp);
             }
+            RC_MARK("interior_end");
             if (n_int < thr_eff) break;  // too few interior lanes left: serve the waiting ones first
         }
         // ---- leaf phase: fast_intersect_triangle (:1756-1797) on BLAS leaves, then pop
         {
             const bool is_leaf = cur_inst >= 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
             if (STATS && __ballot(is_leaf)) { st_iter[2] += 1; st_lane[2] += is_leaf ? 1 : 0; }
+            RC_MARK("leaf_begin");
             if (is_leaf) {
                 const uint32_t off = (cur_off + node) << 6;
                 const float4 na = buf_f4(nrs1, off);
@@ -565,12 +576,15 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 if (ANY && hit) node = RC_INVALID_NODE;  // :2106-2115
                 else node = st.pop(sp);
             }
+            RC_MARK("leaf_end");
         }
         // ---- switch phase: return to the top level (:1996-2006) or enter an instance (:1961-1977)
         {
             const bool is_exit = node == RC_TOP_LEVEL_SENTINEL;
             const bool is_entry = cur_inst < 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
             if (STATS && __ballot(is_exit || is_entry)) { st_iter[3] += 1; st_lane[3] += (is_exit || is_entry) ? 1 : 0; }
+            if (STATS) { if (__ballot(is_exit)) st_sub[0] += 1; if (__ballot(is_entry)) st_sub[1] += 1; }
+            RC_MARK("switch_begin");
             if (is_exit) {
                 node = st.pop(sp);
                 cur_inst = -1;
@@ -579,7 +593,9 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 // ray's o and d are not read again before the next instance entry overwrites them from wo / wd
                 inv = winv;
                 ox = mk3(-wo.x * inv.x, -wo.y * inv.y, -wo.z * inv.z);
+                RC_MARK("switch_end");
             } else if (is_entry) {
+                RC_MARK("entry_begin");
                 float4 m0, m1, m2;
                 u4v m3;
                 if (TLAS_LDS) cur_inst = (int)lt[node - n_level];  // leaf of sorted instance j is node n - 1 + j; its child1 word
@@ -605,10 +621,13 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
                 inv = safe_inv3(d);
                 ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                RC_MARK("entry_end");
             }
         }
         // ---- finished lanes: write out; refill when enough lanes are free
         {
+            RC_MARK("finish_begin");
+            if (STATS) st_outer += 1;
             const bool fin = live && node == RC_INVALID_NODE;
             const int n_free = __popcll(__ballot(fin || !live));
             const bool can_refill = !(exhausted && pool_next == pool_end);
@@ -629,10 +648,15 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             }
             if (n_free == 64 && !can_refill && !__ballot(fin)) break;
             if (n_free >= a.refill || n_free == 64 || !can_refill) {
+                if (STATS && __ballot(fin)) st_sub[2] += 1;
+                RC_MARK("finish_end");
+                RC_MARK("writeout_begin");
                 if (fin) {
                     sink(my_ray, closest_inst >= 0, closest_t, hit_u, hit_v, closest_prim, closest_inst);
                     live = false;
                 }
+                RC_MARK("writeout_end");
+                RC_MARK("finish_begin");
                 if (STATS) { st_iter[0] += 1; }
                 while (can_refill) {
                     const unsigned long long free_mask = __ballot(!live);
@@ -645,6 +669,9 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                     const unsigned long long left = pool_end - pool_next;
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)free_mask, 0u));
+                    if (STATS) st_sub[3] += 1;
+                    RC_MARK("finish_end");
+                    RC_MARK("refill_begin");
                     if (!live && rank < left) {
                         my_ray = pool_next + rank;
                         const RcRay r = src(my_ray);
@@ -664,9 +691,12 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         node = 1;
                         live = true;
                     }
+                    RC_MARK("refill_end");
+                    RC_MARK("finish_begin");
                     pool_next += ((unsigned long long)nf < left) ? (unsigned long long)nf : left;
                 }
             }
+            RC_MARK("finish_end");
         }
     }
     if (TIMELINE && lane == 0 && a.timeline) {  // [t0, tx (claims dry + own pool empty), t(<16 live), t(<4 live), t_end, outer | outer after tx << 32, interior iterations | after tx << 32, sum of live lanes after tx]
@@ -688,6 +718,8 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             atomicAdd(&a.stats[11], t_end - st_tx);
             atomicAdd(&a.stats[12], t_end - st_t0);
             atomicAdd(&a.stats[13], 1ull);
+            atomicAdd(&a.stats[14], st_outer);  // outer iterations (one pass over the phases each)
+            for (int k = 0; k < 4; ++k) atomicAdd(&a.stats[15 + k], st_sub[k]);
         }
     }
 }

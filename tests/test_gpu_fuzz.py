@@ -40,7 +40,7 @@ def hostile_transform(g, kind):
 
 import os
 
-N_SEEDS = int(os.environ.get("RC_FUZZ_SEEDS", "12"))  # raise for a longer campaign (round 1: 4000 seeds clean)
+N_SEEDS = int(os.environ.get("RC_FUZZ_SEEDS", "200"))  # the default -m gpu run; raise for a longer campaign (rounds 1-2: 9000 seeds clean)
 
 
 @pytest.mark.parametrize("seed", range(N_SEEDS))
@@ -77,13 +77,13 @@ def test_random_hostile_scenes(rc, oracle, seed):
     rays["tmin"][::7] = g.uniform(-1, 1, len(rays["tmin"][::7]))
     rays["tmax"][::5] = g.uniform(0, 8, len(rays["tmax"][::5]))
     want_c, want_a = o.trace(rays, nthreads=4), o.trace(rays, mode="any", nthreads=4)
-    for kern in (0, 1, 2, 3, 4, 5, 6):
+    for kern in (-1, 0, 1, 2, 3, 4, 5, 6):
         t.set_option("kernel", kern)
         assert_hits_equal(t.trace(rays), want_c, f"seed {seed} closest k{kern}")
         assert_hits_equal(t.trace(rays, mode="any"), want_a, f"seed {seed} any k{kern}")
 
 
-@pytest.mark.parametrize("seed", range(max(4, N_SEEDS // 3)))
+@pytest.mark.parametrize("seed", range(max(4, N_SEEDS // 4)))
 def test_random_bvh4_and_collision(rc, oracle, seed):
     """BVH4 collapse + closest_hit4 / any_hit4 and the collision broad phase on random inputs, bit for bit against the oracle."""
     sc = rc.scenes

@@ -4,7 +4,7 @@
 # Counters are collected in their own passes (--pmc with --kernel-trace only), HBM counters FETCH_SIZE / WRITE_SIZE in separate passes,
 # FETCH_SIZE doubled afterwards (gfx950 reports half of a 16 B/lane coalesced stream; MI355X_MICROARCH.md, HBM section).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R; P=$O/profiles
 mkdir -p $O $P
 CMD="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
@@ -31,6 +31,12 @@ for f in glob.glob(f"{O}/pmc_*/**/*_counter_collection.csv", recursive=True):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size") if k in r}
 out["kernel"] = meta
+# what these counters describe: the sources the dominant kernel is compiled from.  bench.py recomputes the hash at run time and refuses to
+# derive a utilisation from counters of another kernel (a kernel made faster by issuing fewer instructions must not report a
+# higher "utilisation" off a stale count)
+sys.path.insert(0, ".")
+import bench
+out["fingerprint"] = bench.kernel_fingerprint()
 out["dispatches_averaged"] = {k: len(v) for k, v in sorted(agg.items())}
 out["counters_mean_per_launch"] = {k: sum(v) / len(v) for k, v in sorted(agg.items())}
 c = out["counters_mean_per_launch"]

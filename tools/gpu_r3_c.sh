@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 3, call C: full GPU suite, phase pass counters, rocprofv3 stats + PMC passes of the bench command, the full bench line
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r3c; mkdir -p $O
+timeout 1200 python3 -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -8 $O/pytest.log
+timeout 600 python3 tools/phase_passes.py > $O/r03_phase_passes_kernel5.json 2> $O/phase_passes.err; tail -3 $O/phase_passes.err; head -c 1500 $O/r03_phase_passes_kernel5.json
+timeout 2400 bash tools/capture_profiles.sh r03 > $O/capture.log 2>&1; tail -c 6000 $O/capture.log
