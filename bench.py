@@ -532,8 +532,27 @@ def main():
         # Harness: one worker per CPU this process may run on, pinned; the result array is allocated ONCE and its pages
         # are faulted in by the warm-up pass (a fresh 134 MB array per pass meant page faults under 256 threads inside the timed
         # region); the per-ray fetch counters are taken in ONE untimed instrumented pass, not in the timed ones.
+        # The container may see every hardware thread of the host (sched_getaffinity: 256 on the GPU box) and still be limited to a CPU-time
+        # quota by its cgroup (cpu.max = "1600000 100000" there: 16 CPUs' worth; with 256 runnable threads the kernel throttled the run
+        # for 431 s of thread time and the rate FELL to 5 Mrays/s -- profiles/r03_cpu_scaling.txt).  One worker per CPU the quota pays for.
         po.pool_pin(True)
-        cores = po.allowed_cpus()
+        visible = po.allowed_cpus()
+        quota_cpus, quota_src = None, None
+        for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            try:
+                txt = open(path).read().split()
+                if path.endswith("cpu.max"):
+                    if txt[0] != "max":
+                        quota_cpus, quota_src = int(txt[0]) / int(txt[1]), f"{path} = {' '.join(txt)}"
+                else:
+                    q = int(txt[0])
+                    if q > 0:
+                        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                        quota_cpus, quota_src = q / per, f"{path} = {q} / {per}"
+                break
+            except (OSError, ValueError, IndexError):
+                continue
+        cores = visible if not quota_cpus else max(1, min(visible, int(round(quota_cpus))))
         phys = set()
         cpu_model, pid, cid = "unknown", None, None
         try:
@@ -552,7 +571,7 @@ def main():
                     pid = cid = None
         except OSError:
             pass
-        physical_cores = min(len(phys), cores) if phys else cores
+        physical_cores = min(len(phys), cores) if phys else cores  # cores the run can actually occupy: the quota's, when there is one
         ohits = np.zeros(n, dtype=rc.HIT_DT)
         o.trace(rays, nthreads=cores, out=ohits)  # warm: creates the worker pool, faults the result pages in
         passes = []
@@ -576,9 +595,10 @@ def main():
         o.trace(sample, nthreads=1, out=shits)
         sdt = time.perf_counter() - s0
         single = len(sample) / sdt / 1e6
-        cpu_baseline = {"value": round(n / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "physical_cores": physical_cores, "cpu_model": cpu_model, "kind": "port",
+        cpu_baseline = {"value": round(n / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "physical_cores": physical_cores, "hardware_threads_visible": visible,
+                        "host_physical_cores": len(phys) or None, "cgroup_cpu_quota": quota_src or "none", "cpu_model": cpu_model, "kind": "port",
                         "sample": f"all {n} primary rays of the workload, closest_hit, C restatement of the reference algorithm "
-                                  f"(oracle/, gcc -O2, persistent pool of {cores} pinned pthreads = sched_getaffinity count, dynamic 4096-ray chunks, result array "
+                                  f"(oracle/, gcc -O2, persistent pool of {cores} pinned pthreads = min(sched_getaffinity count, cgroup CPU quota), dynamic 4096-ray chunks, result array "
                                   f"preallocated and pre-faulted, no instrumentation in the timed passes), best of 5 passes, {cdt:.3f} s per pass "
                                   f"(all: {', '.join(f'{p:.3f}' for p in passes)})",
                         "single_thread": {"value": round(single, 3), "unit": "Mrays/s", "cores": 1,

@@ -98,6 +98,7 @@ struct TraceOptions {
     int64_t onesweep_min = 1000000;  // builds: key counts from here up are sorted by Onesweep radix passes, smaller ones by rocPRIM's merge sort (measured: 0.22 vs 0.25 ms at 250 k keys, 0.437 vs 0.425 ms at 1 M)
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
     int64_t host_pipeline = 1; // host-buffer trace calls of >= 1 Mi rays overlap upload / trace / download in chunks
+    int64_t taper = 0;         // persistent kernels: guided chunk sizes at the end of a batch, in eighths of (chunk size x waves) still to hand out per piece (RcClaim); 0 = all chunks of `pool` items
     int64_t claim_shards = 16; // phased kernels: chunk counters in use (a power of two <= kClaimShards)
     int64_t vf_chunk_bytes = 192 << 20;  // host-matrix view factors (rc_multi.hip): device block per row chunk -- large enough for full-rate launches and 2-D copies, small enough that the exposed first trace / last copy are a few ms
     int64_t timeline_ptr = 0;  // dev: device address of 8 x u64 per wave (n_cus x 24 waves) that kernel 5 fills with its waves' event times; 0 = off

@@ -476,10 +476,28 @@ void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcCl
     while ((2u << shift) <= shards) ++shift;
     out.shard_shift = shift;
     out.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
-    const uint64_t n_chunks = (n_items + out.pool - 1) / out.pool;
+    out.total_waves = total_waves;
+    // guided chunk sizes (RcClaim): piece k (chunk size pool >> k) ends where the items left equal taper / 8 x its chunk size x waves
+    const uint64_t P = out.pool;
+    uint64_t begin[4] = {0, 0, 0, 0}, chunks[4] = {0, 0, 0, 0};  // first item and chunk count of the pieces of size P, P/2, P/4, P/8
+    uint64_t pos = 0;
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t size = P >> k;
+        begin[k] = pos;
+        uint64_t end = n_items;
+        if (k < 3 && s->opt.taper > 0) {
+            const uint64_t keep = (uint64_t)s->opt.taper * size * total_waves / 8u;  // items left for the smaller pieces
+            end = n_items > keep ? n_items - keep : 0;
+            if (end < pos) end = pos;
+        }
+        chunks[k] = k < 3 ? (end - pos) / size : (end - pos + size - 1) / size;  // whole chunks only, except in the last piece
+        pos += chunks[k] * size;
+    }
+    const uint64_t n_chunks = chunks[0] + chunks[1] + chunks[2] + chunks[3];
     if (n_chunks >= (1ull << 31)) throw RcError(1, "ray batch too large for 32-bit chunk ids");
     out.n_chunks = (uint32_t)n_chunks;
-    out.total_waves = total_waves;
+    out.g1 = (uint32_t)chunks[0]; out.g2 = (uint32_t)(chunks[0] + chunks[1]); out.g3 = (uint32_t)(chunks[0] + chunks[1] + chunks[2]);
+    out.r1 = begin[1]; out.r2 = begin[2]; out.r3 = begin[3];
 }
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {

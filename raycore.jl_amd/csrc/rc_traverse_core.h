@@ -39,12 +39,19 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
 // launch, and the wave whose failed claim is the last of them puts the counter back to zero -- no memset node between back-to-back
 // launches (6 us, 1 % of a 4 M-ray launch, 3 % of a 1 M-ray one), nothing a later launch could clear under an earlier one, and
 // a launch that is never enqueued leaves nothing behind.
+// Chunk sizes taper towards the end of a batch (guided self-scheduling, option "taper"): chunks [0, g1) hold `pool` items, [g1, g2)
+// pool / 2, [g2, g3) pool / 4, the rest pool / 8, with the boundaries placed where the items still to be handed out equal taper / 8 x
+// (chunk size) x (waves of the launch).  Large chunks keep a wave's lanes on neighbouring rays (coherent fetches) while there is plenty
+// of work; small ones at the end let the waves run dry together -- a launch lasts until the LAST claimed chunk has been traced, and a
+// 128-ray chunk is two generations of a wave's lanes (~150 us on C2).  taper = 0: every chunk holds `pool` items.
 struct RcClaim {
     uint32_t* counters;            // kClaimShards words, kShardStrideWords apart, zero between launches
     uint32_t shard_shift;          // n_shards = 1 << shard_shift <= kClaimShards and <= the waves of the launch (every shard has a wave)
-    uint32_t n_chunks;             // ceil(n_items / pool), < 2^32
-    uint32_t pool;                 // items per claim
+    uint32_t n_chunks;             // chunks of the launch, < 2^31
+    uint32_t pool;                 // items per full-size claim
     uint32_t total_waves;          // waves of the launch: wave w claims from shard w & (n_shards - 1)
+    uint32_t g1, g2, g3;           // first chunk of the pool / 2, pool / 4, pool / 8 pieces (= n_chunks when a piece is empty)
+    unsigned long long r1, r2, r3; // first item of those pieces
 };
 // Wave-uniform: the next chunk of this wave's shard, or false when the shard has run dry.  `wave_id` must be the same in all lanes.
 __device__ inline bool rc_claim_chunk(const RcClaim& c, uint32_t wave_id, int lane, uint64_t n_items, unsigned long long& pool_next,
@@ -64,8 +71,12 @@ __device__ inline bool rc_claim_chunk(const RcClaim& c, uint32_t wave_id, int la
         return false;
     }
     const uint32_t chunk_id = (cs << c.shard_shift) + ((my_shard + cs * 5u) & (n - 1u));
-    pool_next = (unsigned long long)chunk_id * c.pool;
-    pool_end = pool_next + c.pool;
+    uint32_t size = c.pool;  // wave-uniform: all of this is scalar arithmetic
+    if (chunk_id < c.g1) pool_next = (unsigned long long)chunk_id * size;
+    else if (chunk_id < c.g2) { size >>= 1; pool_next = c.r1 + (unsigned long long)(chunk_id - c.g1) * size; }
+    else if (chunk_id < c.g3) { size >>= 2; pool_next = c.r2 + (unsigned long long)(chunk_id - c.g2) * size; }
+    else { size >>= 3; pool_next = c.r3 + (unsigned long long)(chunk_id - c.g3) * size; }
+    pool_end = pool_next + size;
     if (pool_end > n_items) pool_end = n_items;
     return true;
 }

@@ -377,7 +377,8 @@ def test_trace_edge_cases(rc, oracle):
     t.set_option("kernel", -1)
     hit = want["hit"] == 1
     assert np.isnan(want["t"][hit]).any()            # the in-plane rays: det == 0 => u = NaN passes every test => a "hit" with t = NaN
-    assert set(np.unique(want["instance_id"][hit & ~np.isnan(want["t"])])) >= {4}  # five identical instances: every t ties, the LAST visit wins
+    quad_hits = hit & ~np.isnan(want["t"]) & (want["instance_id"] < 5)
+    assert quad_hits.any() and len(np.unique(want["instance_id"][quad_hits])) < 5  # five identical instances: every t ties and ONE visit order decides (the later visit replaces, :1792)
 
 
 def test_weird_rays_and_scales(rc, oracle):
