@@ -98,7 +98,9 @@ struct TraceOptions {
     int64_t onesweep_min = 1000000;  // builds: key counts from here up are sorted by Onesweep radix passes, smaller ones by rocPRIM's merge sort (measured: 0.22 vs 0.25 ms at 250 k keys, 0.437 vs 0.425 ms at 1 M)
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
     int64_t host_pipeline = 1; // host-buffer trace calls of >= 1 Mi rays overlap upload / trace / download in chunks
-    int64_t taper = 0;         // persistent kernels: guided chunk sizes at the end of a batch, in eighths of (chunk size x waves) still to hand out per piece (RcClaim); 0 = all chunks of `pool` items
+    int64_t taper = 12;        // persistent kernels: guided chunk sizes at the end of a batch, in eighths of (chunk size x waves) still to hand out per piece (RcClaim); 0 = all chunks of `pool` items
+    int64_t cost_order = 1;    // phased kernels: chunks that held long rays in the previous launch of the same shape (batch size, mode, stream) are claimed first (RcClaim::order)
+    int64_t cost_thr = 64;     //   initial reporting threshold, in interior-loop iterations of a ray's wave while the ray was in flight (adapted from launch to launch)
     int64_t claim_shards = 16; // phased kernels: chunk counters in use (a power of two <= kClaimShards)
     int64_t vf_chunk_bytes = 192 << 20;  // host-matrix view factors (rc_multi.hip): device block per row chunk -- large enough for full-rate launches and 2-D copies, small enough that the exposed first trace / last copy are a few ms
     int64_t timeline_ptr = 0;  // dev: device address of 8 x u64 per wave (n_cus x 24 waves) that kernel 5 fills with its waves' event times; 0 = off
@@ -191,6 +193,17 @@ struct rc_scene {
     std::vector<LaunchSlot> slots;    // kCounterSlots + 1: the last entry is the scene's own pair (ev0 / ev1)
     uint64_t timing_seq = 0;
     TimingRef last_timing;            // most recent timed operation on the scene by any thread
+    // cost-ordered claiming: what the last launch of a shape learned about its chunks (rc_cost_order_setup, rc_traverse.hip)
+    struct ChunkHistory {
+        uint64_t n_items = 0; int any = 0; hipStream_t stream = nullptr;
+        uint32_t n_chunks = 0, pool = 0;  // chunks of `pool` items
+        DevBuf<uint32_t> cost, order, ctl;  // ctl: [2 p], [2 p + 1] reporting threshold and top of the cost scale for launches of parity p, [4 ...] per-block class counts of the order kernels
+        uint64_t gen = 0;                   // launches of this shape so far
+        uint64_t last_use = 0;
+    };
+    static constexpr int kMaxHistories = 8;
+    std::vector<ChunkHistory> histories;
+    uint64_t history_clock = 0;
 
     // host-buffer trace calls in flight (ctx_mu): a small pool of staging contexts; a call beyond kMaxCallCtx waits for one to come free
     static constexpr int kMaxCallCtx = 4;

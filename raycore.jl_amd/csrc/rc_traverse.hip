@@ -15,6 +15,9 @@
 // (core in rc_traverse_core.h), 4 / 5 phased with the top level -- TLAS interior nodes, instance records, a single BLAS's top nodes --
 // staged in LDS (5 = default when the scene has <= 256 instances).  All return identical results.
 #include <algorithm>
+#include <cstdlib>
+
+#include <hipcub/hipcub.hpp>
 
 #include "rc_traverse_core.h"
 
@@ -418,18 +421,25 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
     if (s->opt.stats) RC_HIP(hipMemsetAsync(rc_stats_words(s), 0, kStatsWords * sizeof(unsigned long long), stream));
 }
 
+static int rc_event_mode() {  // dev (tools/event_probe.py): RC_EVENT_MODE = 0 default events, 1 hipEventDisableSystemFence, 2 no t0 event, 3 no events at all (single-stream runs only)
+    static const int mode = [] { const char* e = getenv("RC_EVENT_MODE"); return e ? atoi(e) : 0; }();
+    return mode;
+}
 void RcLaunchGuard::start() {
     if (capturing) return;
     rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
-    if (!slot.t0) { RC_HIP(hipEventCreate(&slot.t0)); RC_HIP(hipEventCreate(&slot.t1)); }
-    RC_HIP(hipEventRecord(slot.t0, stream));
+    if (!slot.t0) {
+        const unsigned flags = rc_event_mode() == 1 ? hipEventDisableSystemFence : hipEventDefault;
+        RC_HIP(hipEventCreateWithFlags(&slot.t0, flags)); RC_HIP(hipEventCreateWithFlags(&slot.t1, flags));
+    }
+    if (rc_event_mode() < 2) RC_HIP(hipEventRecord(slot.t0, stream));
 }
 
 void RcLaunchGuard::finish() {
     RC_HIP(hipGetLastError());
     if (capturing) return;  // a captured launch has no events of its own: the graph orders it, and its duration is the replay's business
     rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
-    RC_HIP(hipEventRecord(slot.t1, stream));
+    if (rc_event_mode() < 3) RC_HIP(hipEventRecord(slot.t1, stream));
     slot.stream = stream;
     slot.recorded = true;
     slot.seq = ++s->timing_seq;
@@ -477,27 +487,27 @@ void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcCl
     out.shard_shift = shift;
     out.pool = (uint32_t)(s->opt.pool > 0 ? s->opt.pool : 128u);  // measured: 64 loses 10-16 % (a wave's lanes end up on rays of more image regions), 256+ unbalances the tail
     out.total_waves = total_waves;
-    // guided chunk sizes (RcClaim): piece k (chunk size pool >> k) ends where the items left equal taper / 8 x its chunk size x waves
-    const uint64_t P = out.pool;
-    uint64_t begin[4] = {0, 0, 0, 0}, chunks[4] = {0, 0, 0, 0};  // first item and chunk count of the pieces of size P, P/2, P/4, P/8
-    uint64_t pos = 0;
-    for (int k = 0; k < 4; ++k) {
-        const uint64_t size = P >> k;
-        begin[k] = pos;
-        uint64_t end = n_items;
-        if (k < 3 && s->opt.taper > 0) {
-            const uint64_t keep = (uint64_t)s->opt.taper * size * total_waves / 8u;  // items left for the smaller pieces
-            end = n_items > keep ? n_items - keep : 0;
-            if (end < pos) end = pos;
+    // guided claim sizes (RcClaim): the chunks of the claim order are dealt whole, then in halves, quarters, eighths; piece k ends where the
+    // items left equal taper / 8 x its part size x waves
+    const uint64_t P = out.pool, n_base = (n_items + P - 1) / P;
+    uint64_t chunks[4] = {n_base, 0, 0, 0}, done = 0;
+    if (s->opt.taper > 0 && (P & 7u) == 0) {  // parts must tile the chunk: a pool that is not a multiple of eight is dealt whole
+        for (int k = 0; k < 3; ++k) {
+            const uint64_t keep = (uint64_t)s->opt.taper * (P >> k) * total_waves / 8u;          // items left for the smaller parts
+            const uint64_t upto = n_items > keep ? (n_items - keep) / P : 0;                          // whole chunks handed out before that point
+            chunks[k] = upto > done ? upto - done : 0;
+            done += chunks[k];
         }
-        chunks[k] = k < 3 ? (end - pos) / size : (end - pos + size - 1) / size;  // whole chunks only, except in the last piece
-        pos += chunks[k] * size;
+        chunks[3] = n_base - done;
     }
-    const uint64_t n_chunks = chunks[0] + chunks[1] + chunks[2] + chunks[3];
-    if (n_chunks >= (1ull << 31)) throw RcError(1, "ray batch too large for 32-bit chunk ids");
-    out.n_chunks = (uint32_t)n_chunks;
-    out.g1 = (uint32_t)chunks[0]; out.g2 = (uint32_t)(chunks[0] + chunks[1]); out.g3 = (uint32_t)(chunks[0] + chunks[1] + chunks[2]);
-    out.r1 = begin[1]; out.r2 = begin[2]; out.r3 = begin[3];
+    const uint64_t n_claims = chunks[0] + 2 * chunks[1] + 4 * chunks[2] + 8 * chunks[3];
+    if (n_claims >= (1ull << 31)) throw RcError(1, "ray batch too large for 32-bit chunk ids");
+    out.n_chunks = (uint32_t)n_claims;
+    out.g1 = (uint32_t)chunks[0]; out.g2 = (uint32_t)(chunks[0] + 2 * chunks[1]); out.g3 = (uint32_t)(chunks[0] + 2 * chunks[1] + 4 * chunks[2]);
+    out.c1 = (uint32_t)chunks[0]; out.c2 = (uint32_t)(chunks[0] + chunks[1]); out.c3 = (uint32_t)(chunks[0] + chunks[1] + chunks[2]);
+    out.order = nullptr; out.cost = nullptr; out.life_thr_ptr = nullptr;
+    out.pool_shift = 0;
+    while ((2u << out.pool_shift) <= out.pool) ++out.pool_shift;
 }
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
@@ -606,6 +616,114 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
     switch (s->opt.lds_stack) { case 12: case 16: return 8; case 20: return 7; case 32: return 4; default: return 6; }
 }
 
+// ---- cost-ordered claiming (RcClaim::order / cost) -------------------------------------------------------------------------------------
+// Two small kernels turn the chunk costs the previous launch of this shape recorded into this launch's claim order: the reported chunks in
+// nine classes, linear in the lifetime of their longest ray between the reporting threshold and the longest lifetime seen the launch
+// before, longest first; then the chunks nobody reported; chunk ids ascending inside a class (a stable counting sort: k_order_count
+// tallies the classes per 1024-chunk block, k_order_scatter places every chunk, clears its cost for the launch that follows and -- block
+// 0 -- leaves the threshold and the scale of the NEXT launch: the threshold moves so that roughly 10-40 % of the chunks report).
+// ctl[2 * (gen & 1)], ctl[2 * (gen & 1) + 1] = the threshold / the top of the scale launch `gen` works with; the other pair is being written.
+namespace {
+constexpr int kOrderThreads = 256, kOrderPerThread = 4, kOrderTile = kOrderThreads * kOrderPerThread, kOrderClasses = 10, kOrderMaxBlocks = 256;
+__device__ inline int order_class(uint32_t c, uint32_t thr, uint32_t top) {
+    if (c == 0u) return kOrderClasses - 1;
+    const uint32_t span = top > thr ? top - thr + 1u : 1u, above = c > thr ? c - thr : 0u;
+    const uint32_t q = above * (uint32_t)(kOrderClasses - 1) / span;  // 0 .. 8 (and beyond when this launch's rays outlived the scale)
+    return q >= (uint32_t)(kOrderClasses - 1) ? 0 : (int)(kOrderClasses - 2) - (int)q;
+}
+__global__ __launch_bounds__(kOrderThreads) void k_order_count(const uint32_t* cost, const uint32_t* ctl, uint32_t parity, uint32_t* counts, uint32_t n_chunks) {
+    __shared__ uint32_t cnt[kOrderClasses + 1];
+    if (threadIdx.x <= kOrderClasses) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t thr = ctl[2u * parity], top = ctl[2u * parity + 1u];
+    const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
+    uint32_t mx = 0u;
+    for (int j = 0; j < kOrderPerThread; ++j)
+        if (first + j < n_chunks) { const uint32_t c = cost[first + j]; atomicAdd(&cnt[order_class(c, thr, top)], 1u); mx = c > mx ? c : mx; }
+    if (mx) atomicMax(&cnt[kOrderClasses], mx);
+    __syncthreads();
+    if (threadIdx.x <= kOrderClasses) counts[blockIdx.x * (kOrderClasses + 1) + threadIdx.x] = cnt[threadIdx.x];  // [classes ..., block maximum]
+}
+__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost, uint32_t* order, uint32_t* ctl, uint32_t parity, const uint32_t* counts, uint32_t n_chunks) {
+    typedef hipcub::BlockScan<unsigned long long, kOrderThreads> Scan;
+    __shared__ typename Scan::TempStorage scan_tmp;
+    __shared__ uint32_t total[kOrderClasses + 1], before[kOrderClasses];  // chunks of class k in all blocks (last: the maximum cost) / in the blocks before this one
+    if (threadIdx.x <= kOrderClasses) { total[threadIdx.x] = 0u; if (threadIdx.x < kOrderClasses) before[threadIdx.x] = 0u; }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += kOrderThreads) {
+        for (int k = 0; k < kOrderClasses; ++k) {
+            const uint32_t c = counts[b * (kOrderClasses + 1) + k];
+            if (c) { atomicAdd(&total[k], c); if (b < blockIdx.x) atomicAdd(&before[k], c); }
+        }
+        atomicMax(&total[kOrderClasses], counts[b * (kOrderClasses + 1) + kOrderClasses]);
+    }
+    __syncthreads();
+    const uint32_t thr = ctl[2u * parity], top = ctl[2u * parity + 1u];
+    const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
+    int cls[kOrderPerThread];
+    unsigned long long packed[2] = {0ull, 0ull};  // this thread's chunks per class, 12 bits each, five classes per word
+    for (int j = 0; j < kOrderPerThread; ++j) {
+        cls[j] = first + j < n_chunks ? order_class(cost[first + j], thr, top) : -1;
+        if (cls[j] >= 0) packed[cls[j] / 5] += 1ull << (12 * (cls[j] % 5));
+    }
+    unsigned long long prefix[2];
+    Scan(scan_tmp).ExclusiveSum(packed[0], prefix[0]);
+    __syncthreads();
+    Scan(scan_tmp).ExclusiveSum(packed[1], prefix[1]);
+    uint32_t pos[kOrderClasses], acc = 0;
+    for (int k = 0; k < kOrderClasses; ++k) { pos[k] = acc + before[k] + (uint32_t)((prefix[k / 5] >> (12 * (k % 5))) & 0xFFFull); acc += total[k]; }
+    for (int j = 0; j < kOrderPerThread; ++j)
+        if (cls[j] >= 0) { order[pos[cls[j]]++] = first + j; cost[first + j] = 0u; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t reported = n_chunks - total[kOrderClasses - 1];
+        uint32_t next = thr;
+        if (reported * 5u > n_chunks * 2u) next += (next >> 2) + 1u;        // more than 40 % of the chunks reported: raise the bar
+        else if (reported * 10u < n_chunks && next > 2u) next -= next >> 2;  // fewer than 10 %: lower it
+        ctl[2u * (parity ^ 1u)] = next;
+        ctl[2u * (parity ^ 1u) + 1u] = total[kOrderClasses] > next ? total[kOrderClasses] : next + 8u;  // the longest lifetime just seen scales the next launch's classes
+    }
+}
+}  // namespace
+
+// The history entry of a launch shape (batch size, mode, chunk geometry, stream): launches on one stream are ordered, so its buffers have
+// one user at a time; another stream gets its own entry.  Returns false when cost ordering does not apply to this launch.
+static bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t stream, rc::RcClaim& c) {
+    const uint64_t n_base64 = (n + c.pool - 1) / c.pool;  // chunks (the claim order permutes whole chunks; parts follow their chunk)
+    // only where the order can matter: at least a claim per wave; the cost path maps rays to chunks with a shift (pool a power of two)
+    if (!s->opt.cost_order || c.n_chunks < c.total_waves || n_base64 < 64u || n_base64 > (uint64_t)(kOrderTile * kOrderMaxBlocks) || (c.pool & (c.pool - 1u)) != 0u || c.pool < 16u) return false;
+    const uint32_t n_base = (uint32_t)n_base64;
+    rc_scene::ChunkHistory* h = nullptr;
+    for (auto& e : s->histories)
+        if (e.n_items == n && e.any == any_hit && e.stream == stream && e.pool == c.pool) { h = &e; break; }
+    if (!h) {
+        if (s->histories.size() == (size_t)rc_scene::kMaxHistories) {  // evict the least recently used shape; its stream may still be running a launch that records costs
+            size_t victim = 0;
+            for (size_t i = 1; i < s->histories.size(); ++i) if (s->histories[i].last_use < s->histories[victim].last_use) victim = i;
+            if (hipStreamSynchronize(s->histories[victim].stream) != hipSuccess) { (void)hipGetLastError(); RC_HIP(hipDeviceSynchronize()); }
+            s->histories.erase(s->histories.begin() + victim);
+        }
+        s->histories.emplace_back();
+        h = &s->histories.back();
+        h->n_items = n; h->any = any_hit; h->stream = stream; h->n_chunks = n_base; h->pool = c.pool;
+        h->cost.reserve(n_base); h->order.reserve(n_base); h->ctl.reserve(4 + (size_t)kOrderMaxBlocks * (kOrderClasses + 1));
+        RC_HIP(hipMemsetAsync(h->cost.p, 0, sizeof(uint32_t) * n_base, stream));
+        RC_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->ctl.p), (int)s->opt.cost_thr, 4, stream));  // (threshold, top of the scale) x 2 parities: the scale is learned by the first ordered launch
+        h->gen = 0;
+    }
+    h->last_use = ++s->history_clock;
+    h->gen += 1;
+    const uint32_t parity = (uint32_t)(h->gen & 1u);
+    if (h->gen > 1) {  // the previous launch of this shape left its chunk costs: build the claim order from them (and clear them)
+        const uint32_t blocks = (n_base + kOrderTile - 1) / kOrderTile;
+        hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->ctl.p, parity, h->ctl.p + 4, n_base);
+        hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->order.p, h->ctl.p, parity, h->ctl.p + 4, n_base);
+        c.order = h->order.p;
+    }
+    c.cost = h->cost.p;
+    c.life_thr_ptr = h->ctl.p + 2u * parity;
+    return true;
+}
+
 void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream) {
     if (n == 0) return;
     RcLaunchGuard launch(s, stream);  // serialises the enqueue: trace calls on one scene may come from several host threads
@@ -640,6 +758,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
         a.tlas_k = s->tlas_top_k; a.blas_k = s->opt.blas_top ? s->blas_top_k : 0; a.lds_blas_base = s->tlas_top_k;
     }
     launch.start();
+    if ((kernel == 3 || kernel == 5 || kernel == 6) && !launch.capturing) rc_cost_order_setup(s, n, any_hit, stream, a.claim);  // (inside the timed region: the order kernel is part of the launch's cost)
     if (any_hit) launch_variant<true>(s, kernel, a, blocks, stream); else launch_variant<false>(s, kernel, a, blocks, stream);
     launch.finish();
 }

@@ -39,21 +39,32 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
 // launch, and the wave whose failed claim is the last of them puts the counter back to zero -- no memset node between back-to-back
 // launches (6 us, 1 % of a 4 M-ray launch, 3 % of a 1 M-ray one), nothing a later launch could clear under an earlier one, and
 // a launch that is never enqueued leaves nothing behind.
-// Chunk sizes taper towards the end of a batch (guided self-scheduling, option "taper"): chunks [0, g1) hold `pool` items, [g1, g2)
-// pool / 2, [g2, g3) pool / 4, the rest pool / 8, with the boundaries placed where the items still to be handed out equal taper / 8 x
-// (chunk size) x (waves of the launch).  Large chunks keep a wave's lanes on neighbouring rays (coherent fetches) while there is plenty
-// of work; small ones at the end let the waves run dry together -- a launch lasts until the LAST claimed chunk has been traced, and a
-// 128-ray chunk is two generations of a wave's lanes (~150 us on C2).  taper = 0: every chunk holds `pool` items.
+// Work is cut into chunks of `pool` consecutive items.  Towards the END OF THE CLAIM ORDER a chunk is dealt out in parts (guided
+// self-scheduling, option "taper"): the first G1 claims take a whole chunk each, then come chunks dealt in halves, quarters and eighths,
+// with the boundaries placed where the items still to be handed out equal taper / 8 x (part size) x (waves of the launch).  Large claims
+// keep a wave's lanes on neighbouring rays (coherent fetches) while there is plenty of work; small ones at the end let the waves run dry
+// together -- a launch lasts until the LAST claimed part has been traced, and 128 rays are two generations of a wave's lanes (~150 us on
+// C2).  taper = 0: every claim is a whole chunk.
+// Cost-ordered claiming (host side: ChunkHistory, rc_traverse.hip): WHICH chunk the p-th position of the claim order stands for is either p
+// itself or order[p], a permutation built on the device from what the previous launch of the same shape recorded.  A launch lasts until
+// its longest rays are done, and a long ray that sits in a chunk claimed late STARTS late; chunks that held long rays the last time are
+// therefore claimed first, whole (longest-processing-time-first with the previous launch as the predictor: render loops, repeated
+// queries), and the cheap ones end the launch in small parts.
 struct RcClaim {
     uint32_t* counters;            // kClaimShards words, kShardStrideWords apart, zero between launches
     uint32_t shard_shift;          // n_shards = 1 << shard_shift <= kClaimShards and <= the waves of the launch (every shard has a wave)
-    uint32_t n_chunks;             // chunks of the launch, < 2^31
-    uint32_t pool;                 // items per full-size claim
+    uint32_t n_chunks;             // CLAIMS of the launch (whole chunks + parts), < 2^31
+    uint32_t pool;                 // items per chunk
     uint32_t total_waves;          // waves of the launch: wave w claims from shard w & (n_shards - 1)
-    uint32_t g1, g2, g3;           // first chunk of the pool / 2, pool / 4, pool / 8 pieces (= n_chunks when a piece is empty)
-    unsigned long long r1, r2, r3; // first item of those pieces
+    uint32_t g1, g2, g3;           // first claim that takes half / a quarter / an eighth of a chunk (= n_chunks when there is none)
+    uint32_t c1, c2, c3;           // position in the claim order of the first chunk dealt in halves / quarters / eighths
+    const uint32_t* order;         // position in the claim order -> chunk, a permutation of 0 .. ceil(n_items / pool) - 1; nullptr = natural order
+    uint32_t* cost;                // per chunk: the longest time in flight (interior iterations of its wave) of a ray of the chunk this launch; nullptr = not recorded
+    const uint32_t* life_thr_ptr;  // [0] = only rays that were in flight at least this long report (adapted by k_order_scatter so that a minority of the chunks do)
+    uint32_t pool_shift;           // log2(pool) when pool is a power of two (the cost path maps a ray to its chunk with a shift)
 };
-// Wave-uniform: the next chunk of this wave's shard, or false when the shard has run dry.  `wave_id` must be the same in all lanes.
+// Wave-uniform: the next claim of this wave's shard, or false when the shard has run dry.  `wave_id` must be the same in all lanes.
+// (A part that lies beyond the end of the batch -- in the last, incomplete chunk -- comes back empty; the caller simply claims again.)
 __device__ inline bool rc_claim_chunk(const RcClaim& c, uint32_t wave_id, int lane, uint64_t n_items, unsigned long long& pool_next,
                                       unsigned long long& pool_end) {
     const uint32_t n = 1u << c.shard_shift;
@@ -62,7 +73,7 @@ __device__ inline bool rc_claim_chunk(const RcClaim& c, uint32_t wave_id, int la
     uint32_t got = 0;
     if (lane == 0) got = atomicAdd(counter, 1u);
     const uint32_t cs = __builtin_amdgcn_readfirstlane(got);
-    // round cs of the shards takes chunks cs * n .. cs * n + n - 1, rotated per round; this shard's share of the chunks:
+    // round cs of the shards takes claims cs * n .. cs * n + n - 1, rotated per round; this shard's share of the claims:
     const uint32_t full_rounds = c.n_chunks >> c.shard_shift, rem = c.n_chunks & (n - 1u);
     const uint32_t my_chunks = full_rounds + ((((my_shard + full_rounds * 5u) & (n - 1u)) < rem) ? 1u : 0u);
     if (cs >= my_chunks) {  // dry.  The last of this shard's waves to find it so -- nobody touches the counter after it -- zeroes it for the next launch
@@ -70,14 +81,18 @@ __device__ inline bool rc_claim_chunk(const RcClaim& c, uint32_t wave_id, int la
         if (cs + 1u == my_chunks + my_waves && lane == 0) atomicExch(counter, 0u);
         return false;
     }
-    const uint32_t chunk_id = (cs << c.shard_shift) + ((my_shard + cs * 5u) & (n - 1u));
-    uint32_t size = c.pool;  // wave-uniform: all of this is scalar arithmetic
-    if (chunk_id < c.g1) pool_next = (unsigned long long)chunk_id * size;
-    else if (chunk_id < c.g2) { size >>= 1; pool_next = c.r1 + (unsigned long long)(chunk_id - c.g1) * size; }
-    else if (chunk_id < c.g3) { size >>= 2; pool_next = c.r2 + (unsigned long long)(chunk_id - c.g2) * size; }
-    else { size >>= 3; pool_next = c.r3 + (unsigned long long)(chunk_id - c.g3) * size; }
+    const uint32_t v = (cs << c.shard_shift) + ((my_shard + cs * 5u) & (n - 1u));  // claim index; everything below is scalar arithmetic
+    uint32_t pos, part = 0u, shift = 0u;
+    if (v < c.g1) pos = v;
+    else if (v < c.g2) { const uint32_t u = v - c.g1; pos = c.c1 + (u >> 1); part = u & 1u; shift = 1u; }
+    else if (v < c.g3) { const uint32_t u = v - c.g2; pos = c.c2 + (u >> 2); part = u & 3u; shift = 2u; }
+    else { const uint32_t u = v - c.g3; pos = c.c3 + (u >> 3); part = u & 7u; shift = 3u; }
+    const uint32_t chunk = c.order ? __builtin_amdgcn_readfirstlane(c.order[pos]) : pos;
+    const uint32_t size = c.pool >> shift;
+    pool_next = (unsigned long long)chunk * c.pool + (unsigned long long)part * size;
     pool_end = pool_next + size;
     if (pool_end > n_items) pool_end = n_items;
+    if (pool_next > pool_end) pool_next = pool_end;
     return true;
 }
 
@@ -503,6 +518,11 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     uint32_t closest_prim = RC_INVALID_NODE, cur_off = 0, n_level = 0;
     uint32_t node = RC_INVALID_NODE;  // INVALID + !live = empty lane; INVALID + live = finished, result pending
     int closest_inst = -1, cur_inst = -1;
+    // cost-ordered claiming (RcClaim::cost): a ray's cost = the interior-loop iterations its wave ran while the ray was in flight -- the time
+    // the ray occupied its lane, in the unit the launch's tail is made of.  The wave's iteration count lives in a scalar register and every
+    // lane remembers the count at which its ray started: no per-iteration vector work.
+    uint32_t it_total = 0, start_it = 0;
+    const uint32_t life_thr = a.claim.cost ? __builtin_amdgcn_readfirstlane(*a.claim.life_thr_ptr) : 0xFFFFFFFFu;
     typename LaneStackP<LDS_N, BLOCK>::pos_t sp = st.empty();
     bool live = false;
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0}, st_outer = 0, st_sub[4] = {0, 0, 0, 0};  // st_sub: passes with an exit lane / an entry lane / a result to write / rays to start
@@ -519,6 +539,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             const bool is_int = node < n_level;  // sentinels and INVALID are >= 0xFFFFFFFE, never below a leaf threshold
             const int n_int = __popcll(__ballot(is_int));
             if (n_int == 0) break;
+            it_total += 1u;
             if (STATS) { st_iter[1] += 1; st_lane[1] += is_int ? 1 : 0; }
             if (TIMELINE) { tl_int += 1; if (tl_tx) tl_int_x += 1; }
             if (is_int) {
@@ -665,6 +686,8 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 if (fin) {
                     sink(my_ray, closest_inst >= 0, closest_t, hit_u, hit_v, closest_prim, closest_inst);
                     live = false;
+                    const uint32_t life = it_total - start_it;
+                    if (a.claim.cost && life >= life_thr) atomicMax(a.claim.cost + (uint32_t)(my_ray >> a.claim.pool_shift), life);
                 }
                 RC_MARK("writeout_end");
                 RC_MARK("finish_begin");
@@ -701,6 +724,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         st.push(sp, RC_INVALID_NODE);
                         node = 1;
                         live = true;
+                        start_it = it_total;
                     }
                     RC_MARK("refill_end");
                     RC_MARK("finish_begin");

@@ -396,3 +396,56 @@ def test_trace_launches_are_hipgraph_capturable(rc, oracle):
         assert np.array_equal(docc.cpu().numpy().view(rc.HIT_DT)["hit"], want_occ["hit"]), rep
     assert t.get_option("claim_drift") == 0
     t.free()
+
+
+def test_cost_ordered_claiming_and_tapered_chunks_change_no_result(rc, oracle):
+    """Scheduling knobs of the persistent kernels: guided chunk sizes (option "taper") and cost-ordered claiming (option "cost_order": the
+    chunks that held long rays in the previous launch of the same shape are claimed first, through a permutation built on the device).
+    Per-ray results cannot depend on either: repeated launches of one batch -- the second and later ones run in the learned order --
+    equal the oracle bit for bit, for closest and any hit, the three phased kernels, two batch sizes interleaved on two streams, and the
+    claim counters end at zero (a claim order that is not a permutation would skip or repeat chunks)."""
+    import torch
+    cfg = rc.scenes.config_c2(30_000, 100)
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    wb = t.world_bound()
+    batches = [random_rays(rc, 900_000, 11, wb.p_min, wb.p_max), random_rays(rc, 1_300_000, 12, wb.p_min, wb.p_max)]
+    want = [(o.trace(b, nthreads=16), o.trace(b, mode="any", nthreads=16)) for b in batches]
+    d_rays = [torch.from_numpy(b.view(np.uint8).reshape(-1)).cuda() for b in batches]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty(len(b) * 32, dtype=torch.uint8, device="cuda") for b in batches]
+    for kernel, taper, cost_order in ((-1, 12, 1), (3, 12, 1), (5, 0, 1), (5, 32, 1), (-1, 12, 0), (-1, 5, 1)):
+        t.set_option("kernel", kernel); t.set_option("taper", taper); t.set_option("cost_order", cost_order)
+        for rep in range(4):
+            for mode_i, mode in enumerate(("closest", "any")):
+                for j in (0, 1):
+                    outs[j].zero_()
+                torch.cuda.synchronize()
+                for j in (0, 1):
+                    t.trace_device(d_rays[j].data_ptr(), outs[j].data_ptr(), len(batches[j]), mode=mode, stream=streams[j].cuda_stream)
+                torch.cuda.synchronize()
+                for j in (0, 1):
+                    got = outs[j].cpu().numpy().view(rc.HIT_DT)
+                    if mode == "closest":
+                        assert_hits_equal(got, want[j][0], f"kernel {kernel} taper {taper} cost_order {cost_order} rep {rep} batch {j}")
+                    else:
+                        assert np.array_equal(got["hit"], want[j][1]["hit"]), f"any: kernel {kernel} taper {taper} cost_order {cost_order} rep {rep} batch {j}"
+        assert t.get_option("claim_drift") == 0
+    # the claim order the device built for the last shape is a permutation of its chunks (read back through the dev options)
+    import ctypes
+    n_order, p_order = t.get_option("debug_order_n"), t.get_option("debug_order_ptr")
+    assert n_order == -(-len(batches[1]) // 128) and p_order
+    order = torch.empty(n_order, dtype=torch.int32, device="cuda")
+    ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(order.data_ptr()), ctypes.c_void_p(p_order), ctypes.c_size_t(4 * n_order), 3)
+    torch.cuda.synchronize()
+    order = order.cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(n_order)) and not np.array_equal(order, np.arange(n_order))  # ... and not the identity: something was learned
+    # more launch shapes than history entries (8): the least recently used one is dropped, nothing breaks
+    t.set_option("kernel", -1); t.set_option("taper", 12); t.set_option("cost_order", 1)
+    for k in range(12):
+        n = 700_000 + 10_007 * k
+        for rep in range(2):
+            t.trace_device(d_rays[1].data_ptr(), outs[1].data_ptr(), n, stream=streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        assert_hits_equal(outs[1].cpu().numpy().view(rc.HIT_DT)[:n], want[1][0][:n], f"shape {k}")
+    assert t.get_option("claim_drift") == 0
+    t.free()

@@ -40,11 +40,18 @@ def run(name, t, o, rays, mode):
     csum = cost[:nc * 128].reshape(nc, 128).sum(axis=1)
     chunk_order = np.argsort(-csum, kind="stable")
     orders["128-ray chunks by total work, heaviest first"] = np.concatenate([(chunk_order[:, None] * 128 + np.arange(128)[None, :]).reshape(-1), np.arange(nc * 128, n)])
+    q = np.minimum(9, (cmax * 10) // (cmax.max() + 1))           # ten linear classes of the chunk's longest ray, stable inside a class
+    chunk_order = np.argsort(-q, kind="stable")
+    orders["128-ray chunks in ten classes of their longest ray"] = np.concatenate([(chunk_order[:, None] * 128 + np.arange(128)[None, :]).reshape(-1), np.arange(nc * 128, n)])
+    heavy = cmax >= np.percentile(cost, 99)
+    chunk_order = np.argsort(~heavy, kind="stable")
+    orders["128-ray chunks holding a ray above the 99th percentile first"] = np.concatenate([(chunk_order[:, None] * 128 + np.arange(128)[None, :]).reshape(-1), np.arange(nc * 128, n)])
     # long rays first, but only the top 5 % moved to the front (keeps the rest of the image coherent)
     top = np.argsort(-cost, kind="stable")[: n // 20]
     mask = np.ones(n, bool); mask[top] = False
     orders["longest 5 % of the rays first, the rest in natural order"] = np.concatenate([top, np.nonzero(mask)[0]])
     ref = None
+    t.set_option("cost_order", 0)
     for taper in (0, 12):
         t.set_option("taper", taper)
         for label, perm in orders.items():
@@ -53,7 +60,13 @@ def run(name, t, o, rays, mode):
             if ref is None: ref = back
             same = back.tobytes() == ref.tobytes()
             print(f"   taper {taper:2d}  {label:60s} {ms:7.3f} ms  {n / ms / 1e3:8.1f} Mrays/s  same hits: {same}", flush=True)
-    t.set_option("taper", 0)
+    t.set_option("taper", 12)
+    for label, opts in (("product: taper 12, cost_order off", {"cost_order": 0}), ("product: cost_order on (learned from the previous launch)", {"cost_order": 1, "cost_thr": 64}),
+                        ("product: cost_order machinery with nothing to report (identity order: its overhead)", {"cost_order": 1, "cost_thr": 4096})):
+        for k, v in opts.items(): t.set_option(k, v)
+        ms, hits = timed(t, rays, mode, reps=8)
+        print(f"   {label:95s} {ms:7.3f} ms  {n / ms / 1e3:8.1f} Mrays/s  same hits: {hits.tobytes() == ref.tobytes()}", flush=True)
+    t.set_option("cost_order", 1); t.set_option("cost_thr", 64)
 
 sc = rc.scenes
 cfg2 = sc.config_c2(); t2 = build(cfg2); o2 = oracle_of(cfg2)
