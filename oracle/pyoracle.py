@@ -68,6 +68,7 @@ def lib():
         L.rco_closest_hit.argtypes = [vp, vp, vp, vp]
         L.rco_any_hit.argtypes = [vp, vp, vp, vp]
         L.rco_trace_batch.argtypes = [vp, vp, vp, u64, C.c_int, C.c_int, vp]
+        L.rco_trace_deferred_batch.argtypes = [vp, vp, vp, u64, C.c_uint32, C.c_int]
         L.rco_pool_pin.argtypes = [C.c_int]
         L.rco_allowed_cpus.restype = C.c_int
         L.rco_brute_closest.argtypes = [vp, vp, vp]
@@ -237,6 +238,13 @@ class Scene:
         cnt = np.zeros((len(rays), 2), dtype=np.uint32) if counters else None
         lib().rco_trace_batch(self._h, _p(rays), _p(hits), len(rays), 0 if mode == "closest" else 1, nthreads, _p(cnt))
         return (hits, cnt) if counters else hits
+
+    def trace_deferred(self, rays, lag, nthreads=1):
+        """dev experiment: closest_hit whose leaf-test results arrive `lag` loop iterations late (lag 0 = the reference algorithm)."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DT)
+        hits = np.zeros(len(rays), dtype=HIT_DT)
+        lib().rco_trace_deferred_batch(self._h, _p(rays), _p(hits), len(rays), int(lag), nthreads)
+        return hits
 
     def brute(self, rays):
         rays = np.ascontiguousarray(rays, dtype=RAY_DT)

@@ -691,6 +691,81 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
     }
 }
 
+/* dev experiment ("why leaf tests cannot be taken off the critical path"): closest_hit with every leaf test's RESULT arriving
+ * `lag` loop iterations late -- what a kernel would compute if a lane posted its triangle tests to a shared queue and went on walking
+ * interior nodes until the answer came back.  The queued tests are resolved in visit order against the then-current closest t (so a hit
+ * is still "the first minimum, later equal t replaces"), but the box tests in between prune with a STALE closest t: subtrees the reference
+ * prunes are entered, and a triangle in such a subtree whose computed t is <= the closest t -- its box's computed entry was just above it,
+ * the two are different roundings of nearly equal numbers, and exactly equal for duplicated geometry -- is accepted although the
+ * reference never tested it.  tests/test_oracle_properties.py counts the rays this changes. */
+typedef struct { const rco_node* node; int32_t inst; v3 o, d; uint32_t due; } pending_leaf;
+static void traverse_deferred(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_t lag) {
+    set_miss(out);
+    if (s->n_nodes == 0) return;
+    v3 world_o = V(r->ox, r->oy, r->oz);
+    v3 world_d = V(r->dx == 0.0f ? 0.0f : r->dx, r->dy == 0.0f ? 0.0f : r->dy, r->dz == 0.0f ? 0.0f : r->dz);
+    v3 ray_o = world_o, ray_d = world_d;
+    float ray_mint = r->tmin, ray_maxt = r->tmax;
+    v3 ray_inv_d = safe_invdir(ray_d);
+    uint32_t stack[RCO_STACK];
+    int32_t sp = 1;
+    stack[0] = RCO_INVALID_NODE;
+    int32_t current_instance = -1, closest_instance = -1;
+    uint32_t closest_prim = RCO_INVALID_NODE, node_index = 1, current_blas_offset = 0, step = 0;
+    float hit_u = 0.0f, hit_v = 0.0f;
+    enum { QCAP = 64 };
+    pending_leaf q[QCAP];
+    uint32_t q_head = 0, q_tail = 0;
+#define RESOLVE_DUE(all) while (q_head != q_tail && ((all) || q[q_head % QCAP].due <= step)) { \
+        const pending_leaf* p = &q[q_head++ % QCAP]; float t, u, v; \
+        if (fast_intersect_triangle(p->o, p->d, v3_from(p->node->aabb0_min), v3_from(p->node->aabb0_max), v3_from(p->node->aabb1_min), ray_mint, ray_maxt, &t, &u, &v)) { \
+            ray_maxt = t; closest_instance = p->inst; closest_prim = p->node->child1; hit_u = u; hit_v = v; } }
+    while (node_index != RCO_INVALID_NODE) {
+        ++step;
+        RESOLVE_DUE(0)
+        const rco_node* node = (current_instance < 0) ? &s->nodes[node_index - 1] : &s->blas_nodes[current_blas_offset + node_index - 1];
+        if (node->child0 != RCO_INVALID_NODE) {
+            uint32_t near_c, far_c;
+            intersect_internal_node(node, ray_inv_d, ray_o, ray_mint, ray_maxt, &near_c, &far_c);
+            if (far_c != RCO_INVALID_NODE && sp < RCO_STACK) stack[sp++] = far_c;
+            if (near_c != RCO_INVALID_NODE) { node_index = near_c; continue; }
+        } else if (current_instance < 0) {
+            current_instance = (int32_t)node->child1;
+            if (sp < RCO_STACK) stack[sp++] = RCO_TOP_LEVEL_SENTINEL;
+            node_index = 1;
+            const rco_instance* inst = &s->inst[current_instance];
+            current_blas_offset = s->descs[inst->blas_index - 1].nodes_offset;
+            ray_o = xf_point(inst->inv_transform, world_o);
+            ray_d = xf_dir(inst->inv_transform, world_d);
+            ray_inv_d = safe_invdir(ray_d);
+            continue;
+        } else {
+            if (q_tail - q_head == QCAP) { RESOLVE_DUE(1) }
+            pending_leaf* p = &q[q_tail++ % QCAP];
+            p->node = node; p->inst = current_instance; p->o = ray_o; p->d = ray_d; p->due = step + lag;
+            if (lag == 0) { RESOLVE_DUE(1) }
+        }
+        node_index = stack[--sp];
+        if (node_index == RCO_TOP_LEVEL_SENTINEL) {
+            node_index = stack[--sp];
+            current_instance = -1;
+            ray_o = world_o; ray_d = world_d;
+            ray_inv_d = safe_invdir(ray_d);
+        }
+    }
+    RESOLVE_DUE(1)
+#undef RESOLVE_DUE
+    if (closest_instance >= 0) {
+        const rco_instance* inst = &s->inst[closest_instance];
+        const rco_blas_desc* desc = &s->descs[inst->blas_index - 1];
+        out->hit = 1; out->t = ray_maxt; out->bary_u = hit_u; out->bary_v = hit_v;
+        out->primitive_id = desc->primitives_offset + closest_prim - 1;
+        out->instance_id = (uint32_t)closest_instance;
+        out->instance_custom_index = inst->instance_id;
+    }
+}
+typedef struct { const rco_scene* s; const rco_ray* rays; rco_hit* hits; uint32_t lag; } deferred_ctx;
+static void deferred_range(void* p, uint64_t b, uint64_t e);
 void rco_closest_hit(const rco_scene* s, const rco_ray* r, rco_hit* h, uint32_t* c) { traverse(s, r, h, c, 0); }
 /* dev: trace one ray and record its step events (see tl_ev); returns the number of steps (may exceed cap: then only cap were stored) */
 uint32_t rco_trace_events(const rco_scene* s, const rco_ray* r, int any, uint8_t* events, uint8_t* depths, uint32_t cap) {
@@ -823,6 +898,14 @@ typedef struct { const rco_scene* s; const rco_ray* rays; rco_hit* hits; int mod
 static void trace_range(void* p, uint64_t b, uint64_t e) {
     trace_ctx* c = (trace_ctx*)p;
     for (uint64_t i = b; i < e; ++i) traverse(c->s, &c->rays[i], &c->hits[i], c->counters ? c->counters + 2 * i : NULL, c->mode);
+}
+static void deferred_range(void* p, uint64_t b, uint64_t e) {
+    deferred_ctx* c = (deferred_ctx*)p;
+    for (uint64_t i = b; i < e; ++i) traverse_deferred(c->s, &c->rays[i], &c->hits[i], c->lag);
+}
+void rco_trace_deferred_batch(const rco_scene* s, const rco_ray* rays, rco_hit* hits, uint64_t n, uint32_t lag, int nthreads) {
+    deferred_ctx c = {s, rays, hits, lag};
+    parallel_for(n, nthreads, deferred_range, &c);
 }
 void rco_trace_batch(const rco_scene* s, const rco_ray* rays, rco_hit* hits, uint64_t n, int mode, int nthreads, uint32_t* counters) {
     if (counters) memset(counters, 0, sizeof(uint32_t) * 2 * n);

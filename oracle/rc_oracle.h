@@ -102,6 +102,8 @@ void rco_closest_hit(const rco_scene*, const rco_ray*, rco_hit*, uint32_t* count
 void rco_any_hit(const rco_scene*, const rco_ray*, rco_hit*, uint32_t* counters);
 /* Batch over n rays with nthreads pthreads (mirrors Threads.@threads, src/kernels.jl:64).
  * mode 0 = closest, 1 = any.  counters: NULL or n x 2 u32 (zeroed by the callee). */
+/* dev experiment: closest_hit with leaf-test results arriving `lag` loop iterations late (lag 0 = the reference algorithm) */
+void rco_trace_deferred_batch(const rco_scene*, const rco_ray* rays, rco_hit* hits, uint64_t n, uint32_t lag, int nthreads);
 /* worker k of the thread pool pinned to the k-th allowed CPU (before the pool's first use); CPUs this process may run on */
 void rco_pool_pin(int enable);
 int rco_allowed_cpus(void);

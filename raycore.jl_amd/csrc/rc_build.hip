@@ -571,7 +571,8 @@ __global__ __launch_bounds__(kTopBlock) void k_top_remap(const RcNode* nodes, ui
     if (t < total) remap[d_list[t] - 1] = v_list[t];
     if (t < n_top) remap[top[t] - 1] = t + 1u;
 }
-__global__ void k_pack_nodes_remap(const RcNode* src, RcNode* dst, uint32_t n_nodes, uint32_t n_leaves, const uint32_t* remap) {
+// (blas: the leaves -- nodes n_leaves .. 2 n_leaves - 1 -- hold triangles and take the leaf packing; a TLAS's leaves hold instance boxes)
+__global__ void k_pack_nodes_remap(const RcNode* src, RcNode* dst, uint32_t n_nodes, uint32_t n_leaves, const uint32_t* remap, bool blas) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     RcNode nd = src[i];
@@ -581,13 +582,14 @@ __global__ void k_pack_nodes_remap(const RcNode* src, RcNode* dst, uint32_t n_no
         if (nd.child1 < n_leaves) nd.child1 = remap[nd.child1 - 1];
         at = remap[i] - 1u;
     }
-    dst[at] = rc_pack_node(nd);
+    dst[at] = (blas && i + 1u >= n_leaves) ? rc_pack_leaf(nd) : rc_pack_node(nd);
 }
 
-// Traversal copy of a node array in the packed order of rc_pack_node.
-__global__ void k_pack_nodes(const RcNode* src, RcNode* dst, uint32_t n) {
+// Traversal copy of a node array in the packed order of rc_pack_node (interior nodes, TLAS leaves) / rc_pack_leaf (the triangles of a BLAS:
+// nodes n_leaves .. of a tree with n_leaves leaves; blas_leaves = 0 for a TLAS).
+__global__ void k_pack_nodes(const RcNode* src, RcNode* dst, uint32_t n, uint32_t blas_leaves) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = rc_pack_node(src[i]);
+    if (i < n) dst[i] = (blas_leaves && i + 1u >= blas_leaves) ? rc_pack_leaf(src[i]) : rc_pack_node(src[i]);
 }
 
 // Traversal-side instance records: inverse transform + the BLAS offsets it would otherwise chase.
@@ -770,8 +772,8 @@ void rc_build_blas(rc_scene* s, uint32_t n, Blas& out, bool keep_face_map) {
 // The TLAS part of the traversal copy (behind the BLAS nodes), renumbered when the scene keeps the TLAS's top in LDS (tlas_top_k).
 static void pack_tlas(rc_scene* s) {
     const uint32_t n = (s->n_tlas_nodes + 1) / 2;
-    if (s->tlas_top_k) hipLaunchKernelGGL(k_pack_nodes_remap, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes, n, s->tlas_remap.p);
-    else hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes);
+    if (s->tlas_top_k) hipLaunchKernelGGL(k_pack_nodes_remap, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes, n, s->tlas_remap.p, false);
+    else hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->n_tlas_nodes)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, s->flat_nodes.p + s->n_flat_nodes, s->n_tlas_nodes, 0u);
 }
 
 // build_flat_blas_arrays! (:470-517) + the traversal instance records.
@@ -821,8 +823,8 @@ void rc_build_tlas(rc_scene* s) {
         hipLaunchKernelGGL(k_top_remap, dim3(1), dim3(kTopBlock), 0, s->stream, s->blas[0].nodes.p, n_leaves, s->blas_top_k, s->top_remap.p);
     }
     for (uint32_t i = 0; i < nb; ++i) {
-        if (s->blas_top_k) hipLaunchKernelGGL(k_pack_nodes_remap, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes, s->blas[i].n_prims, s->top_remap.p);
-        else hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes);
+        if (s->blas_top_k) hipLaunchKernelGGL(k_pack_nodes_remap, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes, s->blas[i].n_prims, s->top_remap.p, true);
+        else hipLaunchKernelGGL(k_pack_nodes, dim3(grid_for(s->blas[i].n_nodes)), dim3(kBlock), 0, s->stream, s->blas[i].nodes.p, s->flat_nodes.p + s->descs[i].nodes_offset, s->blas[i].n_nodes, s->blas[i].n_prims);
         RC_HIP(hipMemcpyAsync(s->flat_prims.p + s->descs[i].primitives_offset, s->blas[i].prims.p, sizeof(RcPrim) * s->blas[i].n_prims, hipMemcpyDeviceToDevice, s->stream));
     }
     if (nb) RC_HIP(hipMemcpyAsync(s->d_descs.p, s->descs.data(), sizeof(RcBlasDesc) * nb, hipMemcpyHostToDevice, s->stream));

@@ -37,6 +37,25 @@ __host__ __device__ inline RcNode rc_pack_node(const RcNode& n) {
     return p;
 }
 
+// Traversal copy of a BLAS LEAF (round 3).  The canonical record holds v0, v1, v2 (BVH2IL layout); the Moeller-Trumbore test needs v0 and
+// the edges e1 = v1 - v0, e2 = v2 - v0, and its two cross products d x e2 and (o - v0) x e1 are, two components at a time,
+//   (a.y, a.z) * (b.z, b.x) - (a.z, a.x) * (b.y, b.z)
+// -- packed-f32 work on the pairs (y, z) and (z, x) of one operand and (z, x) and (y, z) of the other.  So the copy stores exactly those
+// pairs, 8-byte aligned: three 16-byte loads land them in even-aligned register pairs and the test is 8 packed + ~30 plain VALU instead
+// of ~70 with 21 register moves (the compiler's pairing of the straightforward form).  The edges are the SAME IEEE subtractions the test
+// did per ray, done once per leaf at pack time: bit-identical results.
+//   dword 0..3  = v0.y, v0.z, v0.z, v0.x        dword 4..7 = e1.z, e1.x, e1.y, e1.z        dword 8..11 = e2.z, e2.x, e2.y, e2.z
+__host__ __device__ inline RcNode rc_pack_leaf(const RcNode& n) {
+    RcNode p;
+    const float e1x = n.f[3] - n.f[0], e1y = n.f[4] - n.f[1], e1z = n.f[5] - n.f[2];
+    const float e2x = n.f[6] - n.f[0], e2y = n.f[7] - n.f[1], e2z = n.f[8] - n.f[2];
+    p.f[0] = n.f[1]; p.f[1] = n.f[2]; p.f[2] = n.f[2]; p.f[3] = n.f[0];
+    p.f[4] = e1z; p.f[5] = e1x; p.f[6] = e1y; p.f[7] = e1z;
+    p.f[8] = e2z; p.f[9] = e2x; p.f[10] = e2y; p.f[11] = e2z;
+    p.child0 = n.child0; p.child1 = n.child1; p.parent = n.parent; p.pad = 0;
+    return p;
+}
+
 // Traversal record of a BVHNode4 (src/bvh4.jl:40-69), 128 bytes; word layout documented in rc_bvh4.hip.
 struct __attribute__((aligned(128))) RcNode4 {
     uint32_t w[32];

@@ -291,10 +291,9 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                 const RcNode* np = nodes + (cur_off + node - 1);
                 const float4* q = reinterpret_cast<const float4*>(np);
                 const float4 na = q[0];
-                const float2 nb = *reinterpret_cast<const float2*>(q + 1);
+                const float4 nb = q[1];
                 const float4 nc = q[2];
-                const float3_ v0 = mk3(na.x, na.y, nc.x), v1 = mk3(na.z, na.w, nc.y), v2 = mk3(nb.x, nb.y, nc.z);  // packed order
-                const float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
+                const float3_ v0 = mk3(na.w, na.x, na.y), e1 = mk3(nb.y, nb.z, nb.x), e2 = mk3(nc.y, nc.z, nc.x);  // rc_pack_leaf: v0 and the edges
                 const float3_ s1 = cross3(d, e2);
                 const float det = dot3(s1, e1);
                 const float invd = 1.0f / det;

@@ -266,9 +266,9 @@ __device__ inline bool step(RayState& s, const SceneView& a, Stack& st) {
         s.ox = mk3(-s.o.x * s.inv.x, -s.o.y * s.inv.y, -s.o.z * s.inv.z);
         return true;
     } else {
-        // bottom-level leaf: fast_intersect_triangle (:1756-1797) on the vertices stored in the node
-        float3_ v0 = mk3(nd.a.x, nd.a.y, nd.c.x), v1 = mk3(nd.a.z, nd.a.w, nd.c.y), v2 = mk3(nd.b.x, nd.b.y, nd.c.z);
-        float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
+        // bottom-level leaf: fast_intersect_triangle (:1756-1797) on the leaf record (rc_pack_leaf: v0 and the edges e1 = v1 - v0, e2 = v2 - v0,
+        // the subtractions of :1766-1767 done once at pack time)
+        float3_ v0 = mk3(nd.a.w, nd.a.x, nd.a.y), e1 = mk3(nd.b.y, nd.b.z, nd.b.x), e2 = mk3(nd.c.y, nd.c.z, nd.c.x);
         float3_ s1 = cross3(s.d, e2);
         float det = dot3(s1, e1);
         float invd = 1.0f / det;
@@ -513,7 +513,9 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     bool exhausted = false;
     uint64_t my_ray = 0;
     float3_ wo = mk3(0, 0, 0), wd = mk3(0, 0, 0), winv = mk3(0, 0, 0);
-    float3_ o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0), ox = mk3(0, 0, 0);
+    float3_ inv = mk3(0, 0, 0), ox = mk3(0, 0, 0);
+    // the instance-local ray, kept as the component pairs the packed triangle test multiplies (rc_pack_leaf): (y, z) and (z, x) of o and d
+    v2f oyz = {0.f, 0.f}, ozx = {0.f, 0.f}, dyz = {0.f, 0.f}, dzx = {0.f, 0.f};
     float tmin = 0.f, closest_t = 0.f, hit_u = 0.f, hit_v = 0.f;
     uint32_t closest_prim = RC_INVALID_NODE, cur_off = 0, n_level = 0;
     uint32_t node = RC_INVALID_NODE;  // INVALID + !live = empty lane; INVALID + live = finished, result pending
@@ -586,19 +588,23 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             RC_MARK("leaf_begin");
             if (is_leaf) {
                 const uint32_t off = (cur_off + node) << 6;
-                const float4 na = buf_f4(nrs1, off);
-                const float2 nb = buf_f2(nrs1, off, 16);
-                const float4 nc = buf_f4(nrs1, off, 32);
-                const float3_ v0 = mk3(na.x, na.y, nc.x), v1 = mk3(na.z, na.w, nc.y), v2 = mk3(nb.x, nb.y, nc.z);  // packed order
-                const float3_ e1 = sub3(v1, v0), e2 = sub3(v2, v0);
-                const float3_ s1 = cross3(d, e2);
-                const float det = dot3(s1, e1);
+                const float4 qa = buf_f4(nrs1, off), qb = buf_f4(nrs1, off, 16), qc = buf_f4(nrs1, off, 32);
+                // rc_pack_leaf: qa = v0 (y, z | z, x), qb = e1 (z, x | y, z), qc = e2 (z, x | y, z).  The statements of :1766-1790 with each
+                // cross product's x and y as one packed multiply-multiply-subtract; every component is the same IEEE operation on the same
+                // operands as in the scalar form (no contraction), the dot products keep their (a.x b.x + a.y b.y) + a.z b.z order
+                const v2f A0 = {qa.x, qa.y}, A1 = {qa.z, qa.w}, B0 = {qb.x, qb.y}, B1 = {qb.z, qb.w}, C0 = {qc.x, qc.y}, C1 = {qc.z, qc.w};
+                const float e1x = B0.y, e1y = B1.x, e1z = B0.x, e2x = C0.y, e2y = C1.x, e2z = C0.x, dx = dzx.y, dy = dyz.x, dz = dyz.y;
+                const v2f s1xy = dyz * C0 - dzx * C1;          // s1 = d x e2
+                const float s1z = dx * e2y - dy * e2x;
+                const float det = (s1xy.x * e1x + s1xy.y * e1y) + s1z * e1z;
                 const float invd = 1.0f / det;
-                const float3_ dd = sub3(o, v0);
-                const float u = dot3(dd, s1) * invd;
-                const float3_ s2 = cross3(dd, e1);
-                const float v = dot3(d, s2) * invd;
-                const float t = dot3(e2, s2) * invd;
+                const v2f ddyz = oyz - A0, ddzx = ozx - A1;    // dd = o - v0
+                const float ddx = ddzx.y, ddy = ddyz.x, ddz = ddyz.y;
+                const float u = ((ddx * s1xy.x + ddy * s1xy.y) + ddz * s1z) * invd;
+                const v2f s2xy = ddyz * B0 - ddzx * B1;        // s2 = dd x e1
+                const float s2z = ddx * e1y - ddy * e1x;
+                const float v = ((dx * s2xy.x + dy * s2xy.y) + dz * s2z) * invd;
+                const float t = ((e2x * s2xy.x + e2y * s2xy.y) + e2z * s2z) * invd;
                 const bool hit = !(u < 0.0f || u > 1.0f) && !(v < 0.0f || (u + v) > 1.0f) && !(t < tmin || t > closest_t);
                 closest_prim = hit ? node - n_level + 1u : closest_prim;  // leaf of sorted primitive j sits at n-1+j
                 closest_inst = hit ? cur_inst : closest_inst;
@@ -647,10 +653,11 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 node = 1;
                 cur_off = m3.x;
                 n_level = m3.w;
-                o = mk3(m0.x * wo.x + m0.y * wo.y + m0.z * wo.z + m0.w, m1.x * wo.x + m1.y * wo.y + m1.z * wo.z + m1.w,
-                        m2.x * wo.x + m2.y * wo.y + m2.z * wo.z + m2.w);
-                d = mk3(m0.x * wd.x + m0.y * wd.y + m0.z * wd.z, m1.x * wd.x + m1.y * wd.y + m1.z * wd.z,
-                        m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
+                const float3_ o = mk3(m0.x * wo.x + m0.y * wo.y + m0.z * wo.z + m0.w, m1.x * wo.x + m1.y * wo.y + m1.z * wo.z + m1.w,
+                                      m2.x * wo.x + m2.y * wo.y + m2.z * wo.z + m2.w);
+                const float3_ d = mk3(m0.x * wd.x + m0.y * wd.y + m0.z * wd.z, m1.x * wd.x + m1.y * wd.y + m1.z * wd.z,
+                                      m2.x * wd.x + m2.y * wd.y + m2.z * wd.z);
+                oyz = v2f{o.y, o.z}; ozx = v2f{o.z, o.x}; dyz = v2f{d.y, d.z}; dzx = v2f{d.z, d.x};
                 inv = safe_inv3(d);
                 ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
                 RC_MARK("entry_end");

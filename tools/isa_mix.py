@@ -30,7 +30,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "raycore.jl_amd", "csrc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize"] + os.environ.get("RC_EXTRA_FLAGS", "").split() + [ "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "--cuda-device-only", "-S"]
 KERNEL = "k_trace_phased_ldsILb0ELi768ELi16ELi6ELb0ELb0EE"  # <closest, 768 threads, 16-entry LDS stacks, 6 waves / SIMD, no timeline, no stats>
 CLOCK_GHZ = 2.4

@@ -17,7 +17,7 @@ def to_dev(a):
     return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
 
 
-def time_trace(t, rays, mode, reps=5):
+def time_trace(t, rays, mode, reps=int(os.environ.get("RC_PROBE_REPS", "5"))):
     n = len(rays)
     d_rays = to_dev(rays)
     d_hits = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
