@@ -395,6 +395,32 @@ def test_trace_launches_are_hipgraph_capturable(rc, oracle):
         assert_hits_equal(dh.cpu().numpy().view(rc.HIT_DT), want, f"replay {rep} primary")
         assert np.array_equal(docc.cpu().numpy().view(rc.HIT_DT)["hit"], want_occ["hit"]), rep
     assert t.get_option("claim_drift") == 0
+    # a graph bakes its counter slots in.  Replays on one stream while more than a full rotation of eager launches (the eager
+    # slots: 48) runs on another must never meet on a slot: captured launches have slots of their own.
+    big = sc.c3_primary_rays(cfg, 1500, 1000)
+    want_big = o.trace(big, nthreads=16)
+    dbig = torch.from_numpy(big.view(np.uint8).reshape(-1)).cuda()
+    hbig = torch.empty(len(big) * 32, dtype=torch.uint8, device="cuda")
+    e = torch.cuda.Stream()
+    for rep in range(3):
+        dh.zero_(); docc.zero_(); hbig.zero_()
+        torch.cuda.synchronize()
+        for k in range(60):
+            t.trace_device(dbig.data_ptr(), hbig.data_ptr(), len(big), stream=e.cuda_stream)
+            if k % 6 == 0:
+                g.replay()
+        torch.cuda.synchronize()
+        assert_hits_equal(dh.cpu().numpy().view(rc.HIT_DT), want, f"replay beside eager launches {rep}")
+        assert np.array_equal(docc.cpu().numpy().view(rc.HIT_DT)["hit"], want_occ["hit"])
+        assert_hits_equal(hbig.cpu().numpy().view(rc.HIT_DT), want_big, f"eager launches beside replays {rep}")
+    assert t.get_option("claim_drift") == 0
+    # a capture on a stream the scene has never launched on is refused with an explanation (its stack spill area cannot be allocated then)
+    fresh = torch.cuda.Stream()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(rc.RaycoreError, match="eager launch on the capture stream"):
+        with torch.cuda.graph(g2, stream=fresh):
+            t.trace_device(dr.data_ptr(), dh.data_ptr(), n, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
     t.free()
 
 
