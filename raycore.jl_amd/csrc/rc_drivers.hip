@@ -452,6 +452,8 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
     SceneView v = rc_scene_view(s, blocks * bs);
     PersistArgs p = rc_persist_args(s, ray_end - ray_begin, blocks * bs);
     launch.start();
+    // a repeated get_illumination (same grid: item i is the same cell every time) claims the chunks that held long rays last time first
+    if (!launch.capturing && ray_begin == 0) rc_cost_order_setup(s, ray_end, 2, stream, p.claim);
     if (partial) {
         rc_partial_driver_args(s, p);
         if (!s->lds_attr_set[8]) {

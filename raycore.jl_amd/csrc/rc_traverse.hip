@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost,
 
 // The history entry of a launch shape (batch size, mode, chunk geometry, stream): launches on one stream are ordered, so its buffers have
 // one user at a time; another stream gets its own entry.  Returns false when cost ordering does not apply to this launch.
-static bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t stream, rc::RcClaim& c) {
+bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t stream, rc::RcClaim& c) {
     const uint64_t n_base64 = (n + c.pool - 1) / c.pool;  // chunks (the claim order permutes whole chunks; parts follow their chunk)
     // only where the order can matter: at least a claim per wave; the cost path maps rays to chunks with a shift (pool a power of two)
     if (!s->opt.cost_order || c.n_chunks < c.total_waves || n_base64 < 64u || n_base64 > (uint64_t)(kOrderTile * kOrderMaxBlocks) || (c.pool & (c.pool - 1u)) != 0u || c.pool < 16u) return false;

@@ -771,6 +771,9 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
 
 rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads);  // rc_traverse.hip
 rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads);
+// cost-ordered claiming for a launch inside an RcLaunchGuard: `kind` separates the histories of launches that map items to rays differently
+// (0 closest_hit, 1 any_hit, 2 the get_illumination grid)
+bool rc_cost_order_setup(rc_scene* s, uint64_t n_items, int kind, hipStream_t stream, rc::RcClaim& claim);
 bool rc_lds_driver_ok(rc_scene* s);
 bool rc_partial_driver_ok(rc_scene* s);
 void rc_partial_driver_args(rc_scene* s, rc::PersistArgs& p);
