@@ -666,7 +666,7 @@ static void trace_host_pipelined(rc_scene* s, CallCtx& cx, const rc_ray* rays, r
             if (abort_all.load()) break;
             uint64_t off, cnt; span(c, off, cnt);
             RC_HIP(hipEventRecord(ev_begin[c], cx.stream));
-            rc_launch_trace(s, cx.rays.p + off, cx.hits.p + off, cnt, any, cx.stream);
+            rc_launch_trace(s, cx.rays.p + off, cx.hits.p + off, cnt, any, cx.stream, false);
             RC_HIP(hipEventRecord(ev_end[c], cx.stream));
             launched.store(c + 1, std::memory_order_release);
         }

@@ -247,7 +247,9 @@ void rc_refit_tlas(rc_scene* s, bool from_device = false, bool recompute_inverse
 void rc_mat3x4_inverse(const float m[12], float out[12]);
 
 // rc_traverse.hip
-void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream);
+// learn_order = false: this launch is one piece of a larger batch (the chunked host-buffer path): the next launch of the same size traces OTHER rays,
+// so what this one learns about its chunks predicts nothing
+void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream, bool learn_order = true);
 
 // rc_bvh4.hip
 void rc_build_blas4(rc_scene* s, Blas& b);                            // build_blas4: collapse of b's BVH2 (src/bvh4.jl:511-522)

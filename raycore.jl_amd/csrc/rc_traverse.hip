@@ -723,7 +723,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
     return true;
 }
 
-void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream) {
+void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n, int any_hit, hipStream_t stream, bool learn_order) {
     if (n == 0) return;
     RcLaunchGuard launch(s, stream);  // serialises the enqueue: trace calls on one scene may come from several host threads
     uint64_t want = (n + kBlock - 1) / kBlock, cap = (uint64_t)s->n_cus * rc_blocks_per_cu(s);
@@ -757,7 +757,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
         a.tlas_k = s->tlas_top_k; a.blas_k = s->opt.blas_top ? s->blas_top_k : 0; a.lds_blas_base = s->tlas_top_k;
     }
     launch.start();
-    if ((kernel == 3 || kernel == 5 || kernel == 6) && !launch.capturing) rc_cost_order_setup(s, n, any_hit, stream, a.claim);  // (inside the timed region: the order kernel is part of the launch's cost)
+    if (learn_order && (kernel == 3 || kernel == 5 || kernel == 6) && !launch.capturing) rc_cost_order_setup(s, n, any_hit, stream, a.claim);  // (inside the timed region: the order kernel is part of the launch's cost)
     if (any_hit) launch_variant<true>(s, kernel, a, blocks, stream); else launch_variant<false>(s, kernel, a, blocks, stream);
     launch.finish();
 }
