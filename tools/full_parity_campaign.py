@@ -8,7 +8,7 @@ import raycore_jl_amd as rc
 from oracle import pyoracle as po
 from helpers import build_oracle, build_product, assert_hits_equal
 sc = rc.scenes
-nt = os.cpu_count()
+nt = 16  # the GPU box grants 16 CPUs of time (cgroup quota), whatever it shows
 cfg3 = sc.config_c3()
 t3, o3 = build_product(rc, cfg3), build_oracle(po, cfg3)
 rays = sc.c3_primary_rays(cfg3, 2048, 2048)
