@@ -178,12 +178,17 @@ int rc_trace_any_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, u
 /* Kernel selection for the trace entry points (tuning / A-B measurement).  The default is the tuned
  * kernel; every variant returns identical results.  Names: "kernel" (-1 auto, 0..6),
  * "blocks_per_cu", "lds_stack", "refill", "sched_thr", "pool", "claim_shards" (scheduling knobs of the
- * persistent kernels), "blas_top" (1 = a scene with a single BLAS keeps that BLAS's top internal
+ * persistent kernels), "taper" (guided claim sizes: towards the end of the claim order a 128-ray chunk is dealt in halves, quarters,
+ * eighths; in eighths of (part size x waves) still to hand out per piece, default 12, 0 = whole chunks only), "cost_order" (1 = the
+ * chunks that held long-lived rays in the previous launch of the same batch size, mode and stream are claimed first; default 1),
+ * "cost_thr" (its initial reporting threshold), "vf_chunk_bytes" (device block per row chunk of the host-matrix view factors),
+ * "blas_top" (1 = a scene with a single BLAS keeps that BLAS's top internal
  * nodes in LDS; takes effect at the next structural rc_sync), "onesweep_min" (key count from which
  * the builds sort with Onesweep radix passes instead of a merge sort), "stats" (dev counters),
  * "timeline_ptr" (dev: device address of 8 x u64 per wave that kernel 5 fills with its waves' event
  * times, tools/timeline_probe.py; 0 = off).
- * Read-only: "n_cus", "blas_top_k", "tlas_top_k", "stat0".."statf". */
+ * None of them changes a result: every variant and every claim order returns identical hits.
+ * Read-only: "n_cus", "blas_top_k", "tlas_top_k", "claim_drift", "stat0".."statf", "stat16".."stat23". */
 int rc_set_option(rc_scene* scene, const char* name, int64_t value);
 int rc_get_option(rc_scene* scene, const char* name, int64_t* value);
 
