@@ -247,6 +247,15 @@ int rc_view_factors_rows_host(rc_scene* scene, uint32_t rays_per_triangle, uint6
 #define RC_VF_MODE_ROWS 0
 #define RC_VF_MODE_RAYS 1
 int rc_view_factors_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix, int mode);
+/* closest_hit / any_hit over one HOST batch on several devices of one process (rays are independent -- replicas of the
+ * scene, contiguous ray shards, no collective): scenes[g] is a synced copy of the same scene on device g; shard g is uploaded, traced
+ * and downloaded by device g over its own PCIe link, which is what bounds a host-to-host batch (64 bytes per ray).  hits[i] is what
+ * rc_trace_closest / rc_trace_any on any one of the scenes gives for rays[i]. */
+int rc_trace_closest_multi(rc_scene* const* scenes, int n_scenes, const rc_ray* rays, rc_hit* hits, uint64_t n);
+int rc_trace_any_multi(rc_scene* const* scenes, int n_scenes, const rc_ray* rays, rc_hit* hits, uint64_t n);
+/* get_illumination on several devices: device g traces its share of the grid's rays into its own histogram; the n_prims-long partial
+ * histograms are added on the host (a count stops at 2^24 like the reference's f32 `+= 1`).  Same result as rc_get_illumination. */
+int rc_get_illumination_multi(rc_scene* const* scenes, int n_scenes, const float viewdir[3], uint32_t grid, float* out_counts);
 /* The rays view_factors shoots for one source primitive (ray indices [ray_begin, ray_begin + n_rays)),
  * written to a device buffer: the body of the reference's inner loop up to the Ray constructor
  * (src/kernels.jl:89-92), exposed so ray generation can be checked on its own. */

@@ -716,6 +716,35 @@ def view_factors_multi(accels, rays_per_triangle=10000, seed=0, mode="rows", out
     return out
 
 
+def trace_multi(accels, rays, mode="closest", out=None):
+    """One host batch of rays on several devices of ONE process (rc_trace_closest_multi / rc_trace_any_multi): `accels` are synced accels
+    holding the same scene, one per device; accel g uploads, traces and downloads the g-th contiguous shard of the batch over its own
+    PCIe link (rays are independent -- replicas, no collective).  hits[i] is what any one accel's trace gives for rays[i]."""
+    owners = [_owner(a) for a in accels]
+    rays = _as_rays(rays)
+    if out is None:
+        hits = np.empty(len(rays), dtype=HIT_DT)
+    else:
+        if out.dtype != HIT_DT or len(out) != len(rays) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a contiguous HIT_DT array with one record per ray")
+        hits = out
+    handles = (C.c_void_p * len(owners))(*[o._h for o in owners])
+    fn = lib().rc_trace_closest_multi if mode == "closest" else lib().rc_trace_any_multi
+    check(fn(handles, len(owners), ptr(rays), ptr(hits), len(rays)))
+    return hits
+
+
+def get_illumination_multi(accels, viewdir, grid_size=1000):
+    """get_illumination with the ray grid cut into one share per device (rc_get_illumination_multi); the partial histograms are added
+    on the host.  Same counts as get_illumination."""
+    owners = [_owner(a) for a in accels]
+    out = np.zeros(owners[0].n_primitives(), dtype=np.float32)
+    vd = np.ascontiguousarray(viewdir, dtype=np.float32)
+    handles = (C.c_void_p * len(owners))(*[o._h for o in owners])
+    check(lib().rc_get_illumination_multi(handles, len(owners), ptr(vd), int(grid_size), ptr(out)))
+    return out
+
+
 def expand_faceviews(positions, position_faces, **attributes):
     """GeometryBasics.expand_faceviews as build_and_append_blas! uses it (src/instanced-bvh.jl:581-590): a mesh whose attributes are
     indexed by their own face arrays (a cube: 8 positions, 6 normals, one metadata value per face) becomes a mesh with ONE index set,

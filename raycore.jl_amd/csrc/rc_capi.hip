@@ -693,24 +693,27 @@ static void trace_host_pipelined(rc_scene* s, CallCtx& cx, const rc_ray* rays, r
     if (overflow) throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels)");
 }
 
+// One device's share of a host-buffer batch (throws; the C-ABI wrappers and rc_multi.hip's per-device threads catch).
+extern "C++" void rc_trace_host_impl(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
+    use_device(s);
+    require_synced(s);
+    if (n == 0) return;
+    if (!rays || !hits) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
+    CtxLease lease(s);  // this call's own stream and staging buffers: host-buffer trace calls are re-entrant on a synced scene
+    CallCtx& cx = *lease.c;
+    if (n >= 3 * (1ull << 20) && s->opt.host_pipeline) { trace_host_pipelined(s, cx, rays, hits, n, any); return; }
+    cx.rays.reserve(n);
+    cx.hits.reserve(n);
+    if (n >= (1ull << 16)) populate_pages(hits, sizeof(RcHit) * n);
+    RC_HIP(hipMemcpyAsync(cx.rays.p, rays, sizeof(RcRay) * n, hipMemcpyHostToDevice, cx.stream));
+    rc_launch_trace(s, cx.rays.p, cx.hits.p, n, any, cx.stream);
+    RC_HIP(hipMemcpyAsync(hits, cx.hits.p, sizeof(RcHit) * n, hipMemcpyDeviceToHost, cx.stream));
+    check_status(s, cx.stream);
+}
+
 static int trace_host(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
     if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
-    return guarded([&] {
-        use_device(s);
-        require_synced(s);
-        if (n == 0) return;
-        if (!rays || !hits) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
-        CtxLease lease(s);  // this call's own stream and staging buffers: host-buffer trace calls are re-entrant on a synced scene
-        CallCtx& cx = *lease.c;
-        if (n >= 3 * (1ull << 20) && s->opt.host_pipeline) { trace_host_pipelined(s, cx, rays, hits, n, any); return; }
-        cx.rays.reserve(n);
-        cx.hits.reserve(n);
-        if (n >= (1ull << 16)) populate_pages(hits, sizeof(RcHit) * n);
-        RC_HIP(hipMemcpyAsync(cx.rays.p, rays, sizeof(RcRay) * n, hipMemcpyHostToDevice, cx.stream));
-        rc_launch_trace(s, cx.rays.p, cx.hits.p, n, any, cx.stream);
-        RC_HIP(hipMemcpyAsync(hits, cx.hits.p, sizeof(RcHit) * n, hipMemcpyDeviceToHost, cx.stream));
-        check_status(s, cx.stream);
-    });
+    return guarded([&] { rc_trace_host_impl(s, rays, hits, n, any); });
 }
 int rc_trace_closest(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace_host(s, rays, hits, n, 0); }
 int rc_trace_any(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace_host(s, rays, hits, n, 1); }
@@ -1164,16 +1167,43 @@ int rc_view_factors_rows_host(rc_scene* s, uint32_t rays_per_triangle, uint64_t 
     });
 }
 
+// The scene list of a multi-device call: no NULL, no scene twice.
+static void check_scene_list(rc_scene* const* scenes, int n_scenes, const char* who) {
+    for (int g = 0; g < n_scenes; ++g) {
+        if (!scenes[g]) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+        for (int h = 0; h < g; ++h) if (scenes[h] == scenes[g]) throw RcError(RC_ERR_INVALID_ARGUMENT, std::string(who) + ": the same scene twice");
+    }
+}
+
 int rc_view_factors_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix, int mode) {
     if (!scenes || n_scenes < 1 || !out_matrix) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {
-        std::vector<std::unique_lock<std::mutex>> locks;  // one job at a time per scene (the scenes' auxiliary streams and blocks are the job's); in argument order
-        for (int g = 0; g < n_scenes; ++g) {
-            if (!scenes[g]) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
-            for (int h = 0; h < g; ++h) if (scenes[h] == scenes[g]) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_view_factors_multi: the same scene twice");
-            locks.emplace_back(scenes[g]->host_call_mu);
-        }
+        check_scene_list(scenes, n_scenes, "rc_view_factors_multi");
+        // one job at a time per scene (the scenes' auxiliary streams and blocks are the job's); locked in address order, so that two
+        // callers naming the same scenes in different orders cannot wait for each other
+        std::vector<rc_scene*> by_address(scenes, scenes + n_scenes);
+        std::sort(by_address.begin(), by_address.end());
+        std::vector<std::unique_lock<std::mutex>> locks;
+        for (rc_scene* s : by_address) locks.emplace_back(s->host_call_mu);
         rc_view_factors_multi_impl(scenes, n_scenes, rays_per_triangle, seed, out_matrix, mode);
+    });
+}
+
+static int trace_host_multi(rc_scene* const* scenes, int n_scenes, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
+    if (!scenes || n_scenes < 1) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        check_scene_list(scenes, n_scenes, "rc_trace_*_multi");
+        rc_trace_multi_impl(scenes, n_scenes, rays, hits, n, any);
+    });
+}
+int rc_trace_closest_multi(rc_scene* const* scenes, int n_scenes, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace_host_multi(scenes, n_scenes, rays, hits, n, 0); }
+int rc_trace_any_multi(rc_scene* const* scenes, int n_scenes, const rc_ray* rays, rc_hit* hits, uint64_t n) { return trace_host_multi(scenes, n_scenes, rays, hits, n, 1); }
+
+int rc_get_illumination_multi(rc_scene* const* scenes, int n_scenes, const float viewdir[3], uint32_t grid, float* out_counts) {
+    if (!scenes || n_scenes < 1 || !viewdir || !out_counts) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        check_scene_list(scenes, n_scenes, "rc_get_illumination_multi");
+        rc_illumination_multi_impl(scenes, n_scenes, viewdir, grid, out_counts);
     });
 }
 

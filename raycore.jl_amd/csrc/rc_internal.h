@@ -315,6 +315,11 @@ void rc_vf_source_range(rc_scene* s, uint32_t row_begin, uint32_t row_end, uint3
 // rc_multi.hip
 float rc_view_factors_rows_to_host(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t row_begin, uint32_t row_end, uint32_t* out, uint64_t ld);
 void rc_view_factors_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out, int mode);
+struct rc_ray;  // include/raycore_mi355x.h (same 32 bytes as RcRay / RcHit)
+struct rc_hit;
+void rc_trace_multi_impl(rc_scene* const* scenes, int n_scenes, const rc_ray* rays, rc_hit* hits, uint64_t n, int any);
+void rc_illumination_multi_impl(rc_scene* const* scenes, int n_scenes, const float viewdir[3], uint32_t grid, float* out);
+void rc_trace_host_impl(rc_scene* s, const rc_ray* rays, rc_hit* hits, uint64_t n, int any);  // rc_capi.hip: one scene's host-buffer batch (throws)
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream);
 void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float* d_points, float* d_normals, hipStream_t stream);
 void rc_launch_shadow_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, const float light[3], float bias, RcRay* d_out, hipStream_t stream);

@@ -201,30 +201,38 @@ void check_same_geometry(rc_scene* const* scenes, int n) {
         if (!s->has_static || s->dirty || s->transforms_dirty) throw RcError(RC_ERR_NOT_SYNCED, "scene has pending mutations: call rc_sync first");
         if (s->n_flat_prims != scenes[0]->n_flat_prims || s->n_flat_nodes != scenes[0]->n_flat_nodes || s->n_static_instances != scenes[0]->n_static_instances ||
             memcmp(s->root_min, scenes[0]->root_min, 12) != 0 || memcmp(s->root_max, scenes[0]->root_max, 12) != 0)
-            throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_view_factors_multi: the scenes must hold the same geometry (one copy per device)");
+            throw RcError(RC_ERR_INVALID_ARGUMENT, "the scenes of a multi-device call must hold the same geometry (one copy per device)");
     }
 }
 }  // namespace
 
-// ROWS: device g owns matrix rows [g N / G, (g + 1) N / G) and brings them home over its own PCIe link; one host thread per device.
-static void multi_rows(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out) {
-    const uint32_t n = scenes[0]->n_flat_prims;
+// One host thread per scene (= per device: every thread drives its own device's streams and PCIe link); the first failure is rethrown
+// on the calling thread once every thread is back.
+template <typename F>
+static void for_each_scene(rc_scene* const* scenes, int n_scenes, F&& body) {
     std::vector<std::thread> th;
     std::vector<std::string> err(n_scenes);
     std::vector<int> code(n_scenes, 0);
-    std::vector<float> ms(n_scenes, 0.f);
-    for (int g = 0; g < n_scenes; ++g) {
-        const uint32_t r0 = (uint32_t)((uint64_t)n * g / n_scenes), r1 = (uint32_t)((uint64_t)n * (g + 1) / n_scenes);
-        th.emplace_back([=, &err, &code, &ms] {
+    for (int g = 0; g < n_scenes; ++g)
+        th.emplace_back([&, g] {
             try {
-                ms[g] = rc_view_factors_rows_to_host(scenes[g], rays_per_triangle, seed, r0, r1, out, n);
+                body(g);
             } catch (const RcError& e) { err[g] = e.what(); code[g] = e.code; }
             catch (const std::exception& e) { err[g] = e.what(); code[g] = RC_ERR_INVALID_ARGUMENT; }
         });
-    }
     for (auto& t : th) t.join();
     for (int g = 0; g < n_scenes; ++g)
         if (code[g]) throw RcError(code[g], "device " + std::to_string(scenes[g]->device) + ": " + err[g]);
+}
+
+// ROWS: device g owns matrix rows [g N / G, (g + 1) N / G) and brings them home over its own PCIe link; one host thread per device.
+static void multi_rows(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out) {
+    const uint32_t n = scenes[0]->n_flat_prims;
+    std::vector<float> ms(n_scenes, 0.f);
+    for_each_scene(scenes, n_scenes, [&](int g) {
+        const uint32_t r0 = (uint32_t)((uint64_t)n * g / n_scenes), r1 = (uint32_t)((uint64_t)n * (g + 1) / n_scenes);
+        ms[g] = rc_view_factors_rows_to_host(scenes[g], rays_per_triangle, seed, r0, r1, out, n);
+    });
     for (int g = n_scenes - 1; g >= 0; --g) rc_timing_fixed(scenes[g], ms[g]);  // on the CALLING thread (rc_last_kernel_ms is per thread); scenes[0] last
 }
 
@@ -339,4 +347,61 @@ void rc_view_factors_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t 
     populate_parallel(out, n * n * 4u);
     if (mode == RC_VF_MODE_ROWS) multi_rows(scenes, n_scenes, rays_per_triangle, seed, out);
     else multi_rays(scenes, n_scenes, rays_per_triangle, seed, out);
+}
+
+// closest_hit / any_hit over one host batch on several devices (rays are independent units -- replicas of the scene, the
+// ray array cut into contiguous shards, no collective).  Device g uploads, traces and downloads shard g over its own PCIe link with
+// the same three-stage pipeline a single-device call uses (rc_capi.hip), so a host-to-host batch -- bound by the link at 64 bytes per
+// ray, not by the kernel -- runs G times as fast.  Shard boundaries are multiples of 64 rays; the hits are the single-device hits.
+void rc_trace_multi_impl(rc_scene* const* scenes, int n_scenes, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
+    if (n_scenes < 1 || !scenes) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_trace_*_multi: no scenes");
+    check_same_geometry(scenes, n_scenes);
+    if (n == 0) return;
+    if (!rays || !hits) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits is NULL");
+    struct DeviceRestore { int dev = 0; DeviceRestore() { (void)hipGetDevice(&dev); } ~DeviceRestore() { (void)hipSetDevice(dev); } } restore;
+    if (n_scenes == 1) { rc_trace_host_impl(scenes[0], rays, hits, n, any); return; }
+    const uint64_t per = (((n + n_scenes - 1) / n_scenes) + 63) & ~63ull;
+    std::vector<float> ms(n_scenes, 0.f);
+    for_each_scene(scenes, n_scenes, [&](int g) {
+        const uint64_t b = std::min<uint64_t>(n, per * g), e = std::min<uint64_t>(n, per * (g + 1));
+        if (e <= b) return;
+        rc_trace_host_impl(scenes[g], rays + b, hits + b, e - b, any);
+        ms[g] = rc_timing_read(scenes[g]);  // this thread's launch(es) on this scene
+    });
+    for (int g = n_scenes - 1; g >= 0; --g) rc_timing_fixed(scenes[g], ms[g]);
+}
+
+// get_illumination on several devices: device g traces rays [g M / G, (g + 1) M / G) of the grid's M = grid^2 rays into
+// its own histogram; the N-length partial histograms are summed on the host (N x 4 bytes per device -- nothing worth a collective).
+// A count is a number of rays: the partial counts are integers in f32, exact up to 2^24, where the reference's `+= 1f0`
+// (src/kernels.jl:119-121) and the device's f32 atomic add both stop growing -- the sum is clamped there to stay identical.
+void rc_illumination_multi_impl(rc_scene* const* scenes, int n_scenes, const float viewdir[3], uint32_t grid, float* out) {
+    if (n_scenes < 1 || !scenes) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_get_illumination_multi: no scenes");
+    check_same_geometry(scenes, n_scenes);
+    const uint32_t np = scenes[0]->n_flat_prims;
+    if (np == 0) return;
+    struct DeviceRestore { int dev = 0; DeviceRestore() { (void)hipGetDevice(&dev); } ~DeviceRestore() { (void)hipSetDevice(dev); } } restore;
+    const uint64_t m = (uint64_t)grid * grid;
+    std::vector<std::vector<float>> part(n_scenes);
+    std::vector<float> ms(n_scenes, 0.f);
+    for_each_scene(scenes, n_scenes, [&](int g) {
+        rc_scene* s = scenes[g];
+        const uint64_t b = m * g / n_scenes, e = m * (g + 1) / n_scenes;
+        RC_HIP(hipSetDevice(s->device));
+        std::lock_guard<std::mutex> one_at_a_time(s->host_call_mu);  // the scene's f32 staging buffer
+        part[g].assign(np, 0.f);
+        s->f32_stage.reserve(np);
+        RC_HIP(hipMemsetAsync(s->f32_stage.p, 0, sizeof(float) * np, s->stream));
+        if (e > b) rc_launch_illumination(s, viewdir, grid, b, e, s->f32_stage.p, s->stream);
+        RC_HIP(hipMemcpyAsync(part[g].data(), s->f32_stage.p, sizeof(float) * np, hipMemcpyDeviceToHost, s->stream));
+        RC_HIP(hipStreamSynchronize(s->stream));
+        status_check(s);
+        ms[g] = rc_timing_read(s);
+    });
+    for (uint32_t i = 0; i < np; ++i) {
+        double sum = 0.0;
+        for (int g = 0; g < n_scenes; ++g) sum += part[g][i];
+        out[i] = (float)std::min(sum, 16777216.0);
+    }
+    for (int g = n_scenes - 1; g >= 0; --g) rc_timing_fixed(scenes[g], ms[g]);
 }

@@ -178,6 +178,18 @@ function trace(a::MI355XStaticTLAS, rays::Vector{RTRay}; any::Bool = false)
     return hits
 end
 
+"One host batch on several devices (SURVEY.md 8e: replicas of the scene, contiguous ray shards, no collective): `accels[g]` is the adapted
+accel of the same scene on device g; shard g travels over device g's own PCIe link."
+function trace(accels::Vector{MI355XStaticTLAS}, rays::Vector{RTRay}; any::Bool = false)
+    hits = Vector{RTHitResult}(undef, length(rays))
+    ptrs = Ptr{Cvoid}[a.owner.ptr for a in accels]
+    f = any ? :rc_trace_any_multi : :rc_trace_closest_multi
+    GC.@preserve accels check(ccall((f, LIB), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{RTRay}, Ptr{RTHitResult}, UInt64), ptrs, length(ptrs), rays, hits, length(rays)))
+    return hits
+end
+Raycore.trace_rays(accels::Vector{MI355XStaticTLAS}, rays::AbstractVector{<:Raycore.AbstractRay}) =
+    map(h -> result_tuple(accels[1], h, empty_triangle(Triangle{UInt32})), trace(accels, map(to_rtray, rays)))
+
 function primitives(a::MI355XStaticTLAS)            # all_blas_prims as Triangle{UInt32} values: the library's 136-byte records ARE that struct
     t = a.owner
     if !t.prims_valid
@@ -208,6 +220,13 @@ function Raycore.get_illumination(a::MI355XStaticTLAS, viewdir; grid_size = 1000
     out = Vector{Float32}(undef, counts(a.owner)[4])
     check(ccall((:rc_get_illumination, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, UInt32, Ptr{Float32}),
                 a.owner.ptr, Float32[viewdir...], grid_size, out))
+    return out
+end
+function Raycore.get_illumination(accels::Vector{MI355XStaticTLAS}, viewdir; grid_size = 1000)   # the ray grid in one share per device
+    out = Vector{Float32}(undef, counts(accels[1].owner)[4])
+    ptrs = Ptr{Cvoid}[a.owner.ptr for a in accels]
+    GC.@preserve accels check(ccall((:rc_get_illumination_multi, LIB), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{Float32}, UInt32, Ptr{Float32}),
+                                    ptrs, length(ptrs), Float32[viewdir...], grid_size, out))
     return out
 end
 function Raycore.view_factors(a::MI355XStaticTLAS; rays_per_triangle = 10000, seed::UInt64 = rand(UInt64))
