@@ -108,7 +108,7 @@ def test_each_thread_reads_its_own_launch_time(rc, scene):
     import torch
     t, o, wb = scene
     small = random_rays(rc, 4_096, 7, wb.p_min, wb.p_max)
-    big = random_rays(rc, 2_000_000, 8, wb.p_min, wb.p_max)
+    big = random_rays(rc, 4_000_000, 8, wb.p_min, wb.p_max)
     d_big = torch.from_numpy(big.view(np.uint8).reshape(-1)).cuda()
     d_out = torch.empty(len(big) * 32, dtype=torch.uint8, device="cuda")
     t.trace(small)
@@ -124,5 +124,5 @@ def test_each_thread_reads_its_own_launch_time(rc, scene):
     th = threading.Thread(target=other)
     th.start()
     th.join()
-    assert result["big"] > 3 * ms_small
+    assert result["big"] > 1.5 * ms_small   # ~0.9 ms against ~0.1 ms; the margin only has to tell the two launches apart
     assert abs(t.last_kernel_ms() - ms_small) < 1e-6  # this thread's own launch, still
