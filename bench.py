@@ -100,6 +100,13 @@ def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_
                                        "note": "the issue rate this kernel's dynamic opcode mix could reach on 1024 SIMDs at the cycles measured per opcode (v_pk_*_f32 4.9, "
                                                "v_minimum3 / v_maximum3 4.5, compares 4.9, moves 3.8 ...); none of them issues in the guide's 2 cycles",
                                        "source": MIX_FILE + " (tools/isa_mix.py: per-phase opcode histogram of the kernel's ISA x the STATS kernel's pass counts x profiles/r02_valu_probe.txt)"}
+            rep = m.get("repriced_with_pinned_register_probe")
+            if rep:  # the same histogram priced with the second probe's two tables: how far the per-opcode costs themselves are uncertain
+                lo, hi = rep["varied_operands"]["mix_ceiling_G_wave_instructions_s"], rep["static_operands"]["mix_ceiling_G_wave_instructions_s"]
+                roofline["mix_ceiling"]["range_G_wave_instructions_s"] = [lo, hi]
+                roofline["mix_ceiling"]["achieved_over_mix_ceiling_range"] = [round(achieved / hi, 4), round(achieved / lo, 4)]
+                roofline["mix_ceiling"]["range_note"] = ("per-opcode issue costs depend on the operands' bit activity and on the encoding (full-rate VOP2 opcodes: 2.5-2.8 cycles on "
+                                                         "static operands, 3.8-4.2 on lane-varying ones); the range prices the histogram with both tables of profiles/r03_valu_probe3.txt")
     else:  # no usable counter file for this configuration: only the section-8d figure can be given, and it is not a utilisation
         roofline = {"bound": "valu-issue", "achieved": None, "peak": round(VALU_PEAK_GINST_S, 1), "unit": "G wave-instructions/s", "frac": None, "traffic": traffic,
                     "kernel": kname, "avg_launch_ms": round(launch_ms, 4),

@@ -126,6 +126,41 @@ def cycles_of(op, probe):
     return None
 
 
+def probe3_tables():
+    """{opcode form: (cycles on static operands, cycles on lane-varying operands)} from profiles/r03_valu_probe3.txt (tools/gen_valu_probe.py:
+    physical registers pinned, destination separate from the sources, 6 waves / SIMD)."""
+    table = {}
+    path = os.path.join(ROOT, "profiles", "r03_valu_probe3.txt")
+    if not os.path.exists(path):
+        return table
+    for l in open(path):
+        m = re.match(r"(\S+(?: \S+)?)\s+static ([\d.]+) ns = [\d.]+ cycles\s+varied ([\d.]+) ns", l)
+        if m:
+            table[m.group(1)] = (float(m.group(2)) * CLOCK_GHZ, float(m.group(3)) * CLOCK_GHZ)
+    return table
+
+
+def cycles3(op, table, which):
+    """Price `op` with the pinned-register probe; `which` 0 = static operands, 1 = varied.  Opcodes the probe does not list are priced as
+    the quarter-rate class they almost all belong to (every 3-source, 64-bit, shift-left, compare, select and min / max form measured
+    4.5-4.7 cycles)."""
+    if op in table:
+        return table[op][which]
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    e64 = op.endswith("_e64")
+    for cand in (base, base + "_e32", base + "_e64"):
+        if cand in table and not (e64 and cand.endswith("_e32") and base + "_e64" in table):
+            return table[cand][which]
+    if base.startswith("v_cmp"):
+        key = ("v_cmp_f32" if "_f32" in base else "v_cmp_u32") + ("_e64" if e64 else "_e32")
+        return table[key][which]
+    if base in ("v_subrev_f32",):
+        return table["v_sub_f32" + ("_e64" if e64 else "_e32")][which]
+    if base in ("v_subrev_u32", "v_or_b32", "v_xor_b32"):
+        return table["v_and_b32" + ("_e64" if e64 else "_e32")][which]
+    return table["v_lshl_add_u32"][which]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c3")
@@ -183,6 +218,18 @@ def main():
                       "mix_ceiling_frac_of_peak": round(2.0 / avg, 4),
                       "peak_G_wave_instructions_s": 1024 * CLOCK_GHZ / 2.0,
                       "cycles_source": "profiles/r02_valu_probe.txt (tools/valu_probe.hip: ns per wave-instruction per SIMD at 6 waves / SIMD) x 2.4 GHz"}
+        t3 = probe3_tables()
+        if t3:
+            rep = {}
+            for which, name in ((0, "static_operands"), (1, "varied_operands")):
+                a3 = sum(c * cycles3(op, t3, which) for op, c in dyn.items()) / total
+                rep[name] = {"average_cycles_per_valu_instruction": round(a3, 4), "mix_ceiling_G_wave_instructions_s": round(1024 * CLOCK_GHZ / a3, 1),
+                             "mix_ceiling_frac_of_peak": round(2.0 / a3, 4)}
+            rep["source"] = ("profiles/r03_valu_probe3.txt (tools/gen_valu_probe.py -> tools/valu_probe3.hip): the same histogram priced with a probe that pins "
+                             "physical registers and separates the destination from the sources, once on operands that never change and once on "
+                             "lane-varying ones; the full-rate opcodes (v_mul / v_add / v_sub_f32, v_add_u32, v_and_b32 ...) cost 2.5-2.8 cycles in the "
+                             "first setting and 3.8-4.2 in the second in their VOP2 encoding, the quarter-rate ones 4.5-4.7 in both")
+            out["mix"]["repriced_with_pinned_register_probe"] = rep
         if os.path.exists(args.counters) and args.workload == "c3":
             measured = json.load(open(args.counters))["counters_mean_per_launch"].get("SQ_INSTS_VALU")
             if measured:

@@ -1,0 +1,136 @@
+// Dev microbenchmark, follow-up to valu_probe.hip: the first probe found v_mul_f32 / v_add_f32 / v_and_b32 / v_add_u32 at ~2.8 cycles per
+// wave64 instruction in their VOP3 (_e64) encoding when the destination is also the first source, and at ~4.0 cycles in VOP2 (_e32) or
+// with a separate destination.  This probe pins PHYSICAL registers (so the VGPR banks, = register number mod 4, are known) and varies
+// encoding, destination overlap and source banks one at a time, 8 independent chains per wave, 6 waves per SIMD.
+// build: hipcc --offload-arch=gfx950 -O3 tools/valu_probe2.hip -o tools/valu_probe2
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+#define CLOBBERS "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", \
+                 "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
+
+// 8 instructions, chain k uses registers base+k
+#define I8(op, d, a, b) \
+    op " v" #d "0, v" #a "0, v" #b "0\n" op " v" #d "1, v" #a "1, v" #b "1\n" op " v" #d "2, v" #a "2, v" #b "2\n" op " v" #d "3, v" #a "3, v" #b "3\n" \
+    op " v" #d "4, v" #a "4, v" #b "4\n" op " v" #d "5, v" #a "5, v" #b "5\n" op " v" #d "6, v" #a "6, v" #b "6\n" op " v" #d "7, v" #a "7, v" #b "7\n"
+#define I8C(op, d, a, b, c) \
+    op " v" #d "0, v" #a "0, v" #b "0, v" #c "0\n" op " v" #d "1, v" #a "1, v" #b "1, v" #c "1\n" op " v" #d "2, v" #a "2, v" #b "2, v" #c "2\n" \
+    op " v" #d "3, v" #a "3, v" #b "3, v" #c "3\n" op " v" #d "4, v" #a "4, v" #b "4, v" #c "4\n" op " v" #d "5, v" #a "5, v" #b "5, v" #c "5\n" \
+    op " v" #d "6, v" #a "6, v" #b "6, v" #c "6\n" op " v" #d "7, v" #a "7, v" #b "7, v" #c "7\n"
+// register groups: v4x = v40..v47 (bank = k mod 4), v5x = v50..v57 (bank = (k + 2) mod 4), v6x = v60..v67 (bank = k mod 4), v7x = v70..v77 (bank (k+2) mod 4)
+// "same bank" pairs: (4x, 6x); "different bank" pairs: (4x, 5x)
+
+template <int V>
+__global__ __launch_bounds__(256, 6) void k_probe(float* out, int iters, float seed, int varied) {
+    asm volatile(
+        "v_mov_b32 v40, %0\n v_mov_b32 v41, %0\n v_mov_b32 v42, %0\n v_mov_b32 v43, %0\n v_mov_b32 v44, %0\n v_mov_b32 v45, %0\n v_mov_b32 v46, %0\n v_mov_b32 v47, %0\n"
+        "v_mov_b32 v50, %0\n v_mov_b32 v51, %0\n v_mov_b32 v52, %0\n v_mov_b32 v53, %0\n v_mov_b32 v54, %0\n v_mov_b32 v55, %0\n v_mov_b32 v56, %0\n v_mov_b32 v57, %0\n"
+        "v_mov_b32 v60, %0\n v_mov_b32 v61, %0\n v_mov_b32 v62, %0\n v_mov_b32 v63, %0\n v_mov_b32 v64, %0\n v_mov_b32 v65, %0\n v_mov_b32 v66, %0\n v_mov_b32 v67, %0\n"
+        "v_mov_b32 v70, %0\n v_mov_b32 v71, %0\n v_mov_b32 v72, %0\n v_mov_b32 v73, %0\n v_mov_b32 v74, %0\n v_mov_b32 v75, %0\n v_mov_b32 v76, %0\n v_mov_b32 v77, %0\n"
+        : : "v"(seed) : CLOBBERS);
+    if (varied) {  // operands with busy mantissas that differ per lane and per chain (the first fill is 1.0 everywhere): does the data matter?
+        const float a = 1.0f + (float)(threadIdx.x * 37 % 251) * 0x1p-9f, b = 1.0f + (float)(threadIdx.x % 7 + 1) * 0x1p-23f;
+        asm volatile(
+            "v_mov_b32 v40, %0\n v_add_f32 v41, %0, %1\n v_mul_f32 v42, %0, %1\n v_mov_b32 v43, %0\n v_add_f32 v44, v41, %1\n v_mov_b32 v45, v42\n v_mov_b32 v46, v44\n v_mul_f32 v47, v44, %1\n"
+            "v_mov_b32 v50, %1\n v_mov_b32 v51, %1\n v_mov_b32 v52, %1\n v_mov_b32 v53, %1\n v_mov_b32 v54, %1\n v_mov_b32 v55, %1\n v_mov_b32 v56, %1\n v_mov_b32 v57, %1\n"
+            "v_mov_b32 v60, %1\n v_mov_b32 v61, %1\n v_mov_b32 v62, %1\n v_mov_b32 v63, %1\n v_mov_b32 v64, %1\n v_mov_b32 v65, %1\n v_mov_b32 v66, %1\n v_mov_b32 v67, %1\n"
+            : : "v"(a), "v"(b) : CLOBBERS);
+    }
+    for (int i = 0; i < iters; ++i) {
+        if (V == 0) asm volatile(I8("v_mul_f32_e32", 4, 4, 6) : : : CLOBBERS);          // VOP2, d == s0, sources in the same bank
+        if (V == 1) asm volatile(I8("v_mul_f32_e64", 4, 4, 6) : : : CLOBBERS);          // VOP3, d == s0, same bank
+        if (V == 2) asm volatile(I8("v_mul_f32_e32", 4, 4, 5) : : : CLOBBERS);          // VOP2, d == s0, different banks
+        if (V == 3) asm volatile(I8("v_mul_f32_e64", 4, 4, 5) : : : CLOBBERS);          // VOP3, d == s0, different banks
+        if (V == 4) asm volatile(I8("v_mul_f32_e64", 4, 6, 4) : : : CLOBBERS);          // VOP3, d == s1
+        if (V == 5) asm volatile(I8("v_mul_f32_e32", 7, 4, 6) : : : CLOBBERS);          // VOP2, separate destination, same-bank sources
+        if (V == 6) asm volatile(I8("v_mul_f32_e64", 7, 4, 6) : : : CLOBBERS);          // VOP3, separate destination, same-bank sources
+        if (V == 7) asm volatile(I8("v_mul_f32_e32", 7, 4, 5) : : : CLOBBERS);          // VOP2, separate destination, different banks
+        if (V == 8) asm volatile(I8("v_mul_f32_e64", 7, 4, 5) : : : CLOBBERS);          // VOP3, separate destination, different banks
+        if (V == 9) asm volatile(I8("v_mul_f32_e64", 6, 4, 5) : : : CLOBBERS);          // VOP3, destination in s0's bank
+        if (V == 10) asm volatile(I8C("v_fma_f32", 7, 4, 5, 6) : : : CLOBBERS);         // 3 sources, two in one bank, separate destination
+        if (V == 11) asm volatile(I8C("v_fma_f32", 4, 4, 5, 6) : : : CLOBBERS);         // d == s0
+        if (V == 12) asm volatile(I8C("v_fma_f32", 6, 4, 5, 6) : : : CLOBBERS);         // d == s2 (accumulate)
+        if (V == 13) asm volatile(I8C("v_maximum3_f32", 7, 4, 5, 6) : : : CLOBBERS);
+        if (V == 14) asm volatile(I8C("v_maximum3_f32", 4, 4, 5, 5) : : : CLOBBERS);
+        if (V == 15) asm volatile(I8("v_add_f32_e64", 7, 4, 5) : : : CLOBBERS);
+        if (V == 16) asm volatile(I8("v_add_f32_e64", 4, 4, 5) : : : CLOBBERS);
+        if (V == 17) asm volatile(I8("v_mul_f32_e32", 7, 4, 5) I8("v_add_f32_e32", 7, 7, 6) : : : CLOBBERS);   // compiler-shaped pair: t = a*b; t = t + c   (2 x 8 instructions)
+        if (V == 18) asm volatile(I8("v_mul_f32_e64", 7, 4, 5) I8("v_add_f32_e64", 7, 7, 6) : : : CLOBBERS);
+        if (V == 19) asm volatile(I8("v_max_f32_e64", 4, 4, 5) : : : CLOBBERS);
+        if (V == 20) asm volatile(I8("v_max_f32_e32", 4, 4, 5) : : : CLOBBERS);
+        if (V == 21) asm volatile(I8("v_sub_f32_e64", 4, 4, 5) : : : CLOBBERS);
+        if (V == 22) asm volatile(I8("v_min_u32_e64", 4, 4, 5) : : : CLOBBERS);
+        if (V == 23) asm volatile(I8("v_max_i32_e64", 4, 4, 5) : : : CLOBBERS);
+        if (V == 24) asm volatile(I8("v_and_b32_e64", 7, 4, 5) : : : CLOBBERS);
+        if (V == 25) asm volatile(I8("v_xor_b32_e64", 4, 4, 5) : : : CLOBBERS);
+        if (V == 26) asm volatile(I8("v_mul_f32_e64", 4, 4, 4) : : : CLOBBERS);          // one register read
+        if (V == 27) asm volatile(I8("v_mul_f32_e32", 4, 4, 4) : : : CLOBBERS);
+    }
+    float acc;
+    asm volatile("v_add_f32 %0, v40, v50\n v_add_f32 %0, %0, v60\n v_add_f32 %0, %0, v70\n v_add_f32 %0, %0, v47\n v_add_f32 %0, %0, v77" : "=v"(acc) : : CLOBBERS);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+static int g_varied = 0;
+template <int V>
+static int run(const char* name, float* d_out, int n_cus, int per_iter = 8) {
+    const int iters = 20000, blocks = n_cus * 6;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_probe<V>), dim3(blocks), dim3(256), 0, 0, d_out, 200, 1.0f, g_varied);
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_probe<V>), dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.0f, g_varied);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double ns = best * 1e6 / (6.0 * iters * per_iter);
+    printf("%-64s %.3f ns = %.2f cycles at 2.4 GHz per wave-instruction per SIMD\n", name, ns, ns * 2.4);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    g_varied = argc > 1 ? atoi(argv[1]) : 0;
+    printf("operands: %s\n", g_varied ? "varied per lane (busy mantissas)" : "1.0 everywhere");
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int n = prop.multiProcessorCount;
+    float* d;
+    CK(hipMalloc(&d, sizeof(float) * n * 6 * 256));
+    printf("registers: group 4x / 6x share banks (v4k, v6k: bank k mod 4), 5x / 7x are two banks over\n");
+    if (run<0>("v_mul_f32_e32 v4k, v4k, v6k   VOP2 d==s0, same-bank sources", d, n)) return 1;
+    if (run<1>("v_mul_f32_e64 v4k, v4k, v6k   VOP3 d==s0, same-bank sources", d, n)) return 1;
+    if (run<2>("v_mul_f32_e32 v4k, v4k, v5k   VOP2 d==s0, different banks", d, n)) return 1;
+    if (run<3>("v_mul_f32_e64 v4k, v4k, v5k   VOP3 d==s0, different banks", d, n)) return 1;
+    if (run<4>("v_mul_f32_e64 v4k, v6k, v4k   VOP3 d==s1", d, n)) return 1;
+    if (run<5>("v_mul_f32_e32 v7k, v4k, v6k   VOP2 separate d, same-bank sources", d, n)) return 1;
+    if (run<6>("v_mul_f32_e64 v7k, v4k, v6k   VOP3 separate d, same-bank sources", d, n)) return 1;
+    if (run<7>("v_mul_f32_e32 v7k, v4k, v5k   VOP2 separate d, different banks", d, n)) return 1;
+    if (run<8>("v_mul_f32_e64 v7k, v4k, v5k   VOP3 separate d, different banks", d, n)) return 1;
+    if (run<9>("v_mul_f32_e64 v6k, v4k, v5k   VOP3 d in s0's bank", d, n)) return 1;
+    if (run<10>("v_fma_f32 v7k, v4k, v5k, v6k  separate d", d, n)) return 1;
+    if (run<11>("v_fma_f32 v4k, v4k, v5k, v6k  d==s0", d, n)) return 1;
+    if (run<12>("v_fma_f32 v6k, v4k, v5k, v6k  d==s2", d, n)) return 1;
+    if (run<13>("v_maximum3_f32 v7k, v4k, v5k, v6k", d, n)) return 1;
+    if (run<14>("v_maximum3_f32 v4k, v4k, v5k, v5k", d, n)) return 1;
+    if (run<15>("v_add_f32_e64 v7k, v4k, v5k", d, n)) return 1;
+    if (run<16>("v_add_f32_e64 v4k, v4k, v5k", d, n)) return 1;
+    if (run<17>("pair v_mul_e32 v7k,v4k,v5k ; v_add_e32 v7k,v7k,v6k (per instr)", d, n, 16)) return 1;
+    if (run<18>("pair v_mul_e64 v7k,v4k,v5k ; v_add_e64 v7k,v7k,v6k (per instr)", d, n, 16)) return 1;
+    if (run<19>("v_max_f32_e64 v4k, v4k, v5k", d, n)) return 1;
+    if (run<20>("v_max_f32_e32 v4k, v4k, v5k", d, n)) return 1;
+    if (run<21>("v_sub_f32_e64 v4k, v4k, v5k", d, n)) return 1;
+    if (run<22>("v_min_u32_e64 v4k, v4k, v5k", d, n)) return 1;
+    if (run<23>("v_max_i32_e64 v4k, v4k, v5k", d, n)) return 1;
+    if (run<24>("v_and_b32_e64 v7k, v4k, v5k", d, n)) return 1;
+    if (run<25>("v_xor_b32_e64 v4k, v4k, v5k", d, n)) return 1;
+    if (run<26>("v_mul_f32_e64 v4k, v4k, v4k", d, n)) return 1;
+    if (run<27>("v_mul_f32_e32 v4k, v4k, v4k", d, n)) return 1;
+    return 0;
+}
