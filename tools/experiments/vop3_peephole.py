@@ -30,6 +30,9 @@ def encodable(tok):
     return False  # hex literals, symbols, anything else: leave the instruction alone
 
 
+ONLY_CNDMASK = len(sys.argv) > 3 and sys.argv[3] == "cndmask"   # second experiment: only v_cndmask_b32_e32 ..., vcc -> _e64 (22 cycles in the probe)
+
+
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     counts = {}
@@ -40,9 +43,16 @@ def main():
         if m:
             indent, op, operands, comment = m.group(1), m.group(2), m.group(3), m.group(4) or ""
             toks = [t.strip() for t in operands.split(",")]
-            if op in PLAIN and len(toks) == 3 and all(encodable(t) for t in toks):
+            if op in PLAIN and not ONLY_CNDMASK and len(toks) == 3 and all(encodable(t) for t in toks):
                 out.append(f"{indent}{op}_e64 {', '.join(toks)}{comment}\n")
                 counts[op] = counts.get(op, 0) + 1
+                continue
+            if op == "v_cndmask_b32" and ONLY_CNDMASK and len(toks) == 4 and toks[3] == "vcc" and all(encodable(t) for t in toks[:3]):
+                out.append(f"{indent}v_cndmask_b32_e64 {', '.join(toks)}{comment}\n")
+                counts[op] = counts.get(op, 0) + 1
+                continue
+            if ONLY_CNDMASK:
+                out.append(line)
                 continue
             if op == "v_fmac_f32" and len(toks) == 3 and all(encodable(t) for t in toks):
                 out.append(f"{indent}v_fma_f32 {toks[0]}, {toks[1]}, {toks[2]}, {toks[0]}{comment}\n")

@@ -82,6 +82,8 @@ FORMS = [
     ("v_and_b32_e64", lambda k: f"v_and_b32_e64 {D(k)}, {A(k)}, {B(k)}"),
     ("v_lshrrev_b32_e64", lambda k: f"v_lshrrev_b32_e64 {D(k)}, 3, {A(k)}"),
     ("v_mul_f32_e32 3rd", lambda k: f"v_mul_f32_e32 {D(k)}, {A(k)}, {B(k)}"),
+    ("v_cndmask_b32_e64 vcc", lambda k: f"v_cndmask_b32_e64 {D(k)}, {A(k)}, {B(k)}, vcc"),
+    ("v_cndmask_b32_e32 const", lambda k: f"v_cndmask_b32_e32 {D(k)}, 0, {B(k)}, vcc"),
     ("v_mul_f32_e32 d==s0", lambda k: f"v_mul_f32_e32 {A(k)}, {A(k)}, {B(k)}"),
     ("v_mul_f32_e64 d==s0", lambda k: f"v_mul_f32_e64 {A(k)}, {A(k)}, {B(k)}"),
 ]
