@@ -530,6 +530,63 @@ def main():
         if rank == 0:
             extras["view_factors_c5"] = vf
 
+    def extra_one_process_multi_device():
+        """The C ABI's own multi-device entry points (one process, one scene per device) -- only measurable where this
+        process sees more than one GPU (the driver's 8-GPU node at N = 1).  RC_BENCH_FORCE_MULTI=k puts k replicas on device 0 instead:
+        a functional run of the same code, not a scaling number."""
+        forced = int(os.environ.get("RC_BENCH_FORCE_MULTI", "0"))
+        n_dev = rc.device_count()
+        devices = [0] * forced if forced > 1 else list(range(n_dev))
+        if len(devices) < 2:
+            return
+        md = {"devices": devices, "forced_replicas_on_one_device": bool(forced > 1)}
+        # (1) view_factors into a host matrix, ROWS: every device brings its row block home over its own PCIe link, no collective
+        cfg5 = sc.config_c5()
+        scenes5 = []
+        for d in devices:
+            t = rc.TLAS(d)
+            t.add_geometry(*cfg5["blas"][0])
+            t.push_instances(1, cfg5["instances"][0][1], cfg5["instances"][0][2])
+            scenes5.append(t.sync())
+        n5, rpt = scenes5[0].n_primitives(), cfg5["rays_per_triangle"]
+        out_m = np.empty((n5, n5), dtype=np.uint32, order="F")
+        rc.view_factors(scenes5[0], rpt, 7, out=out_m)            # one device; also faults the matrix in
+        want = int(out_m.sum(dtype=np.int64))
+        best1 = bestn = 1e30
+        for _ in range(2):
+            v0 = time.perf_counter(); rc.view_factors(scenes5[0], rpt, 7, out=out_m); best1 = min(best1, time.perf_counter() - v0)
+        for _ in range(2):
+            v0 = time.perf_counter(); rc.view_factors_multi(scenes5, rpt, 7, mode="rows", out=out_m); bestn = min(bestn, time.perf_counter() - v0)
+        md["view_factors_c5_host_matrix"] = {"one_device_s": round(best1, 4), "all_devices_rows_s": round(bestn, 4), "speedup": round(best1 / bestn, 2),
+                                             "same_count": int(out_m.sum(dtype=np.int64)) == want, "matrix_bytes": 4 * n5 * n5}
+        del out_m
+        for t in scenes5:
+            t.free()
+        # (2) one host batch of closest_hit rays: contiguous shards, every device uploads / traces / downloads its own
+        replicas = []
+        for d in devices:
+            t = rc.TLAS(d)
+            for verts, meta in cfg["blas"]:
+                t.add_geometry(verts, meta)
+            for b, xf, ids in cfg["instances"]:
+                t.push_instances(b, xf, ids)
+            replicas.append(t.sync())
+        big = np.concatenate([rays] * 4)                            # 16.8 M rays, 0.54 GB each way
+        out_h = np.empty(len(big), dtype=rc.HIT_DT)
+        replicas[0].trace(big, out=out_h)
+        ref = out_h.copy()
+        best1 = bestn = 1e30
+        for _ in range(2):
+            v0 = time.perf_counter(); replicas[0].trace(big, out=out_h); best1 = min(best1, time.perf_counter() - v0)
+        for _ in range(2):
+            v0 = time.perf_counter(); rc.trace_multi(replicas, big, out=out_h); bestn = min(bestn, time.perf_counter() - v0)
+        md["host_batch_closest_hit"] = {"rays": len(big), "one_device_Mrays_s": round(len(big) / best1 / 1e6, 1), "all_devices_Mrays_s": round(len(big) / bestn / 1e6, 1),
+                                        "speedup": round(best1 / bestn, 2), "identical_hits": bool(out_h.tobytes() == ref.tobytes()),
+                                        "note": "host buffers in, host buffers out: 64 bytes per ray over PCIe, one link per device"}
+        for t in replicas:
+            t.free()
+        extras["one_process_multi_device"] = md
+
     counts = load_json(COUNTS_FILE) or {}
     node_f = float(counts.get("node_fetches_per_ray", C3_NODE_FETCHES_PER_RAY))
     inst_f = float(counts.get("instance_entries_per_ray", C3_INST_ENTRIES_PER_RAY))
@@ -691,6 +748,8 @@ def main():
         guarded_extra("traces", extra_traces)
         guarded_extra("builds", extra_builds)
         guarded_extra("bvh4_collision", extra_bvh4_and_collision)
+        if world == 1:
+            guarded_extra("one_process_multi_device", extra_one_process_multi_device)
     emit()
     if any(k == "view_factors_error" for k in extras) and world > 1:
         raise SystemExit(3)
