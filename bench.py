@@ -498,10 +498,24 @@ def main():
         hm = rd.view_factors_host_matrix(t5, rpt, 7)
         fence()
         vdt = time.perf_counter() - v0
+        counted_fresh = int(np.asarray(hm).sum(dtype=np.int64)) if rank == 0 else 0
+        del hm
+        # a solver calls view_factors again and again: the shared matrix is created once (SharedHostMatrix) and refilled
+        shared = rd.SharedHostMatrix(n5)
+        best = 1e30
+        for _ in range(2):
+            fence()
+            v0 = time.perf_counter()
+            hm = rd.view_factors_host_matrix(t5, rpt, 7, out=shared)
+            fence()
+            best = min(best, time.perf_counter() - v0)
         if rank == 0:
-            vf["host_matrix_shared_memory"] = {"seconds": round(vdt, 4), "Mrays_s": round(n5 * rpt / vdt / 1e6, 1), "ranks": world,
-                                               "GBs_into_host_memory": round(4 * n5 * n5 / vdt / 1e9, 1), "counted": int(np.asarray(hm).sum(dtype=np.int64)),
-                                               "note": "end to end incl. creating + faulting in the matrix in /dev/shm; every rank writes its rows over its own PCIe link"}
+            vf["host_matrix_shared_memory"] = {"fresh_matrix_s": round(vdt, 4), "reused_matrix_s": round(best, 4), "Mrays_s_reused": round(n5 * rpt / best / 1e6, 1), "ranks": world,
+                                               "GBs_into_host_memory_reused": round(4 * n5 * n5 / best / 1e9, 1), "counted": counted_fresh,
+                                               "counted_reused": int(np.asarray(hm).sum(dtype=np.int64)),
+                                               "note": "one process per GPU, every rank writes its rows into a matrix in /dev/shm over its own PCIe link; fresh = incl. creating + "
+                                                       "faulting in the matrix (shared-memory pages: ~0.3 s per GB from one rank), reused = a SharedHostMatrix created once"}
+        del shared
         del hm
         if world == 1:
             out_m = np.empty((n5, n5), dtype=np.uint32, order="F")

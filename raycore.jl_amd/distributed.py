@@ -170,43 +170,61 @@ def _populate(base, byte_range, n_threads):
         t.join()
 
 
-def view_factors_host_matrix(tlas, rays_per_triangle=10000, seed=0, group=None, dst=0, n_prims=None, compute_rows=None):
+class SharedHostMatrix:
+    """An N x N uint32 matrix, column-major like Julia's Matrix, in shared memory (/dev/shm) that every rank of the group maps.  Creating
+    it is collective and costs what 4 N^2 bytes of fresh shared-memory pages cost (C5: 10 GB, ~3 s from one rank, split G ways with G
+    ranks); a solver that calls view_factors repeatedly creates it ONCE and passes it as `out=` -- the calls then cost the PCIe time of
+    each rank's row block.  `array` is the np.memmap (every rank has the whole matrix mapped; rank `dst` is the one that returns it)."""
+
+    def __init__(self, n, group=None, dst=0):
+        import os
+        dist = _dist()
+        world, rank, me = _ranks(group)
+        self.n, self.group, self.dst = int(n), group, dst
+        name = [None]
+        if me == dst:
+            name[0] = f"/dev/shm/raycore_vf_{os.getpid()}_{np.random.default_rng().integers(1 << 62):x}"
+            with open(name[0], "wb") as f:
+                f.truncate(max(1, 4 * self.n * self.n))
+        if world > 1:
+            dist.broadcast_object_list(name, src=dst, group=group)
+        try:
+            self.array = np.memmap(name[0], dtype=np.uint32, mode="r+", shape=(self.n, self.n), order="F")
+            # fault the pages in before the copies arrive: every rank its own slice of the file, a few threads per rank (shared-memory
+            # pages cost ~0.15 s per GB to allocate from one thread; ctypes releases the GIL during the madvise calls)
+            _populate(self.array.ctypes.data, shard_range(4 * self.n * self.n, rank, world), max(1, min(8, (os.cpu_count() or 8) // max(world, 1))))
+            if world > 1:
+                dist.barrier(group=group)
+        finally:
+            if me == dst:
+                os.unlink(name[0])  # the mappings keep the pages alive
+
+
+def view_factors_host_matrix(tlas, rays_per_triangle=10000, seed=0, group=None, dst=0, n_prims=None, compute_rows=None, out=None):
     """view_factors as the API returns it -- a HOST N x N uint32 matrix, column-major (src/kernels.jl:74-78) -- from one process per GPU:
     rank `dst` creates the matrix in shared memory (/dev/shm), every rank maps it and brings ITS block of rows home over its own PCIe
     link (rc_view_factors_rows_host: row chunks traced while the finished ones are copied), so G links run in parallel, nothing
     crosses xGMI and the only collective is the barrier at the end.  This is the partition that serves the API's return value: at
     C5 the matrix is 10 GB -- 0.18 s over one link, whatever the tracing costs -- against 23 ms per rank with eight.
     Returns the matrix (a np.memmap, order F; the file is already unlinked) on `dst`, None elsewhere.
+    out: a SharedHostMatrix created earlier by every rank of the group -- reuses its pages (every element is overwritten).
     compute_rows(out, (r0, r1)): stand-in for the device call in the CPU tests (fills rows [r0, r1) of `out`)."""
-    import os
     dist = _dist()
     world, rank, me = _ranks(group)
     n = int(n_prims if n_prims is not None else tlas.n_primitives())
-    name = [None]
-    if me == dst:
-        name[0] = f"/dev/shm/raycore_vf_{os.getpid()}_{np.random.default_rng().integers(1 << 62):x}"
-        with open(name[0], "wb") as f:
-            f.truncate(max(1, 4 * n * n))
+    if out is None:
+        out = SharedHostMatrix(n, group, dst)
+    elif out.n != n:
+        raise ValueError(f"out is a {out.n} x {out.n} matrix, the scene has {n} primitives")
+    m = out.array
+    r0, r1 = shard_range(n, rank, world)
+    if compute_rows is not None:
+        compute_rows(m, (r0, r1))
+    else:
+        check(lib().rc_view_factors_rows_host(tlas._h, int(rays_per_triangle), int(seed), r0, r1, m.ctypes.data_as(_capi.C.c_void_p), n))
     if world > 1:
-        dist.broadcast_object_list(name, src=dst, group=group)
-    out = np.memmap(name[0], dtype=np.uint32, mode="r+", shape=(n, n), order="F")
-    try:
-        # fault the pages in before the copies arrive: every rank its own slice of the file, a few threads per rank (shared-memory pages
-        # cost ~0.15 s per GB to allocate from one thread; ctypes releases the GIL during the madvise calls)
-        _populate(out.ctypes.data, shard_range(4 * n * n, rank, world), max(1, min(8, (os.cpu_count() or 8) // max(world, 1))))
-        if world > 1:
-            dist.barrier(group=group)
-        r0, r1 = shard_range(n, rank, world)
-        if compute_rows is not None:
-            compute_rows(out, (r0, r1))
-        else:
-            check(lib().rc_view_factors_rows_host(tlas._h, int(rays_per_triangle), int(seed), r0, r1, out.ctypes.data_as(_capi.C.c_void_p), n))
-        if world > 1:
-            dist.barrier(group=group)
-    finally:
-        if me == dst:
-            os.unlink(name[0])  # the mapping keeps the pages alive
-    return out if me == dst else None
+        dist.barrier(group=group)
+    return m if me == dst else None
 
 
 def _view_factors_general(dist, group, world, rank, me, dst, mode, n, rpt, compute, device, meta):

@@ -64,13 +64,22 @@ def _worker(rank, world, port, mode, q, variant="plain"):
         elif mode == "host_matrix":
             def compute_rows(out, rng):
                 """Stand-in for rc_view_factors_rows_host: matrix rows [r0, r1) of the shared host matrix (column-major), from the oracle."""
+                out[rng[0]:rng[1], :] = 0  # like the real call, every element of the rank's rows is written
                 for prim in range(n):
                     r = int(meta[prim]) - 1
                     if rng[0] <= r < rng[1]:
                         out[r, :] += o.view_factor_row(rpt, int(prim), seed=seed)
             out = rd.view_factors_host_matrix(None, rpt, seed, n_prims=n, compute_rows=compute_rows)
-            res = None if out is None else np.array(out)  # a copy: the mapping dies with the worker
+            first = None if out is None else np.array(out)  # a copy: the mapping dies with the worker
             assert out is None or (out.flags["F_CONTIGUOUS"] and not [f for f in os.listdir("/dev/shm") if f.startswith(f"raycore_vf_{os.getpid()}_")])
+            # a matrix created once and filled repeatedly (a solver's loop): stale contents are overwritten, nothing is re-created
+            shared = rd.SharedHostMatrix(n)
+            shared.array[:] = 0xDEADBEEF
+            dist.barrier()
+            for _ in range(2):
+                again = rd.view_factors_host_matrix(None, rpt, seed, n_prims=n, compute_rows=compute_rows, out=shared)
+            assert (again is None) == (out is None) and (again is None or again is shared.array)
+            res = None if out is None else (first, np.array(again))
         elif mode == "rows_sharded":
             block, rows = rd.view_factors_distributed(None, rpt, seed, mode=mode, n_prims=n, compute=compute, device=torch.device("cpu"), prim_meta=meta)
             res = (block.numpy().view(np.uint32).copy(), rows)
@@ -191,7 +200,10 @@ def test_host_matrix_in_shared_memory_world2(oracle):
     results = _run(2, "host_matrix", "plain", 30)
     o, n = _scene(oracle, rc)
     assert results[1] is None
-    assert np.array_equal(results[0], o.view_factors(64, seed=99)) and results[0].sum() > 0
+    want = o.view_factors(64, seed=99)
+    fresh, reused = results[0]
+    assert np.array_equal(fresh, want) and fresh.sum() > 0
+    assert np.array_equal(reused, want)   # through a SharedHostMatrix created once, prefilled with garbage
 
 
 def test_shard_range_covers_everything():
