@@ -72,6 +72,8 @@ def lib():
         L.rco_pool_pin.argtypes = [C.c_int]
         L.rco_allowed_cpus.restype = C.c_int
         L.rco_brute_closest.argtypes = [vp, vp, vp]
+        L.rco_corner.restype = None
+        L.rco_corner.argtypes = [vp, vp, C.c_int, vp]
         L.rco_expand_bits.restype = u32
         L.rco_expand_bits.argtypes = [u32]
         L.rco_morton_code_30bit.restype = u32

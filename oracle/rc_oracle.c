@@ -413,6 +413,11 @@ static inline v3 corner(const float mn[3], const float mx[3], int c) {
     return V((c & 1) == 0 ? mn[0] : mx[0], (c & 2) == 0 ? mn[1] : mx[1], (c & 4) == 0 ? mn[2] : mx[2]);
 }
 
+void rco_corner(const float mn[3], const float mx[3], int c, float out[3]) { /* test hook: the reference pins corner() in test/bounds.jl:92-103 */
+    v3 p = corner(mn, mx, c);
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
 /* build_tlas_topology (src/instanced-bvh.jl:1485-1594) + flat arrays of build_tlas (:1605-1651) */
 int rco_scene_build(rco_scene* s) {
     free_static(s);

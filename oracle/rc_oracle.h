@@ -114,6 +114,7 @@ void rco_trace_batch(const rco_scene*, const rco_ray* rays, rco_hit* hits, uint6
 void rco_brute_closest(const rco_scene*, const rco_ray*, rco_hit*);
 
 /* ---- small pieces exposed for the reference's unit KATs ------------------------------------------ */
+void rco_corner(const float mn[3], const float mx[3], int c, float out[3]);  /* corner(b, c), c = 1..8, src/bounds.jl:53-59 */
 uint32_t rco_expand_bits(uint32_t x);                       /* :1177-1183 */
 uint32_t rco_morton_code_30bit(const float p[3]);           /* :1189-1200 */
 int32_t rco_clz32(uint32_t x);                              /* :1203-1206 */

@@ -27,6 +27,26 @@ def test_morton_ordering(oracle):  # test/test_instanced_bvh.jl:20-37
     assert c1 < c2 and c1 < c3 < c2
 
 
+def test_bounds3_corner_order(oracle):  # test/bounds.jl:92-103 (corner(b, c): bit 0 -> x, bit 1 -> y, bit 2 -> z; src/bounds.jl:53-59)
+    L = oracle.lib()
+    mn, mx = np.zeros(3, np.float32), np.ones(3, np.float32)
+    want = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1)]
+    for c, w in enumerate(want, start=1):
+        out = np.empty(3, np.float32)
+        L.rco_corner(mn.ctypes.data, mx.ctypes.data, c, out.ctypes.data)
+        assert tuple(out) == w, (c, out)
+    # the instance world AABB is the min / max over these eight corners through the forward transform (src/instanced-bvh-kernels.jl:38-62):
+    # a quarter turn about z maps the unit cube [0,1]^3 to [-1,0] x [0,1] x [0,1]
+    s = oracle.Scene()
+    tri = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 1]], dtype=np.float32)           # root AABB = the unit cube
+    s.add_blas(tri, np.array([1], np.uint32))
+    rot = np.array([[0, -1, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0]], dtype=np.float32)
+    s.add_instance(1, rot, 0)
+    st = s.build()
+    wb = st.world_bound
+    assert np.array_equal(wb[:3], np.float32([-1, 0, 0])) and np.array_equal(wb[3:], np.float32([0, 1, 1]))
+
+
 def test_expand_bits_clz(oracle):  # test/test_instanced_bvh.jl:175-184
     L = oracle.lib()
     assert L.rco_expand_bits(0) == 0
