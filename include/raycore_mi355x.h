@@ -27,9 +27,10 @@
  *    scene on one stream.  rc_last_kernel_ms reports the calling thread's latest launch.  No global mutable state.
  *  - hipGraph capture: trace / driver launches on a capturing stream are captured (no events, a counter slot of their own that eager
  *    launches never use); the stream must have run one eager launch on the scene before (stack spill area), see INTEGRATION.md.
- *    While a capture in hipStreamCaptureModeGlobal is open anywhere in the process, do not call entry points that allocate or free
- *    device memory (scene create / destroy / sync, the host-buffer queries) -- a finaliser destroying a scene counts (HIP invalidates the
- *    capture and the captured launch returns RC_ERR_HIP).
+ *    Entry points that allocate, copy or free (scene create / destroy / sync, the host-buffer queries) may run on any thread while a
+ *    capture is open elsewhere in the process, also one in hipStreamCaptureModeGlobal: they set the calling thread's capture interaction
+ *    mode to relaxed for their duration and touch only the scene's own streams.  rc_scene_destroy waits for the scene's own streams and
+ *    for the launches it recorded on the callers' streams, not for the whole device.
  *  - There is NO CPU fallback: every compute entry point runs hand-written gfx950 HIP kernels and fails
  *    with RC_ERR_NO_DEVICE when no GPU is present.
  *  - Index bases at this boundary are 0-based (C); the host wrappers add 1 where the Julia API is 1-based.

@@ -720,6 +720,7 @@ void rc_launch_export_triangles(rc_scene* s, void* d_out, hipStream_t stream) {
     rc_ensure_flat_attrs(s);
     hipLaunchKernelGGL(k_export_triangles, dim3(grid_for(s->n_flat_prims)), dim3(kBlock), 0, stream, s->flat_prims.p, s->flat_attrs.p, s->n_flat_prims, (uint32_t*)d_out);
     RC_HIP(hipGetLastError());
+    rc_note_stage_launch(s, stream);
 }
 
 void rc_launch_shading_attributes(rc_scene* s, const RcHit* d_hits, uint64_t n, float* d_normals, float* d_uvs, hipStream_t stream) {
@@ -727,6 +728,7 @@ void rc_launch_shading_attributes(rc_scene* s, const RcHit* d_hits, uint64_t n, 
     rc_ensure_flat_attrs(s);
     hipLaunchKernelGGL(k_shading_attributes, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_hits, n, s->flat_attrs.p, d_normals, d_uvs);
     RC_HIP(hipGetLastError());
+    rc_note_stage_launch(s, stream);
 }
 
 void rc_launch_reflection_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float bias, RcRay* d_out, hipStream_t stream) {
@@ -734,6 +736,7 @@ void rc_launch_reflection_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_
     rc_ensure_flat_attrs(s);
     hipLaunchKernelGGL(k_reflection_rays, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_rays, d_hits, n, s->flat_attrs.p, bias, d_out);
     RC_HIP(hipGetLastError());
+    rc_note_stage_launch(s, stream);
 }
 
 // build_blas (src/instanced-bvh.jl:1376-1443) over the n compacted primitives waiting in s->prim_tmp

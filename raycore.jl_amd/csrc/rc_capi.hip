@@ -29,8 +29,21 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+// Another thread of the process may have a stream capture open in hipStreamCaptureModeGlobal (torch.cuda.graph's default): a
+// "potentially unsafe" call from ANY thread -- hipMalloc, hipFree, a blocking copy: what scene creation, rc_sync, the host-buffer queries
+// and rc_scene_destroy do -- would then fail AND invalidate that capture.  Every entry point runs with the calling thread's capture
+// interaction mode set to relaxed for its duration: its own allocations and copies touch only the scene's streams, never the capturing
+// one, so they are safe beside a capture.  (A launch that is itself being captured makes no such call: rc_launch_trace refuses a
+// capture that would need one.)
+struct CaptureRelaxed {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    CaptureRelaxed() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+    ~CaptureRelaxed() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+};
+
 template <typename F>
 int guarded(F&& f) {
+    CaptureRelaxed relaxed;
     try {
         f();
         return RC_OK;
@@ -234,8 +247,19 @@ int rc_scene_create(int device, rc_scene** out) {
 
 int rc_scene_destroy(rc_scene* s) {
     if (!s) return RC_OK;
+    CaptureRelaxed relaxed;  // a finaliser may run this while another thread captures a graph (see guarded())
     (void)hipSetDevice(s->device);
-    (void)hipDeviceSynchronize();
+    // Wait for exactly the work that may still read the scene: the launches it recorded on the callers' streams (launch slots, stage
+    // kernels) and its own streams.  Not hipDeviceSynchronize: HIP refuses that while any stream of the process is being captured, and
+    // the refusal invalidates the capture.  (Replays of graphs that captured launches on this scene are the caller's to wait for.)
+    for (auto& kv : s->stage_events) { (void)hipEventSynchronize(kv.second); (void)hipEventDestroy(kv.second); }
+    s->stage_events.clear();
+    for (int i = 0; i < (int)s->slots.size(); ++i)
+        if (s->slots[i].recorded && s->slots[i].t1) (void)hipEventSynchronize(s->slots[i].t1);
+    for (auto& c : s->call_ctx) if (c && c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto a : s->aux_streams) if (a) (void)hipStreamSynchronize(a);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    (void)hipGetLastError();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (int i = 0; i < kCounterSlots && i < (int)s->slots.size(); ++i) {  // (the last entry aliases ev0 / ev1)

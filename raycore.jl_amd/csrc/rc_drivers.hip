@@ -538,11 +538,35 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     launch.finish();
 }
 
+// Kernels outside RcLaunchGuard that read scene memory on a caller's stream (the wavefront stages): remember the stream's latest such
+// launch.  rc_scene_destroy waits for these events and for the launch slots' -- not for the whole device, which HIP refuses while any
+// stream of the process is being captured.
+void rc_note_stage_launch(rc_scene* s, hipStream_t stream) {
+    if (stream == s->stream) return;  // the scene's own streams are synchronised at destruction
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive) return;  // (a replay in flight is the caller's to wait for)
+    std::lock_guard<std::mutex> lk(s->stage_mu);
+    auto it = s->stage_events.find(stream);
+    if (it == s->stage_events.end()) {
+        if (s->stage_events.size() >= 64) {  // a caller that keeps making streams: retire one whose work is done
+            for (auto jt = s->stage_events.begin(); jt != s->stage_events.end(); ++jt)
+                if (hipEventQuery(jt->second) == hipSuccess) { (void)hipEventDestroy(jt->second); s->stage_events.erase(jt); break; }
+            (void)hipGetLastError();
+            if (s->stage_events.size() >= 64) { auto jt = s->stage_events.begin(); (void)hipEventSynchronize(jt->second); (void)hipEventDestroy(jt->second); s->stage_events.erase(jt); }
+        }
+        hipEvent_t ev = nullptr;
+        RC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        it = s->stage_events.emplace(stream, ev).first;
+    }
+    RC_HIP(hipEventRecord(it->second, stream));
+}
+
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream) {
     if (n_ray == 0) return;
     SceneView v = rc_scene_view(s, 0);
     hipLaunchKernelGGL(k_view_factor_rays, dim3((n_ray + 255) / 256), dim3(256), 0, stream, v, (uint32_t)seed, (uint32_t)(seed >> 32), src, ray_begin, n_ray, d_out);
     RC_HIP(hipGetLastError());
+    rc_note_stage_launch(s, stream);
 }
 
 void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float* d_points, float* d_normals, hipStream_t stream) {
@@ -550,6 +574,7 @@ void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits,
     uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cus * 8);
     hipLaunchKernelGGL(k_hit_points, dim3(blocks), dim3(256), 0, stream, rc_scene_view(s, 0), d_rays, d_hits, n, d_points, d_normals);
     RC_HIP(hipGetLastError());
+    rc_note_stage_launch(s, stream);
 }
 
 void rc_launch_shadow_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, const float light[3], float bias, RcRay* d_out, hipStream_t stream) {
@@ -557,6 +582,7 @@ void rc_launch_shadow_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits
     uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cus * 8);
     hipLaunchKernelGGL(k_shadow_rays, dim3(blocks), dim3(256), 0, stream, rc_scene_view(s, 0), d_rays, d_hits, n, light[0], light[1], light[2], bias, d_out);
     RC_HIP(hipGetLastError());
+    rc_note_stage_launch(s, stream);
 }
 
 void rc_launch_primary_rays(rc_scene* s, const float pos[3], const float right[3], const float up[3], const float forward[3], float half_width,
@@ -588,4 +614,5 @@ void rc_launch_compact_hits(rc_scene* s, const RcHit* d_hits, uint64_t n, uint32
     RC_HIP(hipcub::DeviceScan::ExclusiveSum(s->compact_tmp.p, tmp, s->compact_flags.p, s->compact_pos.p, (int)n, stream));
     hipLaunchKernelGGL(k_scatter_hit_indices, dim3(blocks), dim3(256), 0, stream, s->compact_flags.p, s->compact_pos.p, n, d_indices, d_count);
     RC_HIP(hipGetLastError());
+    rc_note_stage_launch(s, stream);
 }

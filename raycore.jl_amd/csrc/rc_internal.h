@@ -211,6 +211,8 @@ struct rc_scene {
     std::condition_variable ctx_cv;
     std::vector<std::unique_ptr<CallCtx>> call_ctx;
     hipStream_t aux_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // rc_multi.hip: two compute streams, a copy stream, a communication stream (created on first use)
+    std::mutex stage_mu;               // stage kernels (hit points, shadow rays, ...) on the callers' streams: the last launch per stream, so that
+    std::map<hipStream_t, hipEvent_t> stage_events;  // rc_scene_destroy can wait for exactly the work that still reads the scene
     std::mutex host_call_mu;          // the other host-buffer entry points (illumination, view factors, collisions, exports) run one at a time
 
     DevBuf<float> f32_stage;
@@ -307,6 +309,7 @@ void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcCl
 // timing of operations that are not launches through RcLaunchGuard (builds, refits: mutations, externally serialised)
 void rc_timing_scene_begin(rc_scene* s, hipStream_t stream);
 void rc_timing_scene_end(rc_scene* s, hipStream_t stream);
+void rc_note_stage_launch(rc_scene* s, hipStream_t stream);  // after a kernel outside RcLaunchGuard that reads scene memory
 void rc_timing_fixed(rc_scene* s, float ms);
 float rc_timing_read(rc_scene* s);  // the calling thread's latest timed operation on the scene, else the scene's latest
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items);

@@ -1,7 +1,5 @@
 """GPU tests added in round 2: BASELINE config C5 at its stated size, and the work-claim machinery of the persistent kernels
 (chunk counters that are never reset, shard count bounded by the waves of the launch, slot reuse across streams)."""
-import gc
-
 import numpy as np
 import pytest
 
@@ -362,18 +360,7 @@ def test_device_entry_points_reject_null_buffers(rc):
     t.free()
 
 
-@pytest.fixture
-def no_gc():
-    """Nothing may free or allocate device memory anywhere in the process while a (global-mode) stream capture is open -- that includes
-    Python's garbage collector finalising a scene an earlier test dropped (rc_scene_destroy -> hipFree invalidates the capture and the
-    captured launch then fails with hipErrorStreamCaptureInvalidated).  Collect first, keep the collector off for the test."""
-    gc.collect()
-    gc.disable()
-    yield
-    gc.enable()
-
-
-def test_trace_launches_are_hipgraph_capturable(rc, oracle, no_gc):
+def test_trace_launches_are_hipgraph_capturable(rc, oracle):
     """A frame of primary trace -> shadow-ray generation -> any_hit, captured into a hipGraph and replayed: the claim counters reset
     themselves inside the kernels and a launch leaves no host-side state behind, so a replay is as good as a fresh launch (after one
     warm-up launch on the capture stream: the first use of a stream allocates its stack spill region, which a capture cannot do)."""
@@ -399,8 +386,16 @@ def test_trace_launches_are_hipgraph_capturable(rc, oracle, no_gc):
         frame(s.cuda_stream)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
+    bystander = build_product(rc, sc.config_c3(lattice=(2, 1, 1)))
     with torch.cuda.graph(g, stream=s):
         frame(torch.cuda.current_stream().cuda_stream)
+        # entry points that allocate, copy and free run beside an open (global-mode) capture without invalidating it: they switch the
+        # calling thread's capture interaction mode to relaxed (a finaliser destroying a scene mid-capture is the everyday case)
+        bystander.trace(rays[:1000])
+        bystander.free()
+        newcomer = build_product(rc, sc.config_c3(lattice=(1, 1, 1)))
+        frame(torch.cuda.current_stream().cuda_stream)
+    newcomer.free()
     for rep in range(4):
         dh.zero_(); docc.zero_()
         g.replay()
