@@ -715,6 +715,33 @@ void rc_ensure_flat_attrs(rc_scene* s) {
     s->flat_attrs_valid = true;
 }
 
+static hipStream_t rc_utility_stream() {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    int dev = 0;
+    RC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = streams.find(dev);
+    if (it == streams.end()) {
+        hipStream_t st = nullptr;
+        RC_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        it = streams.emplace(dev, st).first;
+    }
+    return it->second;
+}
+void rc_copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (!bytes) return;
+    hipStream_t st = rc_utility_stream();
+    RC_HIP(hipMemcpyAsync(dst, src, bytes, kind, st));
+    RC_HIP(hipStreamSynchronize(st));
+}
+void rc_memset_now(void* p, int value, size_t bytes) {
+    if (!bytes) return;
+    hipStream_t st = rc_utility_stream();
+    RC_HIP(hipMemsetAsync(p, value, bytes, st));
+    RC_HIP(hipStreamSynchronize(st));
+}
+
 void rc_launch_export_triangles(rc_scene* s, void* d_out, hipStream_t stream) {
     if (s->n_flat_prims == 0) return;
     rc_ensure_flat_attrs(s);

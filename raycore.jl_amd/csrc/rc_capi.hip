@@ -35,11 +35,7 @@ int fail(int code, const std::string& msg) {
 // interaction mode set to relaxed for its duration: its own allocations and copies touch only the scene's streams, never the capturing
 // one, so they are safe beside a capture.  (A launch that is itself being captured makes no such call: rc_launch_trace refuses a
 // capture that would need one.)
-struct CaptureRelaxed {
-    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
-    CaptureRelaxed() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
-    ~CaptureRelaxed() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
-};
+using CaptureRelaxed = RcCaptureRelaxed;  // rc_internal.h
 
 template <typename F>
 int guarded(F&& f) {
@@ -100,7 +96,7 @@ void sync_host_instances(rc_scene* s) {
     RC_HIP(hipSetDevice(s->device));
     RC_HIP(hipStreamSynchronize(s->stream));
     if (!s->instances.empty())
-        RC_HIP(hipMemcpy(s->instances.data(), s->d_instances.p, sizeof(RcInstanceDesc) * s->instances.size(), hipMemcpyDeviceToHost));
+        rc_copy_now(s->instances.data(), s->d_instances.p, sizeof(RcInstanceDesc) * s->instances.size(), hipMemcpyDeviceToHost);
     s->host_instances_stale = false;
 }
 
@@ -156,7 +152,7 @@ void export_nodes(rc_scene* s, const RcNode* d, uint32_t n, rc_bvh_node* out, ui
     if (!out || n == 0) return;
     if (capacity < n) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
     std::vector<RcNode> tmp(n);
-    RC_HIP(hipMemcpy(tmp.data(), d, sizeof(RcNode) * n, hipMemcpyDeviceToHost));
+    rc_copy_now(tmp.data(), d, sizeof(RcNode) * n, hipMemcpyDeviceToHost);
     for (uint32_t i = 0; i < n; ++i) {
         memcpy(&out[i], tmp[i].f, 48);
         out[i].child0 = tmp[i].child0; out[i].child1 = tmp[i].child1; out[i].parent = tmp[i].parent;
@@ -175,7 +171,7 @@ void get(FILE* f, void* p, size_t n) { if (n && fread(p, 1, n, f) != n) throw Rc
 template <typename T> void put_dev(FILE* f, const T* d, size_t n, std::vector<unsigned char>& tmp) {
     if (!n) return;
     tmp.resize(n * sizeof(T));
-    RC_HIP(hipMemcpy(tmp.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
+    rc_copy_now(tmp.data(), d, n * sizeof(T), hipMemcpyDeviceToHost);
     put(f, tmp.data(), tmp.size());
 }
 // `check(host copy)` runs before the upload: a scene file is untrusted input, and the kernels index with what it holds
@@ -196,7 +192,7 @@ template <typename T, typename Check> void get_dev(FILE* f, DevBuf<T>& d, size_t
     tmp.resize(n * sizeof(T));
     get(f, tmp.data(), tmp.size());
     check(reinterpret_cast<const T*>(tmp.data()));
-    RC_HIP(hipMemcpy(d.p, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    rc_copy_now(d.p, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice);
 }
 template <typename T> void get_dev(FILE* f, DevBuf<T>& d, size_t n, std::vector<unsigned char>& tmp) { get_dev(f, d, n, tmp, [](const T*) {}); }
 }  // namespace
@@ -569,9 +565,9 @@ int rc_wait(rc_scene* s) {
         // status word is read (and cleared) here
         if (s->counters.p) {
             uint32_t st = 0;
-            RC_HIP(hipMemcpy(&st, rc_status_word(s), 4, hipMemcpyDeviceToHost));
+            rc_copy_now(&st, rc_status_word(s), 4, hipMemcpyDeviceToHost);
             if (st) {
-                RC_HIP(hipMemset(rc_status_word(s), 0, 4));
+                rc_memset_now(rc_status_word(s), 0, 4);
                 throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow in an earlier asynchronous launch (tree deeper than 128 levels)");
             }
         }
@@ -623,7 +619,7 @@ int rc_export_prims(rc_scene* s, rc_prim* out, uint32_t capacity, uint32_t* coun
         if (count) *count = s->n_flat_prims;
         if (!out || s->n_flat_prims == 0) return;
         if (capacity < s->n_flat_prims) throw RcError(RC_ERR_INVALID_ARGUMENT, "export buffer too small");
-        RC_HIP(hipMemcpy(out, s->flat_prims.p, sizeof(RcPrim) * s->n_flat_prims, hipMemcpyDeviceToHost));
+        rc_copy_now(out, s->flat_prims.p, sizeof(RcPrim) * s->n_flat_prims, hipMemcpyDeviceToHost);
     });
 }
 
@@ -655,6 +651,7 @@ static void trace_host_pipelined(rc_scene* s, CallCtx& cx, const rc_ray* rays, r
     std::atomic<bool> abort_all{false};
     auto span = [&](uint64_t c, uint64_t& off, uint64_t& cnt) { off = c * kChunk; cnt = std::min<uint64_t>(kChunk, n - off); };
     std::thread up([&] {
+        RcCaptureRelaxed relaxed;
         hipStream_t st = nullptr;
         hipError_t e = hipSetDevice(s->device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
@@ -668,6 +665,7 @@ static void trace_host_pipelined(rc_scene* s, CallCtx& cx, const rc_ray* rays, r
         if (st) (void)hipStreamDestroy(st);
     });
     std::thread down([&] {
+        RcCaptureRelaxed relaxed;
         hipStream_t st = nullptr;
         hipError_t e = hipSetDevice(s->device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
@@ -710,7 +708,12 @@ static void trace_host_pipelined(rc_scene* s, CallCtx& cx, const rc_ray* rays, r
         }
         (void)hipEventDestroy(ev_begin[c]); (void)hipEventDestroy(ev_end[c]);
     }
-    if (s->counters.p && hipMemcpy(&overflow, rc_status_word(s), 4, hipMemcpyDeviceToHost) == hipSuccess && overflow) (void)hipMemset(rc_status_word(s), 0, 4);
+    if (s->counters.p) {
+        try {
+            rc_copy_now(&overflow, rc_status_word(s), 4, hipMemcpyDeviceToHost);
+            if (overflow) rc_memset_now(rc_status_word(s), 0, 4);
+        } catch (const RcError&) { overflow = 0; (void)hipGetLastError(); }
+    }
     rc_timing_fixed(s, total_ms);  // the chunks' kernel time, transfers excluded (as for the single-launch path)
     if (launch_code) throw RcError(launch_code, launch_error);
     if (copy_error.load()) throw RcError(RC_ERR_HIP, std::string("host-buffer transfer failed: ") + hipGetErrorString((hipError_t)copy_error.load()));
@@ -864,7 +867,7 @@ int rc_collide_instances_any(rc_scene* s, uint32_t handle_a, uint32_t handle_b, 
         if (n == 0) return;
         // "Small download for TLAS nodes" (:247): the leaves only
         std::vector<RcNode> leaves(n);
-        RC_HIP(hipMemcpy(leaves.data(), s->tlas_nodes.p + (n - 1), sizeof(RcNode) * n, hipMemcpyDeviceToHost));
+        rc_copy_now(leaves.data(), s->tlas_nodes.p + (n - 1), sizeof(RcNode) * n, hipMemcpyDeviceToHost);
         for (uint32_t ia = ra.first; ia < ra.first + ra.count; ++ia)
             for (uint32_t ib = rb.first; ib < rb.first + rb.count; ++ib) {
                 const float* a = leaves[ia].f; const float* b = leaves[ib].f;  // leaf position n-1+i (1-based) = leaves[i-1]

@@ -118,6 +118,17 @@ struct TimingRef {
 // Staging of one host-buffer trace call in flight (rc_trace_closest / rc_trace_any / rc_trace_*4): its own stream and device copies of
 // the caller's rays and hits, so that calls from several host threads on one synced scene do not share anything (SURVEY.md 8b:
 // "trace calls are re-entrant on a synced scene"; the reference's drivers call closest_hit from Threads.@threads, src/kernels.jl:64,82).
+// The calling thread's stream-capture interaction mode set to relaxed for a scope (see guarded() in rc_capi.hip): what every entry point and
+// every worker thread of the library runs under, so that its allocations and copies neither fail nor invalidate a capture another thread
+// has open in hipStreamCaptureModeGlobal.
+struct RcCaptureRelaxed {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    RcCaptureRelaxed() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+    ~RcCaptureRelaxed() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+    RcCaptureRelaxed(const RcCaptureRelaxed&) = delete;
+    RcCaptureRelaxed& operator=(const RcCaptureRelaxed&) = delete;
+};
+
 struct CallCtx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -309,6 +320,11 @@ void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcCl
 // timing of operations that are not launches through RcLaunchGuard (builds, refits: mutations, externally serialised)
 void rc_timing_scene_begin(rc_scene* s, hipStream_t stream);
 void rc_timing_scene_end(rc_scene* s, hipStream_t stream);
+// Blocking copies and fills that stay off the legacy null stream: a null-stream operation synchronises with every BLOCKING stream of the
+// device -- also one that another thread is capturing into a graph, which HIP answers by invalidating the capture (no capture
+// interaction mode relaxes that).  These run on a per-device non-blocking utility stream and wait for it.
+void rc_copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+void rc_memset_now(void* p, int value, size_t bytes);
 void rc_note_stage_launch(rc_scene* s, hipStream_t stream);  // after a kernel outside RcLaunchGuard that reads scene memory
 void rc_timing_fixed(rc_scene* s, float ms);
 float rc_timing_read(rc_scene* s);  // the calling thread's latest timed operation on the scene, else the scene's latest

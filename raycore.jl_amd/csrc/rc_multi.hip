@@ -60,9 +60,9 @@ uint32_t chunk_rows_for(rc_scene* s, uint32_t n_cols, uint32_t rows) {  // optio
 
 void status_check(rc_scene* s) {  // after the job's streams have drained
     uint32_t st = 0;
-    RC_HIP(hipMemcpy(&st, rc_status_word(s), 4, hipMemcpyDeviceToHost));
+    rc_copy_now(&st, rc_status_word(s), 4, hipMemcpyDeviceToHost);
     if (st) {
-        RC_HIP(hipMemset(rc_status_word(s), 0, 4));
+        rc_memset_now(rc_status_word(s), 0, 4);
         throw RcError(RC_ERR_STACK_OVERFLOW, "traversal stack overflow (tree deeper than 128 levels)");
     }
 }
@@ -215,6 +215,7 @@ static void for_each_scene(rc_scene* const* scenes, int n_scenes, F&& body) {
     std::vector<int> code(n_scenes, 0);
     for (int g = 0; g < n_scenes; ++g)
         th.emplace_back([&, g] {
+            RcCaptureRelaxed relaxed;
             try {
                 body(g);
             } catch (const RcError& e) { err[g] = e.what(); code[g] = e.code; }

@@ -392,6 +392,13 @@ def test_trace_launches_are_hipgraph_capturable(rc, oracle):
         # entry points that allocate, copy and free run beside an open (global-mode) capture without invalidating it: they switch the
         # calling thread's capture interaction mode to relaxed (a finaliser destroying a scene mid-capture is the everyday case)
         bystander.trace(rays[:1000])
+        big_batch = np.concatenate([rays] * 52)[:3_300_000]       # >= 3 Mi rays: the pipelined path with its upload / download threads
+        assert len(big_batch) == 3_300_000
+        got_big = bystander.trace(big_batch)
+        twin = build_product(rc, sc.config_c3(lattice=(2, 1, 1)))
+        vf2 = rc.view_factors_multi([bystander, twin], 8, seed=3)   # one worker thread per scene
+        assert np.array_equal(got_big[:len(rays)], got_big[len(rays):2 * len(rays)]) and np.array_equal(vf2, rc.view_factors(twin, 8, seed=3))
+        twin.free()
         bystander.free()
         newcomer = build_product(rc, sc.config_c3(lattice=(1, 1, 1)))
         frame(torch.cuda.current_stream().cuda_stream)
