@@ -592,19 +592,103 @@ __global__ void k_pack_nodes(const RcNode* src, RcNode* dst, uint32_t n, uint32_
     if (i < n) dst[i] = (blas_leaves && i + 1u >= blas_leaves) ? rc_pack_leaf(src[i]) : rc_pack_node(src[i]);
 }
 
-// Traversal-side instance records: inverse transform + the BLAS offsets it would otherwise chase.
-__global__ void k_inst_recs(const RcInstanceDesc* inst, const RcBlasDesc* descs, const uint32_t* blas_nprims, uint32_t n, RcInstRec* out) {
+// Per BLAS: the radius, about the centre of its root AABB, of the sphere that holds every LEAF AABB (for a triangle: the distance from the
+// centre to the farthest corner of the triangle's own box).  The reference reaches a triangle only through a slab test of that box, so a
+// ray that stays clear of this sphere -- by more than the slab test's rounding and its 1e-5 direction clamp can move it, see
+// k_inst_recs -- reaches no triangle of the BLAS.  Radii are >= 0: their bit patterns order like the values, and a NaN sorts above all.
+__global__ void k_cull_radius(const RcPrim* prims, uint32_t n, const RcBlasDesc* descs, uint32_t nb, uint32_t* out_bits) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo = 0, hi = nb;  // the BLAS whose primitive range holds i: the last one whose offset is <= i
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (descs[mid].primitives_offset <= i) lo = mid; else hi = mid; }
+    const RcBlasDesc& d = descs[lo];
+    const float* v = prims[i].v;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float c = 0.5f * (d.root_min[k] + d.root_max[k]);
+        const float a = fminf(fminf(v[k], v[3 + k]), v[6 + k]), b = fmaxf(fmaxf(v[k], v[3 + k]), v[6 + k]);
+        const float m = fmaxf(fabsf(a - c), fabsf(b - c));
+        acc += m * m;
+        if (!(v[k] == v[k]) || !(v[3 + k] == v[3 + k]) || !(v[6 + k] == v[6 + k])) acc = NAN;  // (fmin / fmax drop NaNs: keep them)
+    }
+    atomicMax(out_bits + lo, __float_as_uint(sqrtf(acc) * 1.000001f));
+}
+
+// Traversal-side instance records: inverse transform + the BLAS offsets it would otherwise chase -- and the instance's ENTRY-CULL sphere.
+//
+// Entry cull (option "entry_cull").  A TLAS leaf's box is the world AABB of the instance's rotated root box: for round geometry most rays
+// that pass it miss the instance (C3: 72 % of the instance entries reach no triangle), and every such entry costs the ray transform, the
+// three exact reciprocals and a descent that finds nothing.  A skipped entry is exact iff the reference's own traversal of the instance
+// would have tested no triangle: its state after leaving the instance (closest hit, stack, world ray) is then its state before.
+//   (1) In a BLAS of >= 2 triangles every triangle sits in a leaf that is reached only as a child whose box passed the parent's slab
+//       test (intersect_internal_node, :1807-1832); the box is the min / max of the three vertices (exact).
+//   (2) fast_intersect_bbox (:1841-1859) passes only if, for some t in [t_min, closest_t], the ray o' + t e is within 3 eps (|o'| + |box|)
+//       per axis of the box -- o' the computed local origin, e the computed local direction with every component below 1e-5 in magnitude
+//       replaced by +-1e-5 (safe_invdir); NaNs fail the test (NaN-propagating min / max).
+//   (3) |e - d'| < 1.74e-5, and o', d' are the exact images of the world ray under the inverse transform the traversal applies up to
+//       4 eps (|Minv| |o| + |t'|) and 3 eps |Minv| |d|.
+//   So at that t the TRUE world ray is within
+//       r_w + sigma(W) 1.74e-5 |t| + 3 eps kappa |d| |t| + 6 eps (kappa (|o| + |c_w|) + sigma(W) (2 |c'| + r'))
+//   of c_w, with W = Minv^-1, (c', r') the sphere about the root box's centre that holds every leaf box (k_cull_radius), c_w = W (c' - t'),
+//   r_w = sigma(W) r', kappa = sigma(W) sigma(Minv).  The kernel skips the entry only when the SEGMENT t in [t_min, closest_t] of the ray
+//   stays outside the sphere of radius  A + A_ray + (B + 5e-6 |d|) t_bound  around c_w, where
+//       A = 1.01 r_w + 8e-5 (|c_w|_1 + r_w + sigma(W) |c'|_1),  A_ray = 8e-5 |o|_1,  B = 4e-5 sigma(W),
+//       t_bound = 2 (|t_c| + (A + A_ray) / |d|) >= every t at which the ray is that close (t_c = the parameter of closest approach),
+//   and the squared distance is first reduced by 4e-6 |c_w - o|^2 (16x its own rounding): 2.3x the clamp's reach, > 10x every rounding
+//   term (kappa <= 16: 8e-5 / 16 = 80 eps).  The sphere comes from the INVERSE transform the traversal uses, not from the forward one (a
+//   caller may pass an inverse of its own).  Outside the regime these bounds assume nothing is skipped: instances with non-finite or
+//   ill-conditioned transforms (kappa > 16), stretch above 100 or a single-triangle BLAS (that triangle is tested without any box test:
+//   a coplanar ray anywhere in the TLAS leaf's box gets the reference's NaN hit) get A = +inf; rays with a non-finite component or |d|^2
+//   outside [1e-2, 1e6] carry a NaN that fails the comparison (rc_traverse_core.h).  tests/test_gpu_entry_cull.py aims rays at every one of
+//   these edges and compares cull on / off / oracle bit for bit; mutants of the constants are caught by it.
+__global__ void k_inst_recs(const RcInstanceDesc* inst, const RcBlasDesc* descs, const uint32_t* blas_nprims, uint32_t n, RcInstRec* out,
+                            const uint32_t* cull_r_bits, float4* cull_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const RcInstanceDesc& in = inst[i];
     RcInstRec r;
 #pragma unroll
     for (int k = 0; k < 12; ++k) r.inv[k] = in.inv_transform[k];
-    r.nodes_offset = descs[in.blas_index - 1].nodes_offset;
-    r.prims_offset = descs[in.blas_index - 1].primitives_offset;
+    const RcBlasDesc& bd = descs[in.blas_index - 1];
+    r.nodes_offset = bd.nodes_offset;
+    r.prims_offset = bd.primitives_offset;
     r.custom_index = in.instance_id;
     r.n_prims = blas_nprims[in.blas_index - 1];
     out[i] = r;
+    if (!cull_out) return;
+    const float* m = in.inv_transform;  // rows [a b c | t]: local = Minv * world + t
+    const double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6], a20 = m[8], a21 = m[9], a22 = m[10];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+    const double det = a00 * c00 + a01 * c01 + a02 * c02;
+    const double id = 1.0 / det;
+    const double w[9] = {c00 * id, (a02 * a21 - a01 * a22) * id, (a01 * a12 - a02 * a11) * id,
+                         c01 * id, (a00 * a22 - a02 * a20) * id, (a02 * a10 - a00 * a12) * id,
+                         c02 * id, (a01 * a20 - a00 * a21) * id, (a00 * a11 - a01 * a10) * id};  // W = Minv^-1, row-major
+    const double mi[9] = {a00, a01, a02, a10, a11, a12, a20, a21, a22};
+    auto sigma_ub = [](const double* q) {  // sqrt(||Q^T Q||_inf) >= the largest singular value; exact for rotation x uniform scale
+        double best = 0.0;
+        for (int r0 = 0; r0 < 3; ++r0) {
+            double row = 0.0;
+            for (int c0 = 0; c0 < 3; ++c0) row += fabs(q[0 + r0] * q[0 + c0] + q[3 + r0] * q[3 + c0] + q[6 + r0] * q[6 + c0]);
+            best = row > best ? row : best;
+        }
+        return sqrt(best);
+    };
+    const double sW = sigma_ub(w), sI = sigma_ub(mi);
+    const double lx = 0.5 * ((double)bd.root_min[0] + bd.root_max[0]) - m[3], ly = 0.5 * ((double)bd.root_min[1] + bd.root_max[1]) - m[7],
+                 lz = 0.5 * ((double)bd.root_min[2] + bd.root_max[2]) - m[11];
+    const double cx = w[0] * lx + w[1] * ly + w[2] * lz, cy = w[3] * lx + w[4] * ly + w[5] * lz, cz = w[6] * lx + w[7] * ly + w[8] * lz;
+    const double rl = (double)__uint_as_float(cull_r_bits[in.blas_index - 1]);
+    const double rw = rl * sW * 1.00001;
+    const double lc1 = fabs(0.5 * ((double)bd.root_min[0] + bd.root_max[0])) + fabs(0.5 * ((double)bd.root_min[1] + bd.root_max[1])) +
+                       fabs(0.5 * ((double)bd.root_min[2] + bd.root_max[2]));  // |c'|_1: a mesh far from its own origin has large LOCAL coordinates, and the slab test rounds in those
+    double A = 1.01 * rw + 8.0e-5 * (fabs(cx) + fabs(cy) + fabs(cz) + rw + sW * lc1);
+    const double B = 4.0e-5 * sW;
+    const bool ok = r.n_prims >= 2u && sW <= 100.0 && sW * sI <= 16.0 && A < 1.0e30 && fabs(cx) < 1.0e30 && fabs(cy) < 1.0e30 && fabs(cz) < 1.0e30;  // (NaN anywhere: false)
+    if (!ok) A = INFINITY;
+    cull_out[2 * i] = make_float4((float)cx, (float)cy, (float)cz, (float)A * (ok ? 1.000001f : 1.0f));
+    cull_out[2 * i + 1] = make_float4(ok ? (float)B * 1.000001f : 0.0f, 0.f, 0.f, 0.f);
 }
 
 // stable sortperm of the 30-bit keys (Base.sortperm / AK.sortperm, src/instanced-bvh.jl:1399, 1533-1540).  rocPRIM's default switches
@@ -862,6 +946,9 @@ void rc_build_tlas(rc_scene* s) {
     for (uint32_t i = 0; i < nb; ++i) s->blas_nprims[i] = s->blas[i].n_prims;
     s->d_blas_nprims.reserve(nb ? nb : 1);
     if (nb) RC_HIP(hipMemcpyAsync(s->d_blas_nprims.p, s->blas_nprims.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, s->stream));
+    s->blas_cull_bits.reserve(nb ? nb : 1);  // entry cull (k_inst_recs): per-BLAS radius of the sphere holding every leaf box
+    RC_HIP(hipMemsetAsync(s->blas_cull_bits.p, 0, sizeof(uint32_t) * (nb ? nb : 1), s->stream));
+    if (nb && tp) hipLaunchKernelGGL(k_cull_radius, dim3(grid_for(tp)), dim3(kBlock), 0, s->stream, s->flat_prims.p, tp, s->d_descs.p, nb, s->blas_cull_bits.p);
     s->n_static_instances = n;
     if (n == 0) {  // :969-977
         s->n_tlas_nodes = 0;
@@ -870,11 +957,12 @@ void rc_build_tlas(rc_scene* s) {
         return;
     }
     reserve_build_scratch(s, n);
-    s->d_instances.reserve(n); s->inst_recs.reserve(n); s->aabb_tmp.reserve(6 * (size_t)n);
+    s->d_instances.reserve(n); s->inst_recs.reserve(n); s->inst_cull.reserve(2 * (size_t)n); s->aabb_tmp.reserve(6 * (size_t)n);
     s->tlas_nodes.reserve(2 * (size_t)n - 1);
     s->n_tlas_nodes = 2 * n - 1;
     RC_HIP(hipMemcpyAsync(s->d_instances.p, s->instances.data(), sizeof(RcInstanceDesc) * n, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p);
+    hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p,
+                       (const uint32_t*)s->blas_cull_bits.p, s->inst_cull.p);
     s->bounds_partials.reserve((size_t)grid_for(n) * 6);
     hipLaunchKernelGGL(k_instance_aabbs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, n, s->aabb_tmp.p, s->bounds_partials.p);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(384), 0, s->stream, s->bounds_partials.p, grid_for(n), s->scene_enc.p);
@@ -910,7 +998,8 @@ void rc_refit_tlas(rc_scene* s, bool from_device, bool recompute_inverse) {
     } else {
         RC_HIP(hipMemcpyAsync(s->d_instances.p, s->instances.data(), sizeof(RcInstanceDesc) * n, hipMemcpyHostToDevice, s->stream));
     }
-    hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p);
+    hipLaunchKernelGGL(k_inst_recs, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->d_instances.p, s->d_descs.p, s->d_blas_nprims.p, n, s->inst_recs.p,
+                       (const uint32_t*)s->blas_cull_bits.p, s->inst_cull.p);
     hipLaunchKernelGGL(k_tlas_leaves, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->tlas_nodes.p, (const uint32_t*)nullptr, s->d_instances.p, s->d_descs.p, n);
     run_refit(s, s->tlas_nodes.p, nullptr, n, 1, s->tlas_ranges);
     pack_tlas(s);

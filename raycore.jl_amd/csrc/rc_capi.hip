@@ -1062,6 +1062,7 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "claim_shards") { int64_t p2 = 1; while (p2 * 2 <= value && p2 * 2 <= kClaimShards) p2 *= 2; s->opt.claim_shards = p2; }  // a power of two
     else if (k == "host_pipeline") s->opt.host_pipeline = value != 0;
     else if (k == "taper") s->opt.taper = value < 0 ? 0 : (value > 64 ? 64 : value);
+    else if (k == "entry_cull") s->opt.entry_cull = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (k == "cost_order") s->opt.cost_order = value != 0;
     else if (k == "cost_thr") s->opt.cost_thr = value < 1 ? 1 : (value > 4096 ? 4096 : value);
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
@@ -1108,12 +1109,14 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     }
     else if (k == "host_pipeline") *value = s->opt.host_pipeline;
     else if (k == "taper") *value = s->opt.taper;
+    else if (k == "entry_cull") *value = s->opt.entry_cull;
     else if (k == "cost_order") *value = s->opt.cost_order;
     else if (k == "debug_order_ptr" || k == "debug_order_n" || k == "debug_ctl_ptr") {  // dev: the claim order of the most recently used launch shape
         const rc_scene::ChunkHistory* h = nullptr;
         for (const auto& e : s->histories) if (!h || e.last_use > h->last_use) h = &e;
         *value = !h ? 0 : (k == "debug_order_n" ? (int64_t)h->n_chunks : (k == "debug_ctl_ptr" ? (int64_t)(uintptr_t)h->ctl.p : (int64_t)(uintptr_t)h->order.p));
     }
+    else if (k == "debug_inst_cull_ptr") *value = (int64_t)(uintptr_t)s->inst_cull.p;  // dev: the entry-cull spheres, 2 x float4 per instance
     else if (k == "cost_thr") *value = s->opt.cost_thr;
     else if (k == "vf_chunk_bytes") *value = s->opt.vf_chunk_bytes;
     else if (k == "blas_top_k") *value = s->blas_top_k;

@@ -99,6 +99,7 @@ struct TraceOptions {
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
     int64_t host_pipeline = 1; // host-buffer trace calls of >= 1 Mi rays overlap upload / trace / download in chunks
     int64_t taper = 12;        // persistent kernels: guided chunk sizes at the end of a batch, in eighths of (chunk size x waves) still to hand out per piece (RcClaim); 0 = all chunks of `pool` items
+    int64_t entry_cull = 1;    // phased kernels: an instance whose entry-cull sphere the ray's segment misses is not entered (k_inst_recs, rc_build.hip); results never change.  1 = closest_hit and the drivers, 2 = any_hit too
     int64_t cost_order = 1;    // phased kernels: chunks that held long rays in the previous launch of the same shape (batch size, mode, stream) are claimed first (RcClaim::order)
     int64_t cost_thr = 64;     //   initial reporting threshold, in interior-loop iterations of a ray's wave while the ray was in flight (adapted from launch to launch)
     int64_t claim_shards = 16; // phased kernels: chunk counters in use (a power of two <= kClaimShards)
@@ -158,6 +159,8 @@ struct rc_scene {
     uint32_t n_tlas_nodes = 0;
     DevBuf<RcInstanceDesc> d_instances;
     DevBuf<RcInstRec> inst_recs;
+    DevBuf<uint32_t> blas_cull_bits;   // per BLAS: radius (float bits) of the sphere about the root box's centre that holds every leaf box
+    DevBuf<float4> inst_cull;          // per instance: (c_w, A), (B, -, -, -): the entry-cull sphere, k_inst_recs (rc_build.hip)
     uint32_t n_static_instances = 0;
     DevBuf<RcNode> flat_nodes;
     uint32_t n_flat_nodes = 0;

@@ -513,6 +513,7 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     rc::SceneView v;
     v.tlas_nodes = s->tlas_nodes.p; v.blas_nodes = s->flat_nodes.p; v.inst = s->inst_recs.p; v.prims = s->flat_prims.p;
     v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims; v.tlas_off = s->n_flat_nodes; v.n_nodes_total = s->n_flat_nodes + s->n_tlas_nodes; v.n_inst = s->n_static_instances;
+    v.inst_cull = (s->opt.entry_cull && s->inst_cull.p && s->n_static_instances) ? s->inst_cull.p : nullptr;
     v.overflow = s->cur_overflow; v.total_threads = total_threads;
     v.status = rc_status_word(s);
     return v;
@@ -746,6 +747,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     }
     TraceArgs a;
     a.v = rc_scene_view(s, total_threads);
+    if (any_hit && s->opt.entry_cull < 2) a.v.inst_cull = nullptr;  // any_hit rays stop at their first hit and enter few instances that a cull would spare: the test costs what it saves (shadow rays -2 %); 2 = cull there too
     a.rays = d_rays; a.hits = d_hits; a.n_rays = n;
     rc_claim_fill(s, n, total_threads / 64u, a.claim);
     a.refill = (int)s->opt.refill;

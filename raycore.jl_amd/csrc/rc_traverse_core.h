@@ -22,6 +22,7 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
     uint32_t tlas_off;        // a copy of the TLAS nodes sits at blas_nodes[tlas_off ...] (single-base addressing)
     uint32_t n_nodes_total;   // BLAS + TLAS nodes in blas_nodes (sizes the buffer descriptor)
     uint32_t n_inst;          // instance records
+    const float4* inst_cull;  // per instance (c_w, A), (B, ...): the entry-cull sphere (rc_build.hip k_inst_recs); nullptr = never skip an entry
     uint32_t* overflow;       // [kTotalStack][total_threads] spill area of the lane stacks (entries below the LDS depth unused)
     uint32_t total_threads;
     uint32_t* status;         // [0] = stack overflow flag
@@ -509,6 +510,11 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     // the node array addressed by 1-based node index: the base sits one record before element 0 (never dereferenced: index 0 is not a node)
     const __amdgpu_buffer_rsrc_t nrs1 = make_rsrc(reinterpret_cast<const char*>(av.blas_nodes) - 64, (av.n_nodes_total + 1u) * 64u);
     const __amdgpu_buffer_rsrc_t irs = make_rsrc(av.inst, av.n_inst * 64u);
+    // entry cull (k_inst_recs, rc_build.hip): per ray 1 / (d . d) -- NaN when the ray is outside the regime the cull's bounds assume, which
+    // fails every comparison below --, 1 / |d| and the ray's share of the margin
+    const bool cull_on = av.inst_cull != nullptr;
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(av.inst_cull, cull_on ? av.n_inst * 32u : 0u);
+    float c_idd = 0.f, c_idl = 0.f, c_ray = 0.f, c_dd = 0.f;
     unsigned long long pool_next = 0, pool_end = 0;
     bool exhausted = false;
     uint64_t my_ray = 0;
@@ -527,7 +533,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     const uint32_t life_thr = a.claim.cost ? __builtin_amdgcn_readfirstlane(*a.claim.life_thr_ptr) : 0xFFFFFFFFu;
     typename LaneStackP<LDS_N, BLOCK>::pos_t sp = st.empty();
     bool live = false;
-    unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0}, st_outer = 0, st_sub[4] = {0, 0, 0, 0};  // st_sub: passes with an exit lane / an entry lane / a result to write / rays to start
+    unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0}, st_outer = 0, st_sub[4] = {0, 0, 0, 0}, st_cull = 0;  // st_sub: passes with an exit lane / an entry lane / a result to write / rays to start
     unsigned long long st_t0 = STATS ? wall_clock64() : 0ull, st_tx = 0ull;
     int thr_eff = __builtin_amdgcn_readfirstlane(a.int_thr);  // wave-uniform: keeps the loop-exit compare on the scalar unit
     // TIMELINE (dev, tools/timeline_probe.py): per-wave event times and scalar counts, cheap enough not to move the schedule
@@ -617,6 +623,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             RC_MARK("leaf_end");
         }
         // ---- switch phase: return to the top level (:1996-2006) or enter an instance (:1961-1977)
+        bool was_skipped = false;
         {
             const bool is_exit = node == RC_TOP_LEVEL_SENTINEL;
             const bool is_entry = cur_inst < 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
@@ -638,6 +645,29 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 u4v m3;
                 if (TLAS_LDS) cur_inst = (int)lt[node - n_level];  // leaf of sorted instance j is node n - 1 + j; its child1 word
                 else cur_inst = (int)__builtin_amdgcn_raw_buffer_load_b32(nrs1, (cur_off + node) << 6, 52, 0);
+                bool skip = false;
+                if (cull_on) {  // does the ray's segment stay clear of the instance's entry-cull sphere?  (derivation: k_inst_recs, rc_build.hip)
+                    const float4 cs = buf_f4(crs, (uint32_t)cur_inst << 5);
+                    const float cB = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, (uint32_t)cur_inst << 5, 16, 0));
+                    const float Lx = cs.x - wo.x, Ly = cs.y - wo.y, Lz = cs.z - wo.z;
+                    const float LL = __builtin_fmaf(Lz, Lz, __builtin_fmaf(Ly, Ly, Lx * Lx));
+                    const float bq = __builtin_fmaf(Lz, wd.z, __builtin_fmaf(Ly, wd.y, Lx * wd.x));
+                    const float tc = bq * c_idd;                                  // parameter of the closest approach
+                    const float d2 = __builtin_fmaf(-4.0e-6f, LL, __builtin_fmaf(-tc, bq, LL));  // distance^2 of the line, less its own rounding
+                    // a slab test passes only for a parameter inside [tmin, closest_t] (:1853-1856): the SEGMENT has to stay clear of the
+                    // sphere, not the whole line -- instances behind the hit found so far, behind a bounce ray's origin or beyond the light
+                    const float ts = __builtin_amdgcn_fmed3f(tc, tmin, closest_t) - tc;
+                    const float seg = __builtin_fmaf(0.999f * ts * ts, c_dd, d2);
+                    const float Ae = cs.w + c_ray;
+                    const float tb = 2.0f * __builtin_fmaf(Ae, c_idl, __builtin_fabsf(tc));
+                    const float R = __builtin_fmaf(__builtin_fmaf(5.0e-6f, c_dd * c_idl, cB), tb, Ae);  // (B + 5e-6 |d|) t_bound + A + A_ray
+                    skip = seg > R * R;                                           // (any NaN or Inf on the way: false, the instance is entered)
+                }
+                if (STATS) was_skipped = skip;
+                if (skip) {
+                    cur_inst = -1;
+                    node = st.pop(sp);
+                } else {
                 if (INST_LDS) {
                     const float2* q = il + cur_inst;
                     const float2 p0 = q[0], p1 = q[kTlasLdsInst], p2 = q[2 * kTlasLdsInst], p3 = q[3 * kTlasLdsInst],
@@ -660,9 +690,11 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 oyz = v2f{o.y, o.z}; ozx = v2f{o.z, o.x}; dyz = v2f{d.y, d.z}; dzx = v2f{d.z, d.x};
                 inv = safe_inv3(d);
                 ox = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                }
                 RC_MARK("entry_end");
             }
         }
+        if (STATS) st_cull += (unsigned long long)__popcll(__ballot(was_skipped));
         // ---- finished lanes: write out; refill when enough lanes are free
         {
             RC_MARK("finish_begin");
@@ -719,6 +751,15 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         wo = mk3(r.ox, r.oy, r.oz);  // init (:1904-1927); check_direction (src/ray.jl:39-49)
                         wd = mk3(r.dx == 0.0f ? 0.0f : r.dx, r.dy == 0.0f ? 0.0f : r.dy, r.dz == 0.0f ? 0.0f : r.dz);
                         winv = safe_inv3(wd);
+                        if (cull_on) {
+                            const float dd = __builtin_fmaf(wd.z, wd.z, __builtin_fmaf(wd.y, wd.y, wd.x * wd.x));
+                            const float o1 = __builtin_fabsf(wo.x) + __builtin_fabsf(wo.y) + __builtin_fabsf(wo.z);
+                            const bool regime = dd >= 1.0e-2f && dd <= 1.0e6f && o1 < 1.0e30f;  // (false for NaN / Inf components)
+                            c_idd = regime ? __builtin_amdgcn_rcpf(dd) : __builtin_nanf("");
+                            c_idl = __builtin_amdgcn_rsqf(dd);
+                            c_dd = dd;
+                            c_ray = 8.0e-5f * o1;
+                        }
                         inv = winv;  // (o, d are the instance-local ray: set at the first instance entry)
                         ox = mk3(-wo.x * inv.x, -wo.y * inv.y, -wo.z * inv.z);
                         tmin = ANY ? 0.0f : r.tmin;
@@ -762,6 +803,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             atomicAdd(&a.stats[13], 1ull);
             atomicAdd(&a.stats[14], st_outer);  // outer iterations (one pass over the phases each)
             for (int k = 0; k < 4; ++k) atomicAdd(&a.stats[15 + k], st_sub[k]);
+            atomicAdd(&a.stats[19], st_cull);  // instance entries skipped by the entry cull (counted once per wave-pass: lane 0's copy of the wave total)
         }
     }
 }
