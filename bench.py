@@ -709,6 +709,9 @@ def main():
                                    f"{n} pinhole primary rays per GPU per step, closest_hit",
                        "scheduling": "every step traces every ray from scratch; the ORDER in which the 128-ray chunks are claimed is learned from the previous step "
                                      "(option cost_order; worth < 1 % at this batch size, 5-10 % on 1-2 M-ray batches)",
+                       "entry_cull": "on (default): an instance whose conservative sphere the ray's segment misses is not entered -- the reference's traversal of it "
+                                     "would test no triangle (DESIGN 4.1); every hit record identical with the option off (gpu_matches_bit_exact below is against the CPU oracle); "
+                                     "the roofline's VALU counters are those of this kernel, the algorithmic bytes are the reference algorithm's",
                        "triangles": int(n_tris), "rays_per_step_per_gpu": n, "hit_fraction": round(hit_frac, 4),
                        "kernel": {-1: "auto (phased persistent, top level in LDS)", 0: "simple", 1: "persistent", 2: "voted", 3: "phased", 4: "phased + top level in LDS, 1024-thread workgroups", 5: "phased + top level in LDS", 6: "phased + tops of the TLAS / BLAS in LDS"}.get(t.get_option("kernel"), "option"), "parallelism": f"replicas x{world} (rays sharded, no collective)"},
             "roofline": roofline,
