@@ -285,6 +285,17 @@ def main():
             t.set_option("kernel", -1)
             return rate
         extras["c3_two_stream_pipelined_mrays_s"] = {"kernel3": pipelined(3), "kernel5": pipelined(5)}
+        # the headline batch with the entry cull switched off (same kernel otherwise): what the cull is worth, and a bytewise comparison
+        t.set_option("entry_cull", 0)
+        dh_off = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+        best_off = 1e30
+        for _ in range(4):
+            t.trace_device(d_rays.data_ptr(), dh_off.data_ptr(), n, stream=stream.cuda_stream)
+            best_off = min(best_off, t.last_kernel_ms())
+        torch.cuda.synchronize()
+        t.set_option("entry_cull", 1)
+        extras["c3_entry_cull_off"] = {"mrays_s": round(n / best_off / 1e3, 1), "hits_identical_to_the_default_run": bool(torch.equal(dh_off, d_hits))}
+        del dh_off
         shadow = sc.c3_shadow_rays(cfg, rays, hits)
         extras["c3_any_hit_shadow_mrays_s"] = timed(t, shadow, "any")
         bounce = sc.c4_bounce_rays(cfg, rays, hits, 4 * n)
