@@ -163,3 +163,36 @@ def test_random_scenes_on_and_off(rc, oracle, seed):
     rays = sc.make_rays(org, d)
     rays["tmax"][::4] = g.uniform(0, 12, len(rays["tmax"][::4]))
     check(rc, t, o, rays, f"random scene {seed}")
+
+
+def test_inverse_supplied_by_the_caller(rc, oracle):
+    """rc_add_instances_with_inverse: the traversal applies the caller's inverse, the TLAS box comes from the forward transform -- and the two
+    need not agree.  The cull sphere is derived from the inverse (the matrix the ray really goes through), so a ray is spared the entry
+    exactly when the reference, going through the same inverse, reaches no triangle: forward boxes that cover the whole scene with
+    inverses that put the geometry somewhere else, and the other way round."""
+    sc = rc.scenes
+    g = sc.rng(4242)
+    sphere = sc.fan_sphere(16, 9, centre=(0, 0, 0), radius=0.5)
+    fwd, inv = [], []
+    for k in range(8):
+        q = np.linalg.qr(g.normal(size=(3, 3)))[0]
+        f = np.zeros((3, 4)); f[:, :3] = q * (6.0 if k % 2 else 1.0); f[:, 3] = g.uniform(-3, 3, 3) * (0 if k % 2 else 1)   # odd k: a huge forward box
+        where = g.uniform(-3, 3, 3)                                   # where the inverse says the (unit-scale, rotated) geometry is
+        q2 = np.linalg.qr(g.normal(size=(3, 3)))[0]
+        i = np.zeros((3, 4)); i[:, :3] = q2.T; i[:, 3] = -(q2.T @ where)
+        fwd.append(f.astype(np.float32).reshape(12)); inv.append(i.astype(np.float32).reshape(12))
+    fwd, inv = np.stack(fwd), np.stack(inv)
+    t = rc.TLAS(0)
+    t.add_geometry(sphere, None)
+    t.push_instances(1, fwd, np.arange(8, dtype=np.uint32), inv_transforms=inv)
+    t.sync()
+    o = oracle.Scene()
+    o.add_blas(sphere, None)
+    for k in range(8):
+        o.add_instance(1, fwd[k], k, inv=inv[k])
+    o.build()
+    nr = 60_000
+    org = g.uniform(-8, 8, size=(nr, 3)); tgt = g.uniform(-3.5, 3.5, size=(nr, 3))
+    d = tgt - org; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    want = check(rc, t, o, sc.make_rays(org, d), "caller-supplied inverses")
+    assert want["hit"].mean() > 0.02
