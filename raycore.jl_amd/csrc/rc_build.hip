@@ -598,7 +598,8 @@ __global__ void k_pack_nodes(const RcNode* src, RcNode* dst, uint32_t n, uint32_
 // k_inst_recs -- reaches no triangle of the BLAS.  Radii are >= 0: their bit patterns order like the values, and a NaN sorts above all.
 __global__ void k_cull_radius(const RcPrim* prims, uint32_t n, const RcBlasDesc* descs, uint32_t nb, uint32_t* out_bits) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const bool tail = i >= n;  // (threads past the end repeat the last primitive: every thread reaches the barriers below)
+    if (tail) i = n - 1;
     uint32_t lo = 0, hi = nb;  // the BLAS whose primitive range holds i: the last one whose offset is <= i
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (descs[mid].primitives_offset <= i) lo = mid; else hi = mid; }
     const RcBlasDesc& d = descs[lo];
@@ -612,7 +613,21 @@ __global__ void k_cull_radius(const RcPrim* prims, uint32_t n, const RcBlasDesc*
         acc += m * m;
         if (!(v[k] == v[k]) || !(v[3 + k] == v[3 + k]) || !(v[6 + k] == v[6 + k])) acc = NAN;  // (fmin / fmax drop NaNs: keep them)
     }
-    atomicMax(out_bits + lo, __float_as_uint(sqrtf(acc) * 1.000001f));
+    // one atomic per workgroup when the whole workgroup sits in one BLAS (the usual case: a 34 M-triangle BLAS would otherwise queue
+    // 34 M atomics on one address), per lane otherwise
+    const uint32_t bits = __float_as_uint(sqrtf(acc) * 1.000001f);
+    __shared__ uint32_t sh_first, sh_same, sh_max;
+    if (threadIdx.x == 0) { sh_first = lo; sh_same = 1u; sh_max = 0u; }
+    __syncthreads();
+    if (lo != sh_first) sh_same = 0u;
+    __syncthreads();
+    if (sh_same) {
+        atomicMax(&sh_max, bits);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(out_bits + lo, sh_max);
+    } else {
+        atomicMax(out_bits + lo, bits);
+    }
 }
 
 // Traversal-side instance records: inverse transform + the BLAS offsets it would otherwise chase -- and the instance's ENTRY-CULL sphere.
