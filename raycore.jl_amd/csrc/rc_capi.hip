@@ -235,6 +235,7 @@ int rc_scene_create(int device, rc_scene** out) {
         RC_HIP(hipMemsetAsync(s->counters.p, 0, sizeof(uint32_t) * (size_t)kCounterSlots * kCounterSlotWords, s->stream));
         RC_HIP(hipStreamSynchronize(s->stream));
         s->slots.assign(kCounterSlots + 1, rc_scene::LaunchSlot());
+        if (const char* e = getenv("RC_ENTRY_CULL")) s->opt.entry_cull = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);  // test campaigns: the default of option "entry_cull" for every scene of the process
     });
     if (rc != RC_OK) { delete s; return rc; }
     *out = s;
