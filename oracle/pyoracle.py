@@ -93,6 +93,8 @@ def lib():
         L.rco_view_factors.argtypes = [vp, u32, u64, u32, u32, u32, u32, vp, C.c_int]
         L.rco_view_factor_ray.argtypes = [vp, u32, u32, u64, vp]
         L.rco_view_factor_row.argtypes = [vp, u32, u64, u32, u32, u32, vp]
+        L.rco_trace_entries.restype = u32
+        L.rco_trace_entries.argtypes = [vp, vp, C.c_int, vp, vp, vp, u32]
         L.rco_trace_events.restype = u32
         L.rco_trace_events.argtypes = [vp, vp, C.c_int, vp, vp, u32]
         L.rco_hit_points.argtypes = [vp, vp, vp, u64, vp, vp]
@@ -316,6 +318,14 @@ class Scene:
         ev, dp = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
         n = lib().rco_trace_events(self._h, _p(ray), 0 if mode == "closest" else 1, _p(ev), _p(dp), cap)
         return ev[:min(n, cap)], dp[:min(n, cap)]
+
+    def trace_entries(self, ray, mode="closest", cap=512):
+        """test: (instance index, closest_t at entry, triangle tests before leaving) for every instance entry of one ray."""
+        ray = np.ascontiguousarray(ray, dtype=RAY_DT).reshape(1)
+        inst, ct, lf = np.zeros(cap, np.uint32), np.zeros(cap, np.float32), np.zeros(cap, np.uint32)
+        n = lib().rco_trace_entries(self._h, _p(ray), 0 if mode == "closest" else 1, _p(inst), _p(ct), _p(lf), cap)
+        n = min(n, cap)
+        return inst[:n], ct[:n], lf[:n]
 
     def hit_points(self, rays, hits):
         pts, nrm = np.zeros((len(rays), 3), np.float32), np.zeros((len(rays), 3), np.float32)

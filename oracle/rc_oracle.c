@@ -596,6 +596,14 @@ static __thread uint8_t* tl_ev = NULL;
 static __thread uint8_t* tl_ev_sp = NULL;
 static __thread uint32_t tl_ev_cap = 0, tl_ev_n = 0;
 #define EV_PUT(code, depth) do { if (tl_ev) { if (tl_ev_n < tl_ev_cap) { tl_ev[tl_ev_n] = (uint8_t)(code); if (tl_ev_sp) tl_ev_sp[tl_ev_n] = (uint8_t)((depth) > 255 ? 255 : (depth)); } ++tl_ev_n; } } while (0)
+/* dev / test: per instance ENTRY of one ray -- which instance, the closest_t the ray carried when it entered, and how many triangle tests
+ * (leaf visits) the reference performed before it left again.  tests/test_entry_cull_predicate.py checks the product's entry cull against
+ * this: an entry the cull would skip must have zero leaf visits. */
+typedef struct { uint32_t inst; float closest_at_entry; uint32_t leaf_tests; } rco_entry_rec;
+static __thread rco_entry_rec* tl_ent = NULL;
+static __thread uint32_t tl_ent_cap = 0, tl_ent_n = 0;
+#define ENT_BEGIN(i, t) do { if (tl_ent) { if (tl_ent_n < tl_ent_cap) { tl_ent[tl_ent_n].inst = (uint32_t)(i); tl_ent[tl_ent_n].closest_at_entry = (t); tl_ent[tl_ent_n].leaf_tests = 0; } ++tl_ent_n; } } while (0)
+#define ENT_LEAF() do { if (tl_ent && tl_ent_n > 0 && tl_ent_n <= tl_ent_cap) tl_ent[tl_ent_n - 1].leaf_tests += 1; } while (0)
 int32_t rco_max_stack(int reset) { int32_t v = g_max_sp; if (reset) g_max_sp = 0; return v; }
 
 static void set_miss(rco_hit* h) {
@@ -646,6 +654,7 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
             const rco_instance* inst = &s->inst[current_instance];
             const rco_blas_desc* desc = &s->descs[inst->blas_index - 1];
             ++n_inst;
+            ENT_BEGIN(current_instance, ray_maxt);
             current_blas_offset = desc->nodes_offset;
             ray_o = xf_point(inst->inv_transform, world_o);
             ray_d = xf_dir(inst->inv_transform, world_d);
@@ -655,6 +664,7 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
         } else {
             float t, u, v;
             ev = 3u;
+            ENT_LEAF();
             int hit = fast_intersect_triangle(ray_o, ray_d, v3_from(node->aabb0_min), v3_from(node->aabb0_max),
                                               v3_from(node->aabb1_min), ray_mint, ray_maxt, &t, &u, &v);
             if (hit) {
@@ -781,6 +791,19 @@ uint32_t rco_trace_events(const rco_scene* s, const rco_ray* r, int any, uint8_t
     return tl_ev_n;
 }
 void rco_any_hit(const rco_scene* s, const rco_ray* r, rco_hit* h, uint32_t* c) { traverse(s, r, h, c, 1); }
+/* entries of ray r (see rco_entry_rec); returns their number (may exceed cap: then only cap were stored) */
+uint32_t rco_trace_entries(const rco_scene* s, const rco_ray* r, int any, uint32_t* inst, float* closest_at_entry, uint32_t* leaf_tests, uint32_t cap) {
+    rco_hit h;
+    rco_entry_rec* rec = (rco_entry_rec*)malloc(sizeof(rco_entry_rec) * (cap ? cap : 1));
+    tl_ent = rec; tl_ent_cap = cap; tl_ent_n = 0;
+    traverse(s, r, &h, NULL, any);
+    tl_ent = NULL;
+    const uint32_t n = tl_ent_n, m = n < cap ? n : cap;
+    for (uint32_t i = 0; i < m; ++i) { inst[i] = rec[i].inst; closest_at_entry[i] = rec[i].closest_at_entry; leaf_tests[i] = rec[i].leaf_tests; }
+    free(rec);
+    return n;
+}
+
 
 void rco_brute_closest(const rco_scene* s, const rco_ray* r, rco_hit* out) {
     set_miss(out);

@@ -196,3 +196,34 @@ def test_inverse_supplied_by_the_caller(rc, oracle):
     d = tgt - org; d /= np.linalg.norm(d, axis=1, keepdims=True)
     want = check(rc, t, o, sc.make_rays(org, d), "caller-supplied inverses")
     assert want["hit"].mean() > 0.02
+
+
+def test_device_spheres_match_the_model(rc, oracle):
+    """tests/cull_model.py restates k_cull_radius / k_inst_recs in numpy; tests/test_entry_cull_predicate.py (CPU) holds that model against
+    what the reference does inside every instance.  Here: the spheres the DEVICE computed are the model's."""
+    import ctypes
+    import cull_model as cm
+    sc = rc.scenes
+    g = sc.rng(31)
+    sphere = sc.fan_sphere(16, 9, centre=(0, 0, 0), radius=0.5)
+    blob = sc.random_triangles(300, 5, lo=-0.5, hi=0.5, edge=0.4)
+    one = sc.random_triangles(1, 6, lo=-0.5, hi=0.5, edge=0.4)
+    away = (sphere.reshape(-1, 3) + np.float32([1e4, -2e3, 0])).reshape(-1, 9).astype(np.float32)
+    q = np.linalg.qr(g.normal(size=(3, 3)))[0]
+    xfs = [xform(q, 1.0, (0, 0, 0)), xform(q, 99.0, (300, 0, 0)), xform(q, 101.0, (-400, 0, 0)), xform(q, (1.0, 1.0, 1 / 16.5), (0, -5, 0)),
+           xform(q, (1.0, 1.0, 0.0), (5, 5, 0)), xform(q, 1e-6, (1, 1, 1)), xform(q @ np.diag([-1.0, 1, 1]), 0.7, (-3, 2, 1)), xform(q, (0.4, 2.0, 1.0), (2, -3, 2))]
+    cfg = {"blas": [(sphere, None), (blob, None), (one, None), (away, None)],
+           "instances": [(b + 1, np.stack(xfs), np.arange(len(xfs), dtype=np.uint32)) for b in range(4)]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    n = len(o.instances)
+    dev = np.zeros((n, 8), np.float32)
+    hip = ctypes.CDLL("libamdhip64.so")
+    t.wait_for_gpu()
+    assert hip.hipMemcpy(ctypes.c_void_p(dev.ctypes.data), ctypes.c_void_p(t.get_option("debug_inst_cull_ptr")), dev.nbytes, 2) == 0
+    model = cm.instance_spheres(o.instances, o.blas_descs, cm.blas_radii(o.blas_descs, o.blas_prims))
+    for i, (cw, A, B) in enumerate(model):
+        assert np.isinf(A) == np.isinf(dev[i, 3]), (i, A, dev[i, 3])
+        if not np.isinf(A):
+            assert np.allclose(dev[i, :3], cw, rtol=2e-6, atol=1e-6 * (1 + np.abs(cw).max())), (i, dev[i, :3], cw)
+            assert abs(dev[i, 3] - A) <= 2e-6 * A and abs(dev[i, 4] - B) <= 2e-6 * B, (i, dev[i, 3:5], A, B)
+    assert np.isinf(dev[2 * len(xfs):3 * len(xfs), 3]).all()        # the single-triangle BLAS: every instance of it
