@@ -95,6 +95,8 @@ def lib():
         L.rco_view_factor_row.argtypes = [vp, u32, u64, u32, u32, u32, vp]
         L.rco_trace_entries.restype = u32
         L.rco_trace_entries.argtypes = [vp, vp, C.c_int, vp, vp, vp, u32]
+        L.rco_trace_steps.restype = u32
+        L.rco_trace_steps.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, u32]
         L.rco_trace_events.restype = u32
         L.rco_trace_events.argtypes = [vp, vp, C.c_int, vp, vp, u32]
         L.rco_hit_points.argtypes = [vp, vp, vp, u64, vp, vp]
@@ -318,6 +320,13 @@ class Scene:
         ev, dp = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
         n = lib().rco_trace_events(self._h, _p(ray), 0 if mode == "closest" else 1, _p(ev), _p(dp), cap)
         return ev[:min(n, cap)], dp[:min(n, cap)]
+
+    def trace_steps(self, ray, mode="closest", cap=4096):
+        """dev: (events, depths, node indices, closest t at the start of each step) of one ray (tools/tlas_subtree_bound.py)."""
+        ray = np.ascontiguousarray(ray, dtype=RAY_DT).reshape(1)
+        ev, dp, nd, ct = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), np.zeros(cap, np.uint32), np.zeros(cap, np.float32)
+        n = min(lib().rco_trace_steps(self._h, _p(ray), 0 if mode == "closest" else 1, _p(ev), _p(dp), _p(nd), _p(ct), cap), cap)
+        return ev[:n], dp[:n], nd[:n], ct[:n]
 
     def trace_entries(self, ray, mode="closest", cap=512):
         """test: (instance index, closest_t at entry, triangle tests before leaving) for every instance entry of one ray."""

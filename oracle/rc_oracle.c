@@ -595,6 +595,10 @@ static int32_t g_max_sp = 0;  /* dev: deepest stack seen (single-threaded use) *
 static __thread uint8_t* tl_ev = NULL;
 static __thread uint8_t* tl_ev_sp = NULL;
 static __thread uint32_t tl_ev_cap = 0, tl_ev_n = 0;
+/* dev: with an event trace, also the node index visited by each step and the closest t the step started with (tools/tlas_subtree_bound.py) */
+static __thread uint32_t* tl_ev_node = NULL;
+static __thread float* tl_ev_ct = NULL;
+#define EV_STEP(nidx, ct) do { if (tl_ev_node && tl_ev_n < tl_ev_cap) { tl_ev_node[tl_ev_n] = (nidx); tl_ev_ct[tl_ev_n] = (ct); } } while (0)
 #define EV_PUT(code, depth) do { if (tl_ev) { if (tl_ev_n < tl_ev_cap) { tl_ev[tl_ev_n] = (uint8_t)(code); if (tl_ev_sp) tl_ev_sp[tl_ev_n] = (uint8_t)((depth) > 255 ? 255 : (depth)); } ++tl_ev_n; } } while (0)
 /* dev / test: per instance ENTRY of one ray -- which instance, the closest_t the ray carried when it entered, and how many triangle tests
  * (leaf visits) the reference performed before it left again.  tests/test_entry_cull_predicate.py checks the product's entry cull against
@@ -638,6 +642,7 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
         const rco_node* node = (current_instance < 0) ? &s->nodes[node_index - 1]
                                                       : &s->blas_nodes[current_blas_offset + node_index - 1];
         ++n_node;
+        EV_STEP(node_index, ray_maxt);
         if (g_hist_tlas) { if (current_instance < 0) g_hist_tlas[node_index - 1]++; else g_hist_blas[current_blas_offset + node_index - 1]++; }
         int is_leaf = node->child0 == RCO_INVALID_NODE;
         uint32_t ev = 0;
@@ -789,6 +794,13 @@ uint32_t rco_trace_events(const rco_scene* s, const rco_ray* r, int any, uint8_t
     traverse(s, r, &h, NULL, any);
     tl_ev = NULL; tl_ev_sp = NULL;
     return tl_ev_n;
+}
+/* dev: rco_trace_events + per step the visited node index (1-based, in its own tree) and the closest t the step started with */
+uint32_t rco_trace_steps(const rco_scene* s, const rco_ray* r, int any, uint8_t* events, uint8_t* depths, uint32_t* nodes, float* closest, uint32_t cap) {
+    tl_ev_node = nodes; tl_ev_ct = closest;
+    const uint32_t n = rco_trace_events(s, r, any, events, depths, cap);
+    tl_ev_node = NULL; tl_ev_ct = NULL;
+    return n;
 }
 void rco_any_hit(const rco_scene* s, const rco_ray* r, rco_hit* h, uint32_t* c) { traverse(s, r, h, c, 1); }
 /* entries of ray r (see rco_entry_rec); returns their number (may exceed cap: then only cap were stored) */

@@ -130,6 +130,7 @@ void rco_set_histograms(uint32_t* tlas_hist, uint32_t* blas_hist); /* dev: per-n
 /* dev: trace one ray and record one byte per loop iteration (kind | flags, see rc_oracle.c) plus the stack depth after the step;
  * returns the number of steps (only the first `cap` are stored).  Feeds tools/sched_sim.py. */
 uint32_t rco_trace_events(const rco_scene*, const rco_ray*, int any, uint8_t* events, uint8_t* depths, uint32_t cap);
+uint32_t rco_trace_steps(const rco_scene*, const rco_ray*, int any, uint8_t* events, uint8_t* depths, uint32_t* nodes, float* closest, uint32_t cap);
 /* test: the instance entries of one ray -- instance index, closest_t at entry, triangle tests before leaving (tests/test_entry_cull_predicate.py) */
 uint32_t rco_trace_entries(const rco_scene*, const rco_ray*, int any, uint32_t* inst, float* closest_at_entry, uint32_t* leaf_tests, uint32_t cap);
 int32_t rco_max_stack(int reset); /* dev: deepest traversal stack seen since the last reset (single-threaded use) */
