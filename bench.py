@@ -500,6 +500,34 @@ def main():
                             "kernel_ms_rank0": round(t5.last_kernel_ms(), 3)}
             del m
             torch.cuda.empty_cache()
+        # The per-triangle totals (column / row sums of the matrix; what the reference's users read off it) with the RAYS sharded over the
+        # ranks and ONE reduce of 2 N int64 (RCCL ncclReduce over xGMI when world > 1): no N x N array, no PCIe floor.
+        rd.view_factor_totals_distributed(t5, 4, 7)
+        best_tot, tot = 1e30, None
+        for _ in range(3):
+            fence()
+            v0 = time.perf_counter()
+            tot = rd.view_factor_totals_distributed(t5, rpt, 7)
+            fence()
+            best_tot = min(best_tot, time.perf_counter() - v0)
+        if rank == 0:
+            # the one-GPU answer, from this rank alone (40 ms): every sharded mode above must have counted exactly these rays
+            one_r, one_e = rc.view_factor_totals(t5, rpt, 7)
+            one_count = int(one_r.sum())
+            vf["one_gpu_count"] = one_count
+            vf["rccl_ranks"] = world if (use_dist and args.backend == "nccl") else 0
+            for mode in ("rows_sharded", "rows", "rays"):
+                vf[mode]["equals_one_gpu"] = vf[mode]["counted"] == one_count
+                assert vf[mode]["equals_one_gpu"], f"view_factors mode {mode} on {world} ranks counted {vf[mode]['counted']} rays, one GPU counts {one_count}"
+            assert np.array_equal(tot[0], one_r) and np.array_equal(tot[1], one_e), "rays-sharded totals differ from the one-GPU totals"
+            vf["totals_rays_sharded"] = {"seconds": round(best_tot, 4), "Mrays_s": round(n5 * rpt / best_tot / 1e6, 1), "counted": int(tot[0].sum()), "ranks": world,
+                                         "reduce_bytes": 16 * n5, "kernel_ms_rank0": round(t5.last_kernel_ms(), 3),
+                                         "note": "received[N] + emitted[N] (u64) accumulated on the device, rays sharded over the ranks, one reduce; equals the matrix's column / row sums"}
+            vf["totals_rays_sharded"]["equals_one_gpu"] = True  # (asserted above, element by element)
+        if world == 1:
+            rc.view_factor_totals(t5, 4, 7)
+            rc.view_factor_totals(t5, rpt, 7)
+            vf["totals_ms"] = round(t5.last_kernel_ms(), 3)
         # What the API returns: a HOST N x N matrix (src/kernels.jl:74-78).  One process per GPU: every rank copies its block of rows
         # into a matrix in shared memory over its own PCIe link (distributed.view_factors_host_matrix); the time includes creating and
         # faulting in the 10 GB matrix.  One GPU: rc_view_factors, row chunks traced while the finished ones travel.
@@ -582,8 +610,28 @@ def main():
             v0 = time.perf_counter(); rc.view_factors(scenes5[0], rpt, 7, out=out_m); best1 = min(best1, time.perf_counter() - v0)
         for _ in range(2):
             v0 = time.perf_counter(); rc.view_factors_multi(scenes5, rpt, 7, mode="rows", out=out_m); bestn = min(bestn, time.perf_counter() - v0)
+        import zlib
         md["view_factors_c5_host_matrix"] = {"one_device_s": round(best1, 4), "all_devices_rows_s": round(bestn, 4), "speedup": round(best1 / bestn, 2),
                                              "same_count": int(out_m.sum(dtype=np.int64)) == want, "matrix_bytes": 4 * n5 * n5}
+        assert md["view_factors_c5_host_matrix"]["same_count"], "ROWS over all devices counted different rays than one device"
+        # (1b) the per-triangle totals: rays sharded over the devices, ONE ncclReduce of 2 N u64 over xGMI (host sum for forced replicas)
+        r1, e1 = rc.view_factor_totals(scenes5[0], rpt, 7)
+        t1 = tn = 1e30
+        for _ in range(3):
+            v0 = time.perf_counter(); rc.view_factor_totals(scenes5[0], rpt, 7); t1 = min(t1, time.perf_counter() - v0)
+        rc.view_factor_totals_multi(scenes5, 4, 7)                 # communicator set-up outside the timed calls
+        for _ in range(3):
+            v0 = time.perf_counter(); rg, eg = rc.view_factor_totals_multi(scenes5, rpt, 7); tn = min(tn, time.perf_counter() - v0)
+        same = bool(np.array_equal(r1, rg) and np.array_equal(e1, eg)) and int(rg.sum()) == want
+        md["view_factor_totals_c5"] = {"one_device_s": round(t1, 4), "all_devices_rays_s": round(tn, 4), "speedup": round(t1 / tn, 2), "same_vectors": same,
+                                       "rccl_ranks": 0 if forced > 1 else len(devices), "reduce_bytes": 16 * n5,
+                                       "checksum": zlib.crc32(rg.tobytes() + eg.tobytes()), "checksum_one_device": zlib.crc32(r1.tobytes() + e1.tobytes())}
+        assert same, "view_factor_totals_multi differs from one device"
+        # (1c) RAYS on the full matrix (the 10 GB ncclReduce, < 1x by DESIGN 5's own budget) only as a correctness run on distinct devices
+        if forced <= 1:
+            v0 = time.perf_counter(); rc.view_factors_multi(scenes5, rpt, 7, mode="rays", out=out_m); tr = time.perf_counter() - v0
+            md["view_factors_c5_rays_rccl"] = {"seconds": round(tr, 4), "rccl_ranks": len(devices), "same_count": int(out_m.sum(dtype=np.int64)) == want}
+            assert md["view_factors_c5_rays_rccl"]["same_count"], "RAYS (RCCL) counted different rays than one device"
         del out_m
         for t in scenes5:
             t.free()

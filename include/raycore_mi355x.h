@@ -253,6 +253,23 @@ int rc_view_factors_rows_host(rc_scene* scene, uint32_t rays_per_triangle, uint6
 #define RC_VF_MODE_ROWS 0
 #define RC_VF_MODE_RAYS 1
 int rc_view_factors_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out_matrix, int mode);
+/* The per-triangle TOTALS of the view-factor job, without the matrix: out_received[j] = sum_i result[i, j] (the column sums -- how many
+ * rays ARRIVE at the triangles with metadata j+1; the quantity the reference's users read off the matrix,
+ * docs/src/viewfactors_content.md:62-68: sum(view(viewf_matrix, :, i))) and out_emitted[i] = sum_j result[i, j] (the row sums: counted
+ * rays that LEFT triangles with metadata i+1).  Same rays (Philox keyed by seed, ray index, source primitive) and the same counting
+ * rule as view_factors! (src/kernels.jl:93-97), so the vectors equal the sums of rc_view_factors' matrix exactly; u64, n_prims each;
+ * either pointer may be NULL.  No N x N array exists anywhere: the call costs the tracing (C5: ~40 ms), not 10 GB over PCIe.
+ * _device: rays [ray_begin, ray_end) of the sources with flat primitive indices [src_begin, src_end), ACCUMULATED into device vectors
+ *   (the shard unit of a multi-process run: torch.distributed reduce of 2 N int64).
+ * _multi: scenes[g] = synced copies of one scene on DISTINCT devices; device g shoots ray indices [g R / G, (g+1) R / G) of every
+ *   source and ONE ncclReduce (ncclUint64, sum, 2 N elements, over xGMI; librccl.so loaded on first use) brings the vectors to
+ *   scenes[0]'s device -- "rays sharded across the GPUs with an RCCL reduce of the per-triangle accumulators" (SURVEY.md 8e).  Scenes
+ *   that share a device are replicas without a communicator: their partial vectors are added on the host. */
+int rc_view_factor_totals(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint64_t* out_received, uint64_t* out_emitted);
+int rc_view_factor_totals_device(rc_scene* scene, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end,
+                                 uint32_t ray_begin, uint32_t ray_end, uint64_t* d_received, uint64_t* d_emitted, void* stream);
+int rc_view_factor_totals_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint64_t* out_received,
+                                uint64_t* out_emitted);
 /* closest_hit / any_hit over one HOST batch on several devices of one process (rays are independent -- replicas of the
  * scene, contiguous ray shards, no collective): scenes[g] is a synced copy of the same scene on device g; shard g is uploaded, traced
  * and downloaded by device g over its own PCIe link, which is what bounds a host-to-host batch (64 bytes per ray).  hits[i] is what

@@ -716,6 +716,29 @@ def view_factors_multi(accels, rays_per_triangle=10000, seed=0, mode="rows", out
     return out
 
 
+def view_factor_totals(accel, rays_per_triangle=10000, seed=0):
+    """Per-triangle totals of the view-factor job WITHOUT the N x N matrix (rc_view_factor_totals): (received, emitted), uint64 vectors of
+    length N with received[j] = sum(view_factors(...)[:, j]) -- the rays arriving at metadata j+1, what the reference's users compute from
+    the matrix (docs/src/viewfactors_content.md:62-68) -- and emitted[i] = sum(view_factors(...)[i, :]).  Costs the tracing only."""
+    t = _owner(accel)
+    n = t.n_primitives()
+    received, emitted = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    check(lib().rc_view_factor_totals(t._h, int(rays_per_triangle), int(seed), ptr(received), ptr(emitted)))
+    return received, emitted
+
+
+def view_factor_totals_multi(accels, rays_per_triangle=10000, seed=0):
+    """The same totals with the RAYS sharded over several devices of one process (rc_view_factor_totals_multi): accel g shoots ray indices
+    [g R / G, (g+1) R / G) of every source; one RCCL ncclReduce (uint64, 2 N elements) over xGMI into the first device when the accels sit
+    on distinct devices, a host sum for replicas on one device.  Identical vectors for every G."""
+    owners = [_owner(a) for a in accels]
+    n = owners[0].n_primitives()
+    received, emitted = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    handles = (C.c_void_p * len(owners))(*[o._h for o in owners])
+    check(lib().rc_view_factor_totals_multi(handles, len(owners), int(rays_per_triangle), int(seed), ptr(received), ptr(emitted)))
+    return received, emitted
+
+
 def trace_multi(accels, rays, mode="closest", out=None):
     """One host batch of rays on several devices of ONE process (rc_trace_closest_multi / rc_trace_any_multi): `accels` are synced accels
     holding the same scene, one per device; accel g uploads, traces and downloads the g-th contiguous shard of the batch over its own

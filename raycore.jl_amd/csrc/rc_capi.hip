@@ -1220,6 +1220,32 @@ int rc_view_factors_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_p
     });
 }
 
+// Per-triangle totals of the view-factor job (column sums "received", row sums "emitted") without the matrix: rc_multi.hip.
+int rc_view_factor_totals_device(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end, uint32_t ray_begin,
+                                 uint32_t ray_end, uint64_t* d_received, uint64_t* d_emitted, void* stream) {
+    if (!s || (!d_received && !d_emitted)) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        rc_launch_vf_totals(s, rays_per_triangle, seed, src_begin, src_end, ray_begin, ray_end, reinterpret_cast<unsigned long long*>(d_received),
+                            reinterpret_cast<unsigned long long*>(d_emitted), (hipStream_t)stream);
+    });
+}
+int rc_view_factor_totals_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint64_t* out_received, uint64_t* out_emitted) {
+    if (!scenes || n_scenes < 1 || (!out_received && !out_emitted)) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        check_scene_list(scenes, n_scenes, "rc_view_factor_totals_multi");
+        std::vector<rc_scene*> by_address(scenes, scenes + n_scenes);  // (lock order: see rc_view_factors_multi)
+        std::sort(by_address.begin(), by_address.end());
+        std::vector<std::unique_lock<std::mutex>> locks;
+        for (rc_scene* s : by_address) locks.emplace_back(s->host_call_mu);
+        rc_view_factor_totals_multi_impl(scenes, n_scenes, rays_per_triangle, seed, out_received, out_emitted);
+    });
+}
+int rc_view_factor_totals(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint64_t* out_received, uint64_t* out_emitted) {
+    return rc_view_factor_totals_multi(&s, 1, rays_per_triangle, seed, out_received, out_emitted);
+}
+
 static int trace_host_multi(rc_scene* const* scenes, int n_scenes, const rc_ray* rays, rc_hit* hits, uint64_t n, int any) {
     if (!scenes || n_scenes < 1) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
     return guarded([&] {

@@ -257,6 +257,56 @@ struct ViewFactorSink {
         wave_count(matrix, index, counted);
     }
 };
+// Per-triangle TOTALS of the same job (rc_view_factor_totals*): the column sums received[j] = sum_i result[i, j] -- what the reference's own
+// use of the matrix reads off it (docs/src/viewfactors_content.md:62-68: sum(view(viewf_matrix, :, i))) -- and the row sums emitted[i] = sum_j
+// result[i, j], accumulated directly: two u64 atomics per counted ray, no N x N array anywhere.  Same rays, same counting rule as
+// ViewFactorSink (:93-97); 64-bit so that N x rays_per_triangle may pass 2^32.
+struct ViewFactorTotalsSink {
+    const RcInstRec* inst;
+    const RcPrim* prims;
+    uint32_t n_prims, src_begin, n_ray;
+    unsigned long long* received;  // [n_prims] or nullptr
+    unsigned long long* emitted;   // [n_prims] or nullptr
+    __device__ inline void operator()(uint64_t w, bool hit, float, float, float, uint32_t prim, int instance) const {
+        bool counted = false;
+        uint32_t hit_meta = 1, src_meta = 1;
+        if (hit) {
+            const uint32_t src = src_begin + (uint32_t)(w / n_ray);
+            const uint4 m3 = *(reinterpret_cast<const uint4*>(inst + instance) + 3);
+            hit_meta = prims[m3.y + prim - 1u].meta; src_meta = prims[src].meta;
+            counted = hit_meta != src_meta && src_meta >= 1 && src_meta <= n_prims && hit_meta >= 1 && hit_meta <= n_prims;
+        }
+        if (received) wave_count(received, (unsigned long long)(hit_meta - 1u), counted);
+        if (emitted) wave_count(emitted, (unsigned long long)(src_meta - 1u), counted);  // lanes of one pass mostly share the source: one atomic per group
+    }
+};
+__global__ __launch_bounds__(kBlock, 6) void k_vf_totals(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t ray_begin,
+                                                          uint32_t n_ray, unsigned long long* received, unsigned long long* emitted) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    phased_trace<false, kLdsStack, false>(v, p, lds_stack, ViewFactorSource{v.prims, nullptr, k0, k1, src_begin, ray_begin, n_ray},
+                                          ViewFactorTotalsSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, received, emitted});
+}
+__global__ __launch_bounds__(kMidBlock, 6) void k_vf_totals_lds(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t ray_begin,
+                                                                 uint32_t n_ray, unsigned long long* received, unsigned long long* emitted) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LdsTop top(smem + (size_t)kMidStack * kMidBlock * 4);
+    stage_lds_top<kMidBlock>(top, v, p.blas_k, p.lds_blas_base);
+    __syncthreads();
+    phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorTotalsSink, kMidBlock, true, true>(
+        v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, nullptr, k0, k1, src_begin, ray_begin, n_ray},
+        ViewFactorTotalsSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, received, emitted}, top);
+}
+__global__ __launch_bounds__(kMidBlock, 6) void k_vf_totals_partial(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t ray_begin,
+                                                                     uint32_t n_ray, unsigned long long* received, unsigned long long* emitted) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsTop top;
+    top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
+    stage_partial_top<kMidBlock>(top.tl, v, p.tlas_k, p.blas_k, p.lds_blas_base);
+    __syncthreads();
+    phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorTotalsSink, kMidBlock, false, false, true>(
+        v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, nullptr, k0, k1, src_begin, ray_begin, n_ray},
+        ViewFactorTotalsSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, received, emitted}, top);
+}
 __global__ __launch_bounds__(kBlock, 6) void k_view_factors(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin,
                                                              uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
                                                              uint64_t col_stride, uint32_t row_offset, uint32_t flags, const uint32_t* order) {
@@ -535,6 +585,43 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     } else
     hipLaunchKernelGGL(k_view_factors, dim3(blocks), dim3(kBlock), 0, stream, v, p, (uint32_t)seed, (uint32_t)(seed >> 32), src_begin,
                        ray_begin, ray_end - ray_begin, d_matrix, row_stride, col_stride, row_offset, flags, order);
+    launch.finish();
+}
+
+// Totals of rays [ray_begin, ray_end) of the sources with flat indices [src_begin, src_end), ACCUMULATED into d_received / d_emitted
+// (n_prims u64 each, device; either may be nullptr).
+void rc_launch_vf_totals(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end, uint32_t ray_begin,
+                         uint32_t ray_end, unsigned long long* d_received, unsigned long long* d_emitted, hipStream_t stream) {
+    if (src_end > s->n_flat_prims) src_end = s->n_flat_prims;
+    if (ray_end > rays_per_triangle) ray_end = rays_per_triangle;
+    if (src_begin >= src_end || ray_begin >= ray_end || (!d_received && !d_emitted)) return;
+    check_buffer_range(s);
+    const uint64_t total = (uint64_t)(src_end - src_begin) * (ray_end - ray_begin);
+    RcLaunchGuard launch(s, stream);
+    const bool partial = rc_partial_driver_ok(s);
+    const bool lds = partial || rc_lds_driver_ok(s);
+    const uint32_t bs = lds ? (uint32_t)kMidBlock : (uint32_t)kBlock;
+    const uint32_t blocks = lds ? rc_lds_driver_blocks(s, total) : rc_persistent_blocks(s, total);
+    SceneView v = rc_scene_view(s, blocks * bs);
+    PersistArgs p = rc_persist_args(s, total, blocks * bs);
+    launch.start();
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), n_ray = ray_end - ray_begin;
+    if (partial) {
+        rc_partial_driver_args(s, p);
+        if (!s->lds_attr_set[11]) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vf_totals_partial), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartialLdsBytes));
+            s->lds_attr_set[11] = true;
+        }
+        hipLaunchKernelGGL(k_vf_totals_partial, dim3(blocks), dim3(kMidBlock), kPartialLdsBytes, stream, v, p, k0, k1, src_begin, ray_begin, n_ray, d_received, d_emitted);
+    } else if (lds) {
+        rc_lds_driver_args(s, p);
+        if (!s->lds_attr_set[10]) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vf_totals_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
+            s->lds_attr_set[10] = true;
+        }
+        hipLaunchKernelGGL(k_vf_totals_lds, dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, v, p, k0, k1, src_begin, ray_begin, n_ray, d_received, d_emitted);
+    } else
+    hipLaunchKernelGGL(k_vf_totals, dim3(blocks), dim3(kBlock), 0, stream, v, p, k0, k1, src_begin, ray_begin, n_ray, d_received, d_emitted);
     launch.finish();
 }
 

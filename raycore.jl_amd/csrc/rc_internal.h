@@ -230,6 +230,7 @@ struct rc_scene {
     std::mutex host_call_mu;          // the other host-buffer entry points (illumination, view factors, collisions, exports) run one at a time
 
     DevBuf<float> f32_stage;
+    DevBuf<unsigned long long> u64_stage;  // view-factor totals: received[N] then emitted[N] (rc_multi.hip)
     DevBuf<float> vert_stage;
     DevBuf<uint32_t> meta_stage;
     DevBuf<uint32_t> c4_tasks_a, c4_tasks_b, c4_gather, c4_totals;  // BVH4 collapse scratch (rc_bvh4.hip)
@@ -245,7 +246,7 @@ struct rc_scene {
     DevBuf<uint32_t> collide_counts;  // collide_instances' per-leaf counts / prefix sums (the reference's `cache`)
     DevBuf<uint2> contact_stage;
 
-    bool lds_attr_set[10] = {};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any), illumination, view factors, [6, 7] kernel 6, [8, 9] the partial-LDS drivers
+    bool lds_attr_set[12] = {};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any), illumination, view factors, [6, 7] kernel 6, [8, 9] the partial-LDS drivers, [10, 11] view-factor totals
 
     TraceOptions opt;
 };
@@ -335,6 +336,9 @@ uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items);
 void rc_ensure_vf_order(rc_scene* s);  // builds vf_order / vf_meta_sorted if the scene has been rebuilt since
 void rc_vf_source_range(rc_scene* s, uint32_t row_begin, uint32_t row_end, uint32_t& pos_begin, uint32_t& pos_end);  // positions in the metadata order whose metadata - 1 is in [row_begin, row_end)
 // rc_multi.hip
+void rc_launch_vf_totals(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end, uint32_t ray_begin,
+                         uint32_t ray_end, unsigned long long* d_received, unsigned long long* d_emitted, hipStream_t stream);
+void rc_view_factor_totals_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint64_t* out_received, uint64_t* out_emitted);
 float rc_view_factors_rows_to_host(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t row_begin, uint32_t row_end, uint32_t* out, uint64_t ld);
 void rc_view_factors_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out, int mode);
 struct rc_ray;  // include/raycore_mi355x.h (same 32 bytes as RcRay / RcHit)

@@ -169,7 +169,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
-constexpr int kNcclUint32 = 3, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
+constexpr int kNcclUint32 = 3, kNcclUint64 = 5, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
 std::mutex g_rccl_mu;
 Rccl g_rccl;
 std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;  // one communicator set per device list, kept for the life of the process
@@ -192,6 +192,25 @@ Rccl& rccl() {
 }
 void nccl_ok(int rc, const char* what) {
     if (rc != 0) throw RcError(RC_ERR_HIP, std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+}
+
+// The communicator set of a device list (rank g = devs[g]), created on first use and kept for the life of the process.
+std::vector<ncclComm_t> comms_for(const std::vector<int>& devs) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    Rccl& r = rccl();
+    auto it = g_comms.find(devs);
+    if (it == g_comms.end()) {
+        std::vector<ncclComm_t> fresh(devs.size());
+        nccl_ok(r.CommInitAll(fresh.data(), (int)devs.size(), devs.data()), "ncclCommInitAll");
+        it = g_comms.emplace(devs, fresh).first;
+    }
+    return it->second;
+}
+bool distinct_devices(rc_scene* const* scenes, int n) {
+    std::vector<int> d(n);
+    for (int g = 0; g < n; ++g) d[g] = scenes[g]->device;
+    std::sort(d.begin(), d.end());
+    return std::adjacent_find(d.begin(), d.end()) == d.end();
 }
 
 void check_same_geometry(rc_scene* const* scenes, int n) {
@@ -250,18 +269,7 @@ static void multi_rays(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_
         if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
             throw RcError(RC_ERR_INVALID_ARGUMENT, "RC_VF_MODE_RAYS reduces over RCCL, which needs one DISTINCT device per scene (use RC_VF_MODE_ROWS for several scenes on one device)");
     }
-    std::vector<ncclComm_t> comms;
-    {
-        std::lock_guard<std::mutex> lk(g_rccl_mu);
-        Rccl& r = rccl();
-        auto it = g_comms.find(devs);
-        if (it == g_comms.end()) {
-            std::vector<ncclComm_t> fresh(n_scenes);
-            nccl_ok(r.CommInitAll(fresh.data(), n_scenes, devs.data()), "ncclCommInitAll");
-            it = g_comms.emplace(devs, fresh).first;
-        }
-        comms = it->second;
-    }
+    const std::vector<ncclComm_t> comms = comms_for(devs);
     const uint32_t C = chunk_rows_for(scenes[0], n, n), n_chunks = (n + C - 1) / C;
     std::vector<DeviceJob> jobs(n_scenes);
     std::vector<DevBuf<uint32_t>> acc(n_scenes);
@@ -348,6 +356,75 @@ void rc_view_factors_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t 
     populate_parallel(out, n * n * 4u);
     if (mode == RC_VF_MODE_ROWS) multi_rows(scenes, n_scenes, rays_per_triangle, seed, out);
     else multi_rays(scenes, n_scenes, rays_per_triangle, seed, out);
+}
+
+// ---- per-triangle totals: the partition under which "rays sharded + RCCL reduce of the per-triangle accumulators" scales ---------------
+// What the reference's users read off the matrix are its per-triangle sums (docs/src/viewfactors_content.md:62-68: the column sums,
+// "rays that arrive at triangle i").  Those can be accumulated directly: device g shoots ray indices [g R / G, (g + 1) R / G) of EVERY
+// source into two N-vectors of u64 (received = column sums, emitted = row sums; ViewFactorTotalsSink), and ONE ncclReduce(sum,
+// ncclUint64, 2 N elements -- 0.8 MB at C5) over xGMI brings them to scenes[0]'s device.  No N x N array exists on any device or on the
+// host, so neither the 10 GB of PCIe traffic nor its zero fill bound the call: 1 / G of the tracing + one small collective.  Scenes that
+// share a device (replicas) cannot form an RCCL communicator; their partial vectors are added on the host instead.
+void rc_view_factor_totals_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint64_t* out_received, uint64_t* out_emitted) {
+    if (n_scenes < 1 || !scenes) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_view_factor_totals_multi: no scenes");
+    check_same_geometry(scenes, n_scenes);
+    const uint32_t n = scenes[0]->n_flat_prims;
+    if (n == 0) return;
+    struct DeviceRestore { int dev = 0; DeviceRestore() { (void)hipGetDevice(&dev); } ~DeviceRestore() { (void)hipSetDevice(dev); } } restore;
+    const bool use_rccl = n_scenes > 1 && distinct_devices(scenes, n_scenes);
+    std::vector<int> devs(n_scenes);
+    for (int g = 0; g < n_scenes; ++g) devs[g] = scenes[g]->device;
+    std::vector<ncclComm_t> comms;
+    if (use_rccl) comms = comms_for(devs);
+    std::vector<hipStream_t> stream(n_scenes, nullptr);
+    hipEvent_t t_begin = nullptr, t_end = nullptr;
+    RC_HIP(hipSetDevice(scenes[0]->device));
+    RC_HIP(hipEventCreate(&t_begin));
+    RC_HIP(hipEventCreate(&t_end));
+    struct EventPair { int dev; hipEvent_t& a; hipEvent_t& b; ~EventPair() { (void)hipSetDevice(dev); if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev_guard{scenes[0]->device, t_begin, t_end};
+    // trace: one host thread per device (allocation and launch set-up of G devices side by side); everything is enqueued, nothing waited for
+    for_each_scene(scenes, n_scenes, [&](int g) {
+        rc_scene* s = scenes[g];
+        RC_HIP(hipSetDevice(s->device));
+        for (auto& a : s->aux_streams) if (!a) RC_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        stream[g] = s->aux_streams[0];
+        s->u64_stage.reserve((size_t)2 * n);
+        if (g == 0) RC_HIP(hipEventRecord(t_begin, stream[g]));
+        RC_HIP(hipMemsetAsync(s->u64_stage.p, 0, sizeof(unsigned long long) * 2u * n, stream[g]));
+        const uint32_t q0 = (uint32_t)((uint64_t)rays_per_triangle * g / n_scenes), q1 = (uint32_t)((uint64_t)rays_per_triangle * (g + 1) / n_scenes);
+        rc_launch_vf_totals(s, rays_per_triangle, seed, 0, n, q0, q1, s->u64_stage.p, s->u64_stage.p + n, stream[g]);
+    });
+    std::vector<uint64_t> total((size_t)2 * n, 0);
+    if (use_rccl) {  // stream-ordered behind each device's trace: RCCL itself waits for the slowest rank
+        Rccl& r = rccl();
+        nccl_ok(r.GroupStart(), "ncclGroupStart");
+        for (int g = 0; g < n_scenes; ++g)
+            nccl_ok(r.Reduce(scenes[g]->u64_stage.p, scenes[g]->u64_stage.p, (size_t)2 * n, kNcclUint64, kNcclSum, 0, comms[g], stream[g]), "ncclReduce");
+        nccl_ok(r.GroupEnd(), "ncclGroupEnd");
+    }
+    RC_HIP(hipSetDevice(scenes[0]->device));
+    if (use_rccl || n_scenes == 1) {
+        RC_HIP(hipEventRecord(t_end, stream[0]));
+        RC_HIP(hipMemcpyAsync(total.data(), scenes[0]->u64_stage.p, sizeof(uint64_t) * 2u * n, hipMemcpyDeviceToHost, stream[0]));
+        for (int g = n_scenes - 1; g >= 0; --g) { RC_HIP(hipSetDevice(scenes[g]->device)); RC_HIP(hipStreamSynchronize(stream[g])); status_check(scenes[g]); }
+    } else {
+        std::vector<uint64_t> part((size_t)2 * n);
+        for (int g = 0; g < n_scenes; ++g) {
+            RC_HIP(hipSetDevice(scenes[g]->device));
+            RC_HIP(hipMemcpyAsync(part.data(), scenes[g]->u64_stage.p, sizeof(uint64_t) * 2u * n, hipMemcpyDeviceToHost, stream[g]));
+            RC_HIP(hipStreamSynchronize(stream[g]));
+            status_check(scenes[g]);
+            for (size_t i = 0; i < total.size(); ++i) total[i] += part[i];
+        }
+        RC_HIP(hipSetDevice(scenes[0]->device));
+        RC_HIP(hipEventRecord(t_end, stream[0]));  // every device's share is home: first launch to here, on device 0's clock
+    }
+    if (out_received) memcpy(out_received, total.data(), sizeof(uint64_t) * n);
+    if (out_emitted) memcpy(out_emitted, total.data() + n, sizeof(uint64_t) * n);
+    RC_HIP(hipSetDevice(scenes[0]->device));
+    RC_HIP(hipEventSynchronize(t_end));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t_begin, t_end) == hipSuccess) rc_timing_fixed(scenes[0], ms); else (void)hipGetLastError();
 }
 
 // closest_hit / any_hit over one host batch on several devices (rays are independent units -- replicas of the scene, the

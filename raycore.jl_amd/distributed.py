@@ -148,6 +148,44 @@ def view_factors_distributed(tlas, rays_per_triangle=10000, seed=0, mode="rows",
     return local.view(n, n) if me == dst else None
 
 
+def _gpu_view_factor_totals(tlas, rays_per_triangle, seed):
+    def compute(local, src, rays):
+        import torch
+        n = local.numel() // 2
+        base = local.data_ptr()
+        check(lib().rc_view_factor_totals_device(tlas._h, int(rays_per_triangle), int(seed), src[0], src[1], rays[0], rays[1], ptr(base), ptr(base + 8 * n),
+                                                 ptr(torch.cuda.current_stream().cuda_stream) or None))
+    return compute
+
+
+def view_factor_totals_distributed(tlas, rays_per_triangle=10000, seed=0, group=None, dst=0, n_prims=None, compute=None, device=None):
+    """The per-triangle totals of view_factors -- received[j] = column sum j, emitted[i] = row sum i of the N x N matrix, the quantities the
+    reference's users read off it (docs/src/viewfactors_content.md:62-68) -- with the RAYS sharded over the ranks of `group`: rank r shoots
+    ray indices shard_range(rays_per_triangle, r, world) of every source into ONE int64 tensor of 2 N elements (received | emitted) and a
+    single dist.reduce (ncclReduce over xGMI under backend "nccl" = RCCL; 0.8 MB at C5) sums them on global rank `dst`.  No N x N array on
+    any rank.  Returns (received, emitted) as uint64 numpy vectors on `dst`, None elsewhere.  `compute(local, (s0, s1), (r0, r1))` must
+    ACCUMULATE the totals of those sources / rays into `local`; the default launches the HIP kernel through the C ABI."""
+    import torch
+    dist = _dist()
+    world, rank, me = _ranks(group)
+    n = int(n_prims if n_prims is not None else tlas.n_primitives())
+    rpt = int(rays_per_triangle)
+    if device is None:
+        device = torch.device("cuda", tlas.device)
+    if compute is None:
+        compute = _gpu_view_factor_totals(tlas, rpt, seed)
+    local = torch.zeros(2 * n, dtype=torch.int64, device=device)
+    r0, r1 = shard_range(rpt, rank, world)
+    if r1 > r0:
+        compute(local, (0, n), (r0, r1))
+    if world > 1:
+        dist.reduce(local, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if me != dst:
+        return None
+    host = local.cpu().numpy().view(np.uint64)
+    return host[:n].copy(), host[n:].copy()
+
+
 def _populate(base, byte_range, n_threads):
     """MADV_POPULATE_WRITE (Linux 5.14+) over [base + a, base + b), page aligned, split over n_threads; best effort."""
     import ctypes

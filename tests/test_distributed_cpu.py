@@ -80,6 +80,18 @@ def _worker(rank, world, port, mode, q, variant="plain"):
                 again = rd.view_factors_host_matrix(None, rpt, seed, n_prims=n, compute_rows=compute_rows, out=shared)
             assert (again is None) == (out is None) and (again is None or again is shared.array)
             res = None if out is None else (first, np.array(again))
+        elif mode == "totals":
+            def compute_totals(local, src, rays):
+                """Stand-in for rc_view_factor_totals_device: received[hit_meta - 1] and emitted[src_meta - 1] of the oracle's rays."""
+                acc = local.numpy().view(np.uint64)
+                for prim in range(src[0], src[1]):
+                    if not (1 <= meta[prim] <= n):
+                        continue
+                    row = o.view_factor_row(rpt, int(prim), seed=seed, rays=rays).astype(np.uint64)
+                    acc[:n] += row
+                    acc[n + meta[prim] - 1] += row.sum()
+            out = rd.view_factor_totals_distributed(None, rpt, seed, n_prims=n, compute=compute_totals, device=torch.device("cpu"), group=group, dst=dst)
+            res = None if out is None else (out[0].copy(), out[1].copy())
         elif mode == "rows_sharded":
             block, rows = rd.view_factors_distributed(None, rpt, seed, mode=mode, n_prims=n, compute=compute, device=torch.device("cpu"), prim_meta=meta)
             res = (block.numpy().view(np.uint32).copy(), rows)
@@ -165,6 +177,23 @@ def test_subgroup_uses_group_ranks_for_shards_and_a_global_rank_for_dst(oracle, 
     o, n = _scene(oracle, rc)
     assert results[0] == "not in the group" and results[1] is None
     assert np.array_equal(results[2], o.view_factors(64, seed=99))
+
+
+@pytest.mark.parametrize("variant,world", [("plain", 2), ("dup", 2), ("subgroup", 3)])
+def test_view_factor_totals_rays_sharded_one_reduce(oracle, variant, world):
+    """view_factor_totals_distributed: every rank shoots its share of the ray indices of EVERY source into a 2 N vector, one reduce to
+    dst; the result is the column / row sums of the single-process matrix -- also for metadata with duplicates and an out-of-range id,
+    and for a sub-group whose dst is a global rank."""
+    import raycore_jl_amd as rc
+    results = _run(world, "totals", variant, 40 + {"plain": 0, "dup": 1, "subgroup": 2}[variant])
+    o, n = _scene(oracle, rc, dup_meta=(variant == "dup"))
+    want = o.view_factors(64, seed=99)
+    dst = 2 if variant == "subgroup" else 0
+    for r, res in results.items():
+        if r != dst:
+            assert res is None or res == "not in the group"
+    recv, emit = results[dst]
+    assert np.array_equal(recv, want.sum(axis=0, dtype=np.uint64)) and np.array_equal(emit, want.sum(axis=1, dtype=np.uint64)) and recv.sum() > 0
 
 
 def test_bench_launches_its_own_ranks():
