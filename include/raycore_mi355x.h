@@ -187,7 +187,8 @@ int rc_trace_any_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, u
  * chunks that held long-lived rays in the previous launch of the same batch size, mode and stream are claimed first; default 1),
  * "cost_thr" (its initial reporting threshold), "entry_cull" (1 = an instance whose conservative sphere the ray's segment misses is
  * not entered: the reference's traversal of it would test no triangle; 0 = off, 1 = closest_hit and the drivers (default),
- * 2 = any_hit batches too), "vf_chunk_bytes" (device block per row chunk of the host-matrix view factors),
+ * 2 = any_hit batches too), "vf_chunk_bytes" (device block per row chunk of the host-matrix view factors), "vf_first_touch" (ROWS on several devices: each device's
+ * host thread joins the device's NUMA node and faults in its own row block; default 1),
  * "blas_top" (1 = a scene with a single BLAS keeps that BLAS's top internal
  * nodes in LDS; takes effect at the next structural rc_sync), "onesweep_min" (key count from which
  * the builds sort with Onesweep radix passes instead of a merge sort), "stats" (dev counters),

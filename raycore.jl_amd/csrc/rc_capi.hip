@@ -986,7 +986,8 @@ int rc_scene_load(int device, const char* path, rc_scene** out) {
             if (b.n_prims == 0 || b.n_nodes != 2 * b.n_prims - 1) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene file: inconsistent geometry header");
             get(fc.f, b.root_min, 12);
             get(fc.f, b.root_max, 12);
-            get_dev(fc.f, b.prims, b.n_prims, tmp);
+            std::vector<RcPrim> host_prims;
+            get_dev(fc.f, b.prims, b.n_prims, tmp, [&](const RcPrim* p) { host_prims.assign(p, p + b.n_prims); });
             get_dev(fc.f, b.nodes, b.n_nodes, tmp, [&](const RcNode* nd) {  // internal nodes 1..n-1 point at nodes, leaves n..2n-1 at a sorted primitive
                 // The links must form a TREE: a traversal pushes one child and descends into the other, so a node that points at
                 // itself or at an ancestor would make a ray loop for ever (the lane stack stops growing at 128 entries, the descent
@@ -1006,6 +1007,32 @@ int rc_scene_load(int device, const char* path, rc_scene** out) {
                 if (refs[0] != 0) bad_file("node links do not form a tree (the root is somebody's child)");
                 for (uint32_t i = 1; i < b.n_nodes; ++i)
                     if (refs[i] != 1) bad_file("node links do not form a tree (an unreferenced node)");
+                // The NODES are what a ray meets, the primitive array is what the entry cull's spheres and the epilogues are derived from
+                // (ADVICE r3): a file whose leaves carry other vertices than its primitives, or whose boxes are not the refit's boxes (a
+                // leaf's box = min / max of its three vertices, an interior child's = the union of that child's two boxes), would make
+                // "no option changes a result" false.  min / max are exact, so a file written by rc_scene_save matches bit for bit
+                // (NaN components compare as equal to NaN).
+                auto same = [](float a, float c) { return memcmp(&a, &c, 4) == 0 || (a != a && c != c); };
+                for (uint32_t i = b.n_prims - 1; i < b.n_nodes; ++i) {  // the leaves
+                    const RcPrim& pr = host_prims[nd[i].child1 - 1];
+                    for (int k = 0; k < 9; ++k) if (!same(nd[i].f[k], pr.v[k])) bad_file("a leaf node's vertices differ from the primitive it names");
+                }
+                for (uint32_t i = 0; i + 1 < b.n_prims; ++i) {  // the interior nodes
+                    for (int side = 0; side < 2; ++side) {
+                        const RcNode& ch = nd[(side ? nd[i].child1 : nd[i].child0) - 1];
+                        float3_ lo, hi;
+                        if (ch.child0 == RC_INVALID_NODE) {
+                            const float3_ v0 = mk3(ch.f[0], ch.f[1], ch.f[2]), v1 = mk3(ch.f[3], ch.f[4], ch.f[5]), v2 = mk3(ch.f[6], ch.f[7], ch.f[8]);
+                            lo = min3v(min3v(v0, v1), v2); hi = max3v(max3v(v0, v1), v2);
+                        } else {
+                            lo = min3v(mk3(ch.f[0], ch.f[1], ch.f[2]), mk3(ch.f[6], ch.f[7], ch.f[8]));
+                            hi = max3v(mk3(ch.f[3], ch.f[4], ch.f[5]), mk3(ch.f[9], ch.f[10], ch.f[11]));
+                        }
+                        const float* box = nd[i].f + 6 * side;
+                        if (!same(box[0], lo.x) || !same(box[1], lo.y) || !same(box[2], lo.z) || !same(box[3], hi.x) || !same(box[4], hi.y) || !same(box[5], hi.z))
+                            bad_file("a node's child box is not the box of that child (the tree was not refitted from these vertices)");
+                    }
+                }
             });
             if (b.has_attrs) {
                 get_dev(fc.f, b.m_normals, 3 * (size_t)b.n_mesh_verts, tmp);
@@ -1067,6 +1094,15 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "cost_order") s->opt.cost_order = value != 0;
     else if (k == "cost_thr") s->opt.cost_thr = value < 1 ? 1 : (value > 4096 ? 4096 : value);
     else if (k == "sched_thr") s->opt.sched_thr = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (k == "vf_first_touch") s->opt.vf_first_touch = value ? 1 : 0;
+    else if (k == "release_captures") {  // the caller's hipGraphs that captured launches of this scene are destroyed: free their spill regions, hand their counter slots out again
+        if (value) {
+            (void)hipSetDevice(s->device);
+            std::lock_guard<std::mutex> g(s->launch_mu);
+            s->capture_regions.clear();
+            s->graph_seq = 0;
+        }
+    }
     else if (k == "vf_chunk_bytes") s->opt.vf_chunk_bytes = value < 4096 ? 4096 : (value > (int64_t(4) << 30) ? (int64_t(4) << 30) : value);
     else if (k == "timeline_ptr") s->opt.timeline_ptr = value;  // dev instrumentation: the caller owns the buffer and its size (8 x u64 per wave of the launch)
     else if (k == "debug_set_overflow") {  // test hook: raise the sticky stack-overflow word as a kernel would (no LBVH is deep enough to do it for real)
@@ -1119,6 +1155,8 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     }
     else if (k == "debug_inst_cull_ptr") *value = (int64_t)(uintptr_t)s->inst_cull.p;  // dev: the entry-cull spheres, 2 x float4 per instance
     else if (k == "cost_thr") *value = s->opt.cost_thr;
+    else if (k == "vf_first_touch") *value = s->opt.vf_first_touch;
+    else if (k == "release_captures") { std::lock_guard<std::mutex> g(s->launch_mu); *value = (int64_t)s->graph_seq; }  // captured launches currently holding a region and a slot
     else if (k == "vf_chunk_bytes") *value = s->opt.vf_chunk_bytes;
     else if (k == "blas_top_k") *value = s->blas_top_k;
     else if (k == "tlas_top_k") *value = s->tlas_top_k;

@@ -103,6 +103,7 @@ struct TraceOptions {
     int64_t cost_order = 1;    // phased kernels: chunks that held long rays in the previous launch of the same shape (batch size, mode, stream) are claimed first (RcClaim::order)
     int64_t cost_thr = 64;     //   initial reporting threshold, in interior-loop iterations of a ray's wave while the ray was in flight (adapted from launch to launch)
     int64_t claim_shards = 16; // phased kernels: chunk counters in use (a power of two <= kClaimShards)
+    int64_t vf_first_touch = 1;          // ROWS on several devices: each device's host thread joins the device's NUMA node and faults in its own row block (rc_multi.hip)
     int64_t vf_chunk_bytes = 192 << 20;  // host-matrix view factors (rc_multi.hip): device block per row chunk -- large enough for full-rate launches and 2-D copies, small enough that the exposed first trace / last copy are a few ms
     int64_t timeline_ptr = 0;  // dev: device address of 8 x u64 per wave (n_cus x 24 waves) that kernel 5 fills with its waves' event times; 0 = off
 };
@@ -188,15 +189,16 @@ struct rc_scene {
     std::mutex launch_mu;
     // global spill areas of the traversal stacks: one per stream that has launched on this scene (launches on one stream are
     // ordered and share theirs; launches on different streams may overlap and must not), at most kMaxOverflowRegions (a ninth stream
-    // waits for the oldest unpinned region's stream and takes it over).  A region used by a launch that was captured into a hipGraph is
-    // pinned: the graph keeps its address.
+    // takes over the region of an idle stream, or waits for the oldest).  Launches CAPTURED into a hipGraph never use these: each owns a
+    // region of its own (capture_regions).
     static constexpr int kMaxOverflowRegions = 8;  // each is allocated on first use by a new stream
-    struct OverflowRegion { hipStream_t stream = nullptr; bool pinned = false; DevBuf<uint32_t> buf; };
+    struct OverflowRegion { hipStream_t stream = nullptr; DevBuf<uint32_t> buf; };
     std::vector<OverflowRegion> overflow_regions;
+    std::vector<std::unique_ptr<DevBuf<uint32_t>>> capture_regions;  // one per CAPTURED launch (graph_seq of them): a graph bakes the address in
     uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared
     DevBuf<uint32_t> counters;        // kCounterSlots slots of claim counters (self-resetting, rc_claim_chunk), the sticky status word, dev statistics; zeroed at rc_scene_create
     uint64_t launch_seq = 0;          // eager launches so far; slot = launch_seq % kEagerSlots
-    uint64_t graph_seq = 0;           // captured launches so far; slot = kEagerSlots + graph_seq % (kCounterSlots - kEagerSlots)
+    uint64_t graph_seq = 0;           // captured launches holding a slot and a spill region; slot = kEagerSlots + its number (option "release_captures" resets)
     int cur_slot = 0;                 // slot of the launch being prepared
     struct LaunchSlot {               // per counter slot: the events of its latest launch
         hipEvent_t t0 = nullptr, t1 = nullptr;  // timing pair; t1 also orders the slot's next user when that one runs on another stream
@@ -216,6 +218,10 @@ struct rc_scene {
         uint64_t last_use = 0;
     };
     static constexpr int kMaxHistories = 8;
+    static constexpr int kRecentShapes = 16;
+    struct ShapeKey { uint32_t n_chunks = 0, pool = 0; int any = 0; hipStream_t stream = nullptr; };
+    std::vector<ShapeKey> recent_shapes;  // shapes launched lately without a history entry: one that comes back may take over an entry
+    uint64_t recent_clock = 0;
     std::vector<ChunkHistory> histories;
     uint64_t history_clock = 0;
 

@@ -17,6 +17,7 @@
 // Philox is keyed by (seed; ray index, source primitive), so every partition produces the same matrix bit for bit.
 // Reference: src/kernels.jl:74-104; SURVEY.md 8b / 8e.
 #include <dlfcn.h>
+#include <sched.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -49,6 +50,51 @@ void populate_parallel(void* p, size_t bytes) {
         th.emplace_back([=] { (void)madvise(reinterpret_cast<void*>(a + off), len, MADV_POPULATE_WRITE); });
     }
     for (auto& t : th) t.join();
+}
+
+// Several devices, ROWS: device g's thread owns rows [r0, r1) of a column-major matrix = one piece of (r1 - r0) * 4 bytes per column.
+// First touch decides which NUMA node a fresh page lands on, and the device's DMA writes should land on the socket its PCIe root hangs
+// off: the thread moves itself to the CPUs of the device's NUMA node (sysfs, best effort: containers often hide it) and faults in ITS
+// pieces -- no numactl, no policy calls, the kernel's default first-touch placement does the rest.  Pieces shorter than two pages are
+// left to the copies (neighbouring devices share those pages anyway).
+void adopt_device_numa_node(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0) return;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) { fclose(f); return; }
+    int a = 0, b = 0;
+    char sep = ',';
+    while (fscanf(f, "%d", &a) == 1) {  // "0-63,128-191"
+        b = a;
+        int ch = fgetc(f);
+        if (ch == '-') { if (fscanf(f, "%d", &b) != 1) break; ch = fgetc(f); }
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) CPU_SET(c, &want);
+        sep = (char)ch;
+        if (sep != ',') break;
+    }
+    fclose(f);
+    if (CPU_COUNT(&want) > 0) (void)sched_setaffinity(0, sizeof want, &want);  // this thread only (it ends with the job)
+}
+void populate_row_block(uint32_t* out, uint64_t ld, uint32_t n_cols, uint32_t r0, uint32_t r1) {
+    const uintptr_t page = 4096;
+    if ((uint64_t)(r1 - r0) * 4u < 2 * page) return;
+    for (uint32_t c = 0; c < n_cols; ++c) {
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(out + r0 + ld * c) + page - 1) & ~(page - 1), b = reinterpret_cast<uintptr_t>(out + r1 + ld * c) & ~(page - 1);
+        if (b > a && madvise(reinterpret_cast<void*>(a), b - a, MADV_POPULATE_WRITE) != 0) return;  // old kernel: the copies fault the pages in
+    }
 }
 
 uint32_t chunk_rows_for(rc_scene* s, uint32_t n_cols, uint32_t rows) {  // option "vf_chunk_bytes"
@@ -251,6 +297,10 @@ static void multi_rows(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_
     std::vector<float> ms(n_scenes, 0.f);
     for_each_scene(scenes, n_scenes, [&](int g) {
         const uint32_t r0 = (uint32_t)((uint64_t)n * g / n_scenes), r1 = (uint32_t)((uint64_t)n * (g + 1) / n_scenes);
+        if (n_scenes > 1 && scenes[g]->opt.vf_first_touch) {
+            adopt_device_numa_node(scenes[g]->device);
+            populate_row_block(out, n, n, r0, r1);
+        }
         ms[g] = rc_view_factors_rows_to_host(scenes[g], rays_per_triangle, seed, r0, r1, out, n);
     });
     for (int g = n_scenes - 1; g >= 0; --g) rc_timing_fixed(scenes[g], ms[g]);  // on the CALLING thread (rc_last_kernel_ms is per thread); scenes[0] last
@@ -319,18 +369,45 @@ static void multi_rays(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_
         RC_HIP(hipSetDevice(scenes[0]->device));
         RC_HIP(hipEventRecord(reduced[k], jobs[0].comm));
     };
-    auto enqueue_copy = [&](uint32_t k) {  // may block the host while the chunk travels (pageable `out`): the next chunk's trace and reduce are enqueued first
+    auto enqueue_copy = [&](uint32_t k) {  // (copier thread) may block while the chunk travels (pageable `out`)
         uint32_t r0, r1; chunk_range(k, r0, r1);
         RC_HIP(hipSetDevice(scenes[0]->device));
         RC_HIP(hipStreamWaitEvent(jobs[0].copy, reduced[k], 0));
         RC_HIP(hipMemcpy2DAsync(out + r0, (size_t)n * 4u, acc[0].p + (size_t)r0 * n, (size_t)(r1 - r0) * 4u, (size_t)(r1 - r0) * 4u, n, hipMemcpyDeviceToHost, jobs[0].copy));
     };
-    enqueue_trace(0);
-    enqueue_reduce(0);
-    for (uint32_t k = 0; k < n_chunks; ++k) {
-        if (k + 1 < n_chunks) { enqueue_trace(k + 1); enqueue_reduce(k + 1); }
-        enqueue_copy(k);
+    // The copies leave from their own host thread: a 2-D copy into PAGEABLE memory blocks its caller while the chunk travels, and the
+    // thread that feeds every device's streams must never wait behind device 0's PCIe link (the accumulators are whole matrices, so
+    // no trace or reduce ever waits for a copy: the enqueuing thread runs ahead freely; the copier follows the `reduced` events).
+    std::atomic<uint32_t> ready{0};   // chunks whose reduce has been enqueued and whose `reduced` event has been recorded
+    std::atomic<bool> abort_copies{false};
+    std::string copy_err;
+    int copy_code = 0;
+    std::thread copier([&] {
+        RcCaptureRelaxed relaxed;
+        try {
+            for (uint32_t k = 0; k < n_chunks; ++k) {
+                while (ready.load(std::memory_order_acquire) <= k) {
+                    if (abort_copies.load(std::memory_order_acquire)) return;
+                    std::this_thread::yield();
+                }
+                enqueue_copy(k);
+            }
+        } catch (const RcError& e) { copy_err = e.what(); copy_code = e.code; }
+        catch (const std::exception& e) { copy_err = e.what(); copy_code = RC_ERR_HIP; }
+    });
+    try {
+        for (uint32_t k = 0; k < n_chunks; ++k) {
+            enqueue_trace(k);
+            enqueue_reduce(k);
+            ready.store(k + 1, std::memory_order_release);
+        }
+    } catch (...) {
+        abort_copies.store(true, std::memory_order_release);
+        copier.join();
+        throw;
     }
+    copier.join();
+    if (copy_code) throw RcError(copy_code, copy_err);
     RC_HIP(hipSetDevice(scenes[0]->device));
     RC_HIP(hipEventRecord(jobs[0].t_end, jobs[0].copy));
     RC_HIP(hipStreamSynchronize(jobs[0].copy));
@@ -353,7 +430,7 @@ void rc_view_factors_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t 
     const uint64_t n = scenes[0]->n_flat_prims;
     if (n == 0) return;
     struct DeviceRestore { int dev = 0; DeviceRestore() { (void)hipGetDevice(&dev); } ~DeviceRestore() { (void)hipSetDevice(dev); } } restore;  // the caller's current device is the caller's
-    populate_parallel(out, n * n * 4u);
+    if (!(mode == RC_VF_MODE_ROWS && n_scenes > 1 && scenes[0]->opt.vf_first_touch)) populate_parallel(out, n * n * 4u);  // (ROWS on several devices: every device's thread faults in its own rows)
     if (mode == RC_VF_MODE_ROWS) multi_rows(scenes, n_scenes, rays_per_triangle, seed, out);
     else multi_rays(scenes, n_scenes, rays_per_triangle, seed, out);
 }

@@ -378,40 +378,61 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
     capturing = cap == hipStreamCaptureStatusActive;
-    // the lane-stack spill area of the launch's stream
-    size_t idx = 0;
-    for (; idx < s->overflow_regions.size(); ++idx)
-        if (s->overflow_regions[idx].stream == stream) break;
     const size_t region_words = (size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock;  // the largest grid any option can ask for: rc_set_option clamps blocks_per_cu to 8 blocks of 256 threads per CU
-    if (idx == s->overflow_regions.size() || s->overflow_regions[idx].buf.cap < region_words) {
-        if (capturing)  // hipMalloc is not allowed while a stream is being captured
-            throw RcError(1, "a launch is being captured into a hipGraph on a stream this scene has not launched on yet: run one eager launch on the capture stream first (INTEGRATION.md, hipGraph capture)");
-        if (idx == s->overflow_regions.size()) {
-            if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // one stream too many: wait for the oldest unpinned region's stream, then take it over
-                size_t victim = 0;
-                while (victim < idx && s->overflow_regions[victim].pinned) ++victim;
-                if (victim == idx) throw RcError(1, "every stack spill region of this scene belongs to a captured hipGraph launch: at most 8 capture streams per scene");
-                if (hipStreamSynchronize(s->overflow_regions[victim].stream) != hipSuccess) {  // the caller may have destroyed that stream since
-                    (void)hipGetLastError();
-                    RC_HIP(hipDeviceSynchronize());
-                }
-                std::rotate(s->overflow_regions.begin() + victim, s->overflow_regions.begin() + victim + 1, s->overflow_regions.end());
-                idx -= 1;
-                s->overflow_regions[idx].stream = stream;
-            } else {
-                s->overflow_regions.emplace_back();
-                s->overflow_regions.back().stream = stream;
-            }
-        }
-        s->overflow_regions[idx].buf.reserve(region_words);
-    }
-    if (capturing) s->overflow_regions[idx].pinned = true;
-    s->cur_overflow = s->overflow_regions[idx].buf.p;
-    // the launch's slot of chunk counters; a launch that reuses an eager slot from another stream waits for the slot's previous user
     if (capturing) {
-        s->cur_slot = kEagerSlots + (int)(s->graph_seq % (uint64_t)(kCounterSlots - kEagerSlots));
+        // A captured launch bakes its addresses into the graph and may be replayed at any time, beside eager launches and beside other
+        // graphs: it gets a lane-stack spill region AND a slot of claim counters that no other launch, eager or captured, will ever use
+        // (graphs captured on one stream used to share that stream's region, so two of them replayed side by side on a tree
+        // deeper than the LDS stack overwrote each other's entries).  Both come from a pool of kCounterSlots - kEagerSlots per scene;
+        // option "release_captures" returns them once the caller's graphs are gone.  The allocation happens inside the capture: the
+        // entry points run with the thread's capture-interaction mode relaxed, in which hipMalloc is legal.
+        if (s->graph_seq >= (uint64_t)(kCounterSlots - kEagerSlots))
+            throw RcError(1, "this scene already holds " + std::to_string(kCounterSlots - kEagerSlots) + " captured launches (each owns a stack spill region and a counter slot): "
+                             "destroy the graphs and set option \"release_captures\" to 1, or capture several launches' worth of rays in one launch");
+        s->capture_regions.emplace_back(new DevBuf<uint32_t>());
+        try {
+            s->capture_regions.back()->reserve(region_words);
+        } catch (const RcError&) {
+            s->capture_regions.pop_back();
+            (void)hipGetLastError();
+            throw RcError(1, "could not allocate the stack spill region of a captured launch inside the capture (capture mode does not allow hipMalloc here): "
+                             "capture with hipStreamCaptureModeRelaxed / ThreadLocal, or run the launch eagerly");
+        }
+        s->cur_overflow = s->capture_regions.back()->p;
+        s->cur_slot = kEagerSlots + (int)s->graph_seq;
         s->graph_seq += 1;
     } else {
+        // the lane-stack spill area of the launch's stream (eager launches on one stream are ordered and share it)
+        size_t idx = 0;
+        for (; idx < s->overflow_regions.size(); ++idx)
+            if (s->overflow_regions[idx].stream == stream) break;
+        if (idx == s->overflow_regions.size() || s->overflow_regions[idx].buf.cap < region_words) {
+            if (idx == s->overflow_regions.size()) {
+                if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // one stream too many: take over the region of a stream that is idle (oldest first), else wait for the oldest
+                    size_t victim = idx;
+                    for (size_t v = 0; v < idx; ++v)
+                        if (hipStreamQuery(s->overflow_regions[v].stream) == hipSuccess) { victim = v; break; }
+                    (void)hipGetLastError();  // (hipErrorNotReady, or an invalid handle: a stream the caller has destroyed since)
+                    if (victim == idx) {
+                        victim = 0;
+                        if (hipStreamSynchronize(s->overflow_regions[victim].stream) != hipSuccess) {  // destroyed since: its work finished before the destroy returned resources; wait on the slots' events instead of the device
+                            (void)hipGetLastError();
+                            for (auto& slot : s->slots) if (slot.recorded && slot.t1) (void)hipEventSynchronize(slot.t1);
+                            (void)hipGetLastError();
+                        }
+                    }
+                    std::rotate(s->overflow_regions.begin() + victim, s->overflow_regions.begin() + victim + 1, s->overflow_regions.end());
+                    idx -= 1;
+                    s->overflow_regions[idx].stream = stream;
+                } else {
+                    s->overflow_regions.emplace_back();
+                    s->overflow_regions.back().stream = stream;
+                }
+            }
+            s->overflow_regions[idx].buf.reserve(region_words);
+        }
+        s->cur_overflow = s->overflow_regions[idx].buf.p;
+        // the launch's slot of chunk counters; a launch that reuses an eager slot from another stream waits for the slot's previous user
         s->launch_seq += 1;
         s->cur_slot = (int)(s->launch_seq % (uint64_t)kEagerSlots);
         rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
@@ -692,20 +713,46 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
     // only where the order can matter: at least a claim per wave; the cost path maps rays to chunks with a shift (pool a power of two)
     if (!s->opt.cost_order || c.n_chunks < c.total_waves || n_base64 < 64u || n_base64 > (uint64_t)(kOrderTile * kOrderMaxBlocks) || (c.pool & (c.pool - 1u)) != 0u || c.pool < 16u) return false;
     const uint32_t n_base = (uint32_t)n_base64;
+    // Keyed by the number of CHUNKS (a batch a few rays shorter or longer has the same chunks in the same places), mode, stream and chunk size.
     rc_scene::ChunkHistory* h = nullptr;
     for (auto& e : s->histories)
-        if (e.n_items == n && e.any == any_hit && e.stream == stream && e.pool == c.pool) { h = &e; break; }
+        if (e.n_chunks == n_base && e.any == any_hit && e.stream == stream && e.pool == c.pool) { h = &e; break; }
     if (!h) {
-        if (s->histories.size() == (size_t)rc_scene::kMaxHistories) {  // evict the least recently used shape; its stream may still be running a launch that records costs
-            size_t victim = 0;
-            for (size_t i = 1; i < s->histories.size(); ++i) if (s->histories[i].last_use < s->histories[victim].last_use) victim = i;
-            if (hipStreamSynchronize(s->histories[victim].stream) != hipSuccess) { (void)hipGetLastError(); RC_HIP(hipDeviceSynchronize()); }
-            s->histories.erase(s->histories.begin() + victim);
+        // A shape this scene has no history for.  Nothing here may block or synchronise (the *_device entry points are
+        // asynchronous, and a workload whose batch size changes with every launch -- a wavefront tracer compacting its rays bounce by
+        // bounce -- misses every time): a free entry is taken at once; a full table gives up an entry only to a shape that has been seen
+        // BEFORE (a one-off size learns nothing worth keeping), and only an entry whose buffers nobody can still be using -- its stream
+        // is this launch's stream (stream order protects them) or is idle right now (hipStreamQuery, non-blocking).  Otherwise the
+        // launch simply runs in natural order.  Buffers have ONE size (the largest batch the order kernels handle), so re-keying an
+        // entry frees and allocates nothing.
+        bool seen_before = false;
+        for (const auto& r : s->recent_shapes) if (r.n_chunks == n_base && r.any == any_hit && r.stream == stream && r.pool == c.pool) { seen_before = true; break; }
+        if (!seen_before) {
+            if (s->recent_shapes.size() < (size_t)rc_scene::kRecentShapes) s->recent_shapes.emplace_back();
+            auto& r = s->recent_shapes.size() < (size_t)rc_scene::kRecentShapes ? s->recent_shapes.back() : s->recent_shapes[s->recent_clock % (uint64_t)rc_scene::kRecentShapes];
+            s->recent_clock += 1;
+            r.n_chunks = n_base; r.any = any_hit; r.stream = stream; r.pool = c.pool;
         }
-        s->histories.emplace_back();
-        h = &s->histories.back();
+        if (s->histories.size() < (size_t)rc_scene::kMaxHistories) {
+            s->histories.emplace_back();
+            h = &s->histories.back();
+            const size_t cap = (size_t)kOrderTile * kOrderMaxBlocks;
+            h->cost.reserve(cap); h->order.reserve(cap); h->ctl.reserve(4 + (size_t)kOrderMaxBlocks * (kOrderClasses + 1));
+        } else {
+            if (!seen_before) return false;
+            size_t victim = s->histories.size();
+            uint64_t oldest = ~0ull;
+            for (size_t i = 0; i < s->histories.size(); ++i) {
+                auto& e = s->histories[i];
+                if (e.last_use >= oldest) continue;
+                const bool reusable = e.stream == stream || hipStreamQuery(e.stream) == hipSuccess;
+                (void)hipGetLastError();
+                if (reusable) { victim = i; oldest = e.last_use; }
+            }
+            if (victim == s->histories.size()) return false;
+            h = &s->histories[victim];
+        }
         h->n_items = n; h->any = any_hit; h->stream = stream; h->n_chunks = n_base; h->pool = c.pool;
-        h->cost.reserve(n_base); h->order.reserve(n_base); h->ctl.reserve(4 + (size_t)kOrderMaxBlocks * (kOrderClasses + 1));
         RC_HIP(hipMemsetAsync(h->cost.p, 0, sizeof(uint32_t) * n_base, stream));
         RC_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->ctl.p), (int)s->opt.cost_thr, 4, stream));  // (threshold, top of the scale) x 2 parities: the scale is learned by the first ordered launch
         h->gen = 0;

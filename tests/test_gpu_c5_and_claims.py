@@ -362,8 +362,7 @@ def test_device_entry_points_reject_null_buffers(rc):
 
 def test_trace_launches_are_hipgraph_capturable(rc, oracle):
     """A frame of primary trace -> shadow-ray generation -> any_hit, captured into a hipGraph and replayed: the claim counters reset
-    themselves inside the kernels and a launch leaves no host-side state behind, so a replay is as good as a fresh launch (after one
-    warm-up launch on the capture stream: the first use of a stream allocates its stack spill region, which a capture cannot do)."""
+    themselves inside the kernels and a launch leaves no host-side state behind, so a replay is as good as a fresh launch."""
     import torch
     sc = rc.scenes
     cfg = sc.config_c3(lattice=(3, 3, 2))
@@ -429,13 +428,98 @@ def test_trace_launches_are_hipgraph_capturable(rc, oracle):
         assert np.array_equal(docc.cpu().numpy().view(rc.HIT_DT)["hit"], want_occ["hit"])
         assert_hits_equal(hbig.cpu().numpy().view(rc.HIT_DT), want_big, f"eager launches beside replays {rep}")
     assert t.get_option("claim_drift") == 0
-    # a capture on a stream the scene has never launched on is refused with an explanation (its stack spill area cannot be allocated then)
+    # a capture on a stream the scene has never launched on works too: every captured launch gets a stack spill region of its own,
+    # allocated inside the capture (the entry points run in relaxed capture-interaction mode)
     fresh = torch.cuda.Stream()
     g2 = torch.cuda.CUDAGraph()
-    with pytest.raises(rc.RaycoreError, match="eager launch on the capture stream"):
-        with torch.cuda.graph(g2, stream=fresh):
-            t.trace_device(dr.data_ptr(), dh.data_ptr(), n, stream=torch.cuda.current_stream().cuda_stream)
+    with torch.cuda.graph(g2, stream=fresh):
+        t.trace_device(dr.data_ptr(), dh.data_ptr(), n, stream=torch.cuda.current_stream().cuda_stream)
+    dh.zero_()
+    g2.replay()
     torch.cuda.synchronize()
+    assert_hits_equal(dh.cpu().numpy().view(rc.HIT_DT), want, "graph captured on a fresh stream")
+    # the pool: 16 captured launches per scene (2 x 3 in g, 1 in g2 so far); the 17th is refused with an explanation, and
+    # "release_captures" (the caller's promise that its graphs are gone) hands regions and slots out again
+    held = t.get_option("release_captures")
+    assert held == 5   # two frames x (closest + any) in g, one in g2
+    graphs = []
+    with pytest.raises(rc.RaycoreError, match="captured launches"):
+        for _ in range(14):
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk, stream=fresh):
+                t.trace_device(dr.data_ptr(), dh.data_ptr(), n, stream=torch.cuda.current_stream().cuda_stream)
+            graphs.append(gk)
+    assert len(graphs) == 16 - held and t.get_option("release_captures") == 16
+    torch.cuda.synchronize()
+    del graphs, g, g2, gk
+    t.set_option("release_captures", 1)
+    assert t.get_option("release_captures") == 0
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3, stream=fresh):
+        t.trace_device(dr.data_ptr(), dh.data_ptr(), n, stream=torch.cuda.current_stream().cuda_stream)
+    dh.zero_()
+    g3.replay()
+    torch.cuda.synchronize()
+    assert_hits_equal(dh.cpu().numpy().view(rc.HIT_DT), want, "graph captured after release_captures")
+    assert t.get_option("claim_drift") == 0
+    t.free()
+
+
+def test_graphs_captured_on_one_stream_replay_concurrently_on_deep_trees(rc, oracle):
+    """graphs captured on the SAME stream used to share that stream's stack spill region; replayed side by side on a tree
+    deeper than the LDS lane stack they overwrote each other's entries (silently wrong hits).  Every captured launch now owns its
+    region: two graphs (different ray sets) captured on one stream, replayed at once on two streams beside eager launches on a third,
+    each equal to the oracle."""
+    import torch
+
+    def chain(levels, fat=0.3):
+        tris = []
+        for j in range(1, levels + 1):
+            for axis in range(3):
+                size = 2.0 ** (-j + 1)
+                p = np.full(3, fat * size); p[axis] = size
+                q = p.copy(); q[(axis + 1) % 3] += 0.5 * size * fat
+                r = np.full(3, -1e-4 * (1 + 0.5 * j))
+                tris.append(np.concatenate([r, p, q]))
+        return np.array(tris, dtype=np.float32)
+    xf = np.tile(rc.scenes.IDENTITY3x4, (4, 1)).astype(np.float32)
+    xf[1, [0, 5, 10]] = 0.5
+    xf[2, [0, 5, 10]] = 0.25
+    xf[3, [3, 7, 11]] = [0.01, 0.0, 0.0]
+    cfg = {"blas": [(chain(10), None)], "instances": [(1, xf, np.arange(4, dtype=np.uint32))]}
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    g = rc.scenes.rng(77)
+    n = 400_000   # long enough launches that the two replays overlap
+    sets = []
+    for k in range(3):
+        org = g.uniform(-0.2, 0.0, size=(n, 3))
+        d = rc.scenes.normalize(g.uniform(0.05, 1.0, size=(n, 3)))
+        rays = rc.scenes.make_rays(org, d)
+        sets.append((rays, o.trace(rays, nthreads=16), torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda(),
+                     torch.empty(n * 32, dtype=torch.uint8, device="cuda")))
+    cap, s1, s2, s3 = (torch.cuda.Stream() for _ in range(4))
+    graphs = []
+    for k in range(2):
+        gk = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gk, stream=cap):   # both on the SAME capture stream
+            for _ in range(3):
+                t.trace_device(sets[k][2].data_ptr(), sets[k][3].data_ptr(), n, stream=torch.cuda.current_stream().cuda_stream)
+        graphs.append(gk)
+    for rep in range(5):
+        for k in range(3):
+            sets[k][3].zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            graphs[0].replay()
+        with torch.cuda.stream(s2):
+            graphs[1].replay()
+        for _ in range(3):
+            t.trace_device(sets[2][2].data_ptr(), sets[2][3].data_ptr(), n, stream=s3.cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert_hits_equal(sets[k][3].cpu().numpy().view(rc.HIT_DT), sets[k][1], f"rep {rep} set {k}")
+    assert t.get_option("claim_drift") == 0
+    del graphs
     t.free()
 
 
@@ -488,5 +572,45 @@ def test_cost_ordered_claiming_and_tapered_chunks_change_no_result(rc, oracle):
             t.trace_device(d_rays[1].data_ptr(), outs[1].data_ptr(), n, stream=streams[0].cuda_stream)
         torch.cuda.synchronize()
         assert_hits_equal(outs[1].cpu().numpy().view(rc.HIT_DT)[:n], want[1][0][:n], f"shape {k}")
+    assert t.get_option("claim_drift") == 0
+    t.free()
+
+
+def test_changing_batch_sizes_never_block_and_change_no_result(rc, oracle):
+    """cost-ordered claiming keeps 8 histories keyed by launch shape.  A workload whose batch size changes with every launch (a
+    wavefront tracer compacting its rays bounce by bounce) used to evict -- stream synchronise, 3 x hipFree, 3 x hipMalloc -- on every
+    launch after the eighth.  Now a miss never blocks: one-off shapes run in natural order, a shape that comes back takes over the entry
+    of an idle or same-stream shape with no allocation.  Results are the oracle's whatever order the chunks were claimed in."""
+    import time
+    import torch
+    cfg = rc.scenes.config_c3(lattice=(4, 4, 2))
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    rays = rc.scenes.c3_primary_rays(cfg, 1024, 600)
+    want = o.trace(rays, nthreads=16)
+    dr = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+    s = torch.cuda.Stream()
+    sizes = [len(rays) - 4096 * k for k in range(24)]           # 24 distinct chunk counts on one stream: three times the table
+    outs = [torch.empty(n * 32, dtype=torch.uint8, device="cuda") for n in sizes]
+    t.trace_device(dr.data_ptr(), outs[0].data_ptr(), sizes[0], stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for n, out in zip(sizes, outs):
+        t.trace_device(dr.data_ptr(), out.data_ptr(), n, stream=s.cuda_stream)
+    enqueue_s = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    total_s = time.perf_counter() - t0
+    for n, out in zip(sizes, outs):
+        assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), want[:n], f"n = {n}")
+    assert enqueue_s < 0.5 * total_s or enqueue_s < 2e-3, f"enqueueing 24 launches took {enqueue_s * 1e3:.2f} ms of {total_s * 1e3:.2f} ms: the enqueue waited for the device"
+    # two shapes that keep coming back after the table is full of one-offs: they are recognised and learn (third launch runs ordered)
+    a, b = sizes[20], sizes[22]
+    for rep in range(4):
+        for n in (a, b):
+            out = outs[sizes.index(n)]
+            out.zero_()
+            t.trace_device(dr.data_ptr(), out.data_ptr(), n, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    for n in (a, b):
+        assert_hits_equal(outs[sizes.index(n)].cpu().numpy().view(rc.HIT_DT), want[:n], f"recurring n = {n}")
     assert t.get_option("claim_drift") == 0
     t.free()

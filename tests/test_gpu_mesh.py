@@ -168,6 +168,16 @@ def test_scene_save_load_roundtrip(rc, oracle, tmp_path):
         (tmp_path / f"cycle_{name}.rcs").write_bytes(bytes(data))
         with pytest.raises(rc.RaycoreError, match="do not form a tree"):
             rc.TLAS.load(tmp_path / f"cycle_{name}.rcs")
+    # the nodes are what rays meet, the primitives are what the entry cull's spheres come from -- a file in which they
+    # disagree (a leaf with other vertices than its primitive, a box that is not its child's box) would let "entry_cull" change results
+    leaf_rec = root_rec + 64 * (2 * n_prims - 2)     # the last node is a leaf
+    for name, where, pattern in (("leaf_vertex", leaf_rec, "leaf node's vertices"), ("root_box", root_rec + 12, "child box")):
+        data = bytearray(good)
+        old = np.frombuffer(data, np.float32, 1, where)[0]
+        data[where:where + 4] = np.float32(old + 0.25).tobytes()
+        (tmp_path / f"forged_{name}.rcs").write_bytes(bytes(data))
+        with pytest.raises(rc.RaycoreError, match=pattern):
+            rc.TLAS.load(tmp_path / f"forged_{name}.rcs")
     # counts in a header are checked against the file's length before anything is allocated for them
     data = bytearray(good)
     data[off:off + 8] = np.array([0x10000000, 0x1FFFFFFF], np.uint32).tobytes()   # n_prims = 2^28, n_nodes = 2 n - 1: consistent, and absent
