@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_trace4(Trace4Args a) {
                     if (nf == 0) break;
                     if (pool_next == pool_end) {
                         if (exhausted) break;
-                        if (!rc_claim_chunk(a.claim, (blockIdx.x * kBlock + threadIdx.x) >> 6, lane, a.n_rays, pool_next, pool_end)) { exhausted = true; break; }
+                        if (!rc_claim_chunk(a.claim, nullptr, (blockIdx.x * kBlock + threadIdx.x) >> 6, lane, a.n_rays, pool_next, pool_end)) { exhausted = true; break; }
                     }
                     const unsigned long long left = pool_end - pool_next;
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_mask, 0u));

@@ -503,7 +503,13 @@ void rc_launch_illumination(rc_scene* s, const float viewdir[3], uint32_t grid, 
     PersistArgs p = rc_persist_args(s, ray_end - ray_begin, blocks * bs);
     launch.start();
     // a repeated get_illumination (same grid: item i is the same cell every time) claims the chunks that held long rays last time first
-    if (!launch.capturing && ray_begin == 0) rc_cost_order_setup(s, ray_end, 2, stream, p.claim);
+    if (!launch.capturing && ray_begin == 0) {
+        // (the rays are generated: the batch is described by its view direction and grid size -- another direction is another batch)
+        const float diag = sqrtf((s->root_max[0] - s->root_min[0]) * (s->root_max[0] - s->root_min[0]) + (s->root_max[1] - s->root_min[1]) * (s->root_max[1] - s->root_min[1]) +
+                                 (s->root_max[2] - s->root_min[2]) * (s->root_max[2] - s->root_min[2]));
+        const float stand_in[8] = {(float)grid * diag, 0.f, 0.f, 0.f, g.dir[0], g.dir[1], g.dir[2], 0.f};
+        rc_cost_order_setup(s, ray_end, 2, stream, p.claim, nullptr, stand_in);
+    }
     if (partial) {
         rc_partial_driver_args(s, p);
         if (!s->lds_attr_set[8]) {

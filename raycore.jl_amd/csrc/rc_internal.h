@@ -213,7 +213,8 @@ struct rc_scene {
     struct ChunkHistory {
         uint64_t n_items = 0; int any = 0; hipStream_t stream = nullptr;
         uint32_t n_chunks = 0, pool = 0;  // chunks of `pool` items
-        DevBuf<uint32_t> cost, order, ctl;  // ctl: [2 p], [2 p + 1] reporting threshold and top of the cost scale for launches of parity p, [4 ...] per-block class counts of the order kernels
+        DevBuf<uint32_t> cost, order, ctl;  // cost: kHistSlots arrays (one per remembered batch); ctl: the header words kHist* (rc_traverse_core.h) + per-block class counts of the order kernels
+        DevBuf<float> samples;              // kHistSlots x kHistSamples sample rays (8 floats each): how a launch's batch is recognised
         uint64_t gen = 0;                   // launches of this shape so far
         uint64_t last_use = 0;
     };

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_persistent(TraceArgs a) 
                 if (pool_next == pool_end) {
                     if (exhausted) break;
                     // one chunk of rays from this wave's shard of the interleaved chunk counters (RcClaim, rc_traverse_core.h)
-                    if (!rc_claim_chunk(a.claim, (blockIdx.x * kBlock + threadIdx.x) >> 6, lane, a.n_rays, pool_next, pool_end)) { exhausted = true; break; }
+                    if (!rc_claim_chunk(a.claim, nullptr, (blockIdx.x * kBlock + threadIdx.x) >> 6, lane, a.n_rays, pool_next, pool_end)) { exhausted = true; break; }
                 }
                 const unsigned long long left = pool_end - pool_next;
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_trace_sched(TraceArgs a) {
                 if (pool_next == pool_end) {
                     if (exhausted) break;
                     // one chunk of rays from this wave's shard of the interleaved chunk counters (RcClaim, rc_traverse_core.h)
-                    if (!rc_claim_chunk(a.claim, (blockIdx.x * kBlock + threadIdx.x) >> 6, lane, a.n_rays, pool_next, pool_end)) { exhausted = true; break; }
+                    if (!rc_claim_chunk(a.claim, nullptr, (blockIdx.x * kBlock + threadIdx.x) >> 6, lane, a.n_rays, pool_next, pool_end)) { exhausted = true; break; }
                 }
                 const unsigned long long left = pool_end - pool_next;
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
@@ -525,7 +525,7 @@ void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcCl
     out.n_chunks = (uint32_t)n_claims;
     out.g1 = (uint32_t)chunks[0]; out.g2 = (uint32_t)(chunks[0] + 2 * chunks[1]); out.g3 = (uint32_t)(chunks[0] + 2 * chunks[1] + 4 * chunks[2]);
     out.c1 = (uint32_t)chunks[0]; out.c2 = (uint32_t)(chunks[0] + chunks[1]); out.c3 = (uint32_t)(chunks[0] + chunks[1] + chunks[2]);
-    out.order = nullptr; out.cost = nullptr; out.life_thr_ptr = nullptr;
+    out.order = nullptr; out.cost = nullptr; out.hist = nullptr;
     out.pool_shift = 0;
     while ((2u << out.pool_shift) <= out.pool) ++out.pool_shift;
 }
@@ -637,50 +637,131 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
     switch (s->opt.lds_stack) { case 12: case 16: return 8; case 20: return 7; case 32: return 4; default: return 6; }
 }
 
-// ---- cost-ordered claiming (RcClaim::order / cost) -------------------------------------------------------------------------------------
-// Two small kernels turn the chunk costs the previous launch of this shape recorded into this launch's claim order: the reported chunks in
-// nine classes, linear in the lifetime of their longest ray between the reporting threshold and the longest lifetime seen the launch
-// before, longest first; then the chunks nobody reported; chunk ids ascending inside a class (a stable counting sort: k_order_count
-// tallies the classes per 1024-chunk block, k_order_scatter places every chunk, clears its cost for the launch that follows and -- block
-// 0 -- leaves the threshold and the scale of the NEXT launch: the threshold moves so that roughly 10-40 % of the chunks report).
-// ctl[2 * (gen & 1)], ctl[2 * (gen & 1) + 1] = the threshold / the top of the scale launch `gen` works with; the other pair is being written.
+// ---- cost-ordered claiming (RcClaim::order / cost / hist) -------------------------------------------------------------------------------
+// Small kernels in front of a launch turn what an earlier launch of the SAME BATCH recorded into this launch's claim order.
+//   k_order_select (one wave): which batch is this?  kHistSamples sample rays of the launch are compared with the samples kept for each of
+//     the history's kHistSlots batch slots (mean squared difference of direction and of origin / scene diagonal); the closest slot below
+//     the threshold is this batch's (its samples are replaced: a camera that moves a little per frame stays in its slot), otherwise the
+//     least recently used slot is given to it and its recorded costs are void ("fresh").  Two cameras, or N light samples, alternating on
+//     one stream therefore each learn from their own previous launch (VERDICT r3 #5a: with ONE history per shape the alternation ran
+//     4-6 % SLOWER than with no ordering at all, profiles/r04_alternating_batches.txt).
+//     A fresh batch runs in natural order.  (A first-launch PREDICTOR -- claim order from the number of top-of-tree boxes each chunk's
+//     middle ray passes, VERDICT r3 #5b -- was built and measured: reordering the chunks by it is worth 5-12 % of a 1 M-ray launch on C2 and
+//     C3, nothing on random geometry or any_hit rays, and the three extra small kernels it needs in front of the launch cost as much:
+//     profiles/r04_first_launch_predictor.txt.  Not kept.)
+//   k_order_count / k_order_scatter: the reported chunks in nine classes, linear in the lifetime of their longest ray between the
+//     reporting threshold and the longest lifetime seen the launch before, longest first; then the chunks nobody reported; chunk ids
+//     ascending inside a class (a stable counting sort: k_order_count tallies the classes per 1024-chunk block, k_order_scatter places
+//     every chunk, clears its cost for the launch that follows and -- block 0 -- leaves the threshold and the scale of the slot's NEXT
+//     launch: the threshold moves so that roughly 10-40 % of the chunks report).
+// hist[kHistScale + 4 slot + 2 p], [.. + 1] = the threshold / the top of the scale the slot's launch of parity p works with; the other pair is being written.
 namespace {
 constexpr int kOrderThreads = 256, kOrderPerThread = 4, kOrderTile = kOrderThreads * kOrderPerThread, kOrderClasses = 10, kOrderMaxBlocks = 256;
+static_assert((uint32_t)(kOrderTile * kOrderMaxBlocks) == kHistSlotStride, "a slot's cost array holds the most chunks the order kernels handle");
+constexpr int kOrderCountWords = kOrderClasses + 1;  // per block: the classes' chunk counts, the largest cost
+constexpr size_t kHistWords = kHistCounts + (size_t)kOrderMaxBlocks * kOrderCountWords;
+
+struct HostSample { float f[8]; };
+
+__global__ __launch_bounds__(64) void k_order_select(const RcRay* rays, uint64_t n, HostSample hs, float inv_l2, uint32_t* hist, float* samples, uint32_t init_thr) {
+    const int lane = threadIdx.x;
+    float r[8];
+    if (rays) {
+        uint64_t idx = (uint64_t)lane * n / (uint64_t)kHistSamples + n / (2u * kHistSamples);
+        if (idx >= n) idx = n - 1;
+        const float4* q = reinterpret_cast<const float4*>(rays + idx);
+        const float4 a = q[0], b = q[1];
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    } else {
+        for (int k = 0; k < 8; ++k) r[k] = hs.f[k];
+    }
+    int best = -1;
+    float best_d = 0.02f;  // mean over the samples of |dd|^2 / |d|^2 + |do|^2 / diagonal^2: ~0.1 rad of rotation, or a tenth of the scene of travel
+    for (int k = 0; k < kHistSlots; ++k) {
+        if (hist[kHistStamp + k] == 0u) continue;
+        const float* sp = samples + ((size_t)k * kHistSamples + lane) * 8;
+        const float ox = r[0] - sp[0], oy = r[1] - sp[1], oz = r[2] - sp[2], dx = r[4] - sp[4], dy = r[5] - sp[5], dz = r[6] - sp[6];
+        const float na = r[4] * r[4] + r[5] * r[5] + r[6] * r[6], nb = sp[4] * sp[4] + sp[5] * sp[5] + sp[6] * sp[6];
+        float d = (dx * dx + dy * dy + dz * dz) / fmaxf(fmaxf(na, nb), 1e-30f) + (ox * ox + oy * oy + oz * oz) * inv_l2;
+        for (int m = 32; m > 0; m >>= 1) d += __shfl_xor(d, m);  // (a NaN anywhere: the sum is NaN and the comparison fails -- no match)
+        d *= 1.0f / kHistSamples;
+        if (d < best_d) { best_d = d; best = k; }
+    }
+    const bool fresh = best < 0;
+    int sel = best;
+    if (fresh) {  // an empty slot, else the least recently used one
+        uint32_t oldest = 0xFFFFFFFFu;
+        for (int k = 0; k < kHistSlots; ++k) { const uint32_t st = hist[kHistStamp + k]; if (st < oldest) { oldest = st; sel = k; } }
+    }
+    float* out = samples + ((size_t)sel * kHistSamples + lane) * 8;
+    for (int k = 0; k < 8; ++k) out[k] = r[k];
+    if (lane == 0) {
+        const uint32_t clock = hist[kHistClock] + 1u;
+        hist[kHistClock] = clock;
+        hist[kHistStamp + sel] = clock;
+        const uint32_t gen = fresh ? 1u : hist[kHistGen + sel] + 1u;
+        hist[kHistGen + sel] = gen;
+        const uint32_t parity = gen & 1u;
+        uint32_t* scale = hist + kHistScale + 4 * sel;
+        if (fresh) { scale[0] = scale[1] = scale[2] = scale[3] = init_thr; }
+        hist[kHistSel] = (uint32_t)sel;
+        hist[kHistParity] = parity;
+        hist[kHistFresh] = fresh ? 1u : 0u;
+        hist[kHistOrderValid] = fresh ? 0u : 1u;
+        hist[kHistLifeThr] = scale[2u * parity];
+    }
+}
+
 __device__ inline int order_class(uint32_t c, uint32_t thr, uint32_t top) {
     if (c == 0u) return kOrderClasses - 1;
     const uint32_t span = top > thr ? top - thr + 1u : 1u, above = c > thr ? c - thr : 0u;
     const uint32_t q = above * (uint32_t)(kOrderClasses - 1) / span;  // 0 .. 8 (and beyond when this launch's rays outlived the scale)
     return q >= (uint32_t)(kOrderClasses - 1) ? 0 : (int)(kOrderClasses - 2) - (int)q;
 }
-__global__ __launch_bounds__(kOrderThreads) void k_order_count(const uint32_t* cost, const uint32_t* ctl, uint32_t parity, uint32_t* counts, uint32_t n_chunks) {
-    __shared__ uint32_t cnt[kOrderClasses + 1];
-    if (threadIdx.x <= kOrderClasses) cnt[threadIdx.x] = 0u;
+// the scale a launch's costs are classed with: the slot's own (threshold, top) of this launch's parity
+__device__ inline void order_scale(const uint32_t* hist, uint32_t& thr, uint32_t& top) {
+    const uint32_t* scale = hist + kHistScale + 4u * hist[kHistSel] + 2u * hist[kHistParity];
+    thr = scale[0]; top = scale[1];
+}
+__global__ __launch_bounds__(kOrderThreads) void k_order_count(const uint32_t* cost_base, uint32_t* hist, uint32_t n_chunks) {
+    if (hist[kHistOrderValid] == 0u) return;  // a fresh slot: natural order, nothing to count
+    __shared__ uint32_t cnt[kOrderCountWords];
+    if (threadIdx.x < kOrderCountWords) cnt[threadIdx.x] = 0u;
     __syncthreads();
-    const uint32_t thr = ctl[2u * parity], top = ctl[2u * parity + 1u];
+    const uint32_t* cost = cost_base + (size_t)hist[kHistSel] * kHistSlotStride;
+    uint32_t thr, top;
+    order_scale(hist, thr, top);
     const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
     uint32_t mx = 0u;
     for (int j = 0; j < kOrderPerThread; ++j)
         if (first + j < n_chunks) { const uint32_t c = cost[first + j]; atomicAdd(&cnt[order_class(c, thr, top)], 1u); mx = c > mx ? c : mx; }
     if (mx) atomicMax(&cnt[kOrderClasses], mx);
     __syncthreads();
-    if (threadIdx.x <= kOrderClasses) counts[blockIdx.x * (kOrderClasses + 1) + threadIdx.x] = cnt[threadIdx.x];  // [classes ..., block maximum]
+    if (threadIdx.x < kOrderCountWords) hist[kHistCounts + blockIdx.x * kOrderCountWords + threadIdx.x] = cnt[threadIdx.x];  // [classes ..., block maximum]
 }
-__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost, uint32_t* order, uint32_t* ctl, uint32_t parity, const uint32_t* counts, uint32_t n_chunks) {
+__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_base, uint32_t* order, uint32_t* hist, uint32_t n_chunks) {
+    uint32_t* cost = cost_base + (size_t)hist[kHistSel] * kHistSlotStride;
+    const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
+    if (hist[kHistOrderValid] == 0u) {  // fresh: the slot's array still holds the costs of the batch that was evicted
+        for (int j = 0; j < kOrderPerThread; ++j) if (first + j < n_chunks) cost[first + j] = 0u;
+        return;
+    }
     typedef hipcub::BlockScan<unsigned long long, kOrderThreads> Scan;
     __shared__ typename Scan::TempStorage scan_tmp;
-    __shared__ uint32_t total[kOrderClasses + 1], before[kOrderClasses];  // chunks of class k in all blocks (last: the maximum cost) / in the blocks before this one
-    if (threadIdx.x <= kOrderClasses) { total[threadIdx.x] = 0u; if (threadIdx.x < kOrderClasses) before[threadIdx.x] = 0u; }
+    __shared__ uint32_t total[kOrderCountWords], before[kOrderClasses];  // chunks of class k in all blocks (last: the largest cost) / in the blocks before this one
+    if (threadIdx.x < kOrderCountWords) { total[threadIdx.x] = 0u; if (threadIdx.x < kOrderClasses) before[threadIdx.x] = 0u; }
     __syncthreads();
+    const uint32_t* counts = hist + kHistCounts;
     for (uint32_t b = threadIdx.x; b < gridDim.x; b += kOrderThreads) {
         for (int k = 0; k < kOrderClasses; ++k) {
-            const uint32_t c = counts[b * (kOrderClasses + 1) + k];
+            const uint32_t c = counts[b * kOrderCountWords + k];
             if (c) { atomicAdd(&total[k], c); if (b < blockIdx.x) atomicAdd(&before[k], c); }
         }
-        atomicMax(&total[kOrderClasses], counts[b * (kOrderClasses + 1) + kOrderClasses]);
+        atomicMax(&total[kOrderClasses], counts[b * kOrderCountWords + kOrderClasses]);
     }
     __syncthreads();
-    const uint32_t thr = ctl[2u * parity], top = ctl[2u * parity + 1u];
-    const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
+    uint32_t thr, top;
+    order_scale(hist, thr, top);
     int cls[kOrderPerThread];
     unsigned long long packed[2] = {0ull, 0ull};  // this thread's chunks per class, 12 bits each, five classes per word
     for (int j = 0; j < kOrderPerThread; ++j) {
@@ -695,23 +776,27 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost,
     for (int k = 0; k < kOrderClasses; ++k) { pos[k] = acc + before[k] + (uint32_t)((prefix[k / 5] >> (12 * (k % 5))) & 0xFFFull); acc += total[k]; }
     for (int j = 0; j < kOrderPerThread; ++j)
         if (cls[j] >= 0) { order[pos[cls[j]]++] = first + j; cost[first + j] = 0u; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t reported = n_chunks - total[kOrderClasses - 1];
-        uint32_t next = thr;
-        if (reported * 5u > n_chunks * 2u) next += (next >> 2) + 1u;        // more than 40 % of the chunks reported: raise the bar
-        else if (reported * 10u < n_chunks && next > 2u) next -= next >> 2;  // fewer than 10 %: lower it
-        ctl[2u * (parity ^ 1u)] = next;
-        ctl[2u * (parity ^ 1u) + 1u] = total[kOrderClasses] > next ? total[kOrderClasses] : next + 8u;  // the longest lifetime just seen scales the next launch's classes
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the scale of the slot's NEXT launch (nobody reads that pair during this one)
+        uint32_t* next_scale = hist + kHistScale + 4u * hist[kHistSel] + 2u * (hist[kHistParity] ^ 1u);
+        {
+            const uint32_t reported = n_chunks - total[kOrderClasses - 1];
+            uint32_t next = thr;
+            if (reported * 5u > n_chunks * 2u) next += (next >> 2) + 1u;        // more than 40 % of the chunks reported: raise the bar
+            else if (reported * 10u < n_chunks && next > 2u) next -= next >> 2;  // fewer than 10 %: lower it
+            next_scale[0] = next;
+            next_scale[1] = total[kOrderClasses] > next ? total[kOrderClasses] : next + 8u;  // the longest lifetime just seen scales the next launch's classes
+        }
     }
 }
 }  // namespace
 
-// The history entry of a launch shape (batch size, mode, chunk geometry, stream): launches on one stream are ordered, so its buffers have
+// The history entry of a launch shape (chunk count, mode, chunk geometry, stream): launches on one stream are ordered, so its buffers have
 // one user at a time; another stream gets its own entry.  Returns false when cost ordering does not apply to this launch.
-bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t stream, rc::RcClaim& c) {
+bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t stream, rc::RcClaim& c, const RcRay* d_rays, const float* host_sample) {
     const uint64_t n_base64 = (n + c.pool - 1) / c.pool;  // chunks (the claim order permutes whole chunks; parts follow their chunk)
     // only where the order can matter: at least a claim per wave; the cost path maps rays to chunks with a shift (pool a power of two)
     if (!s->opt.cost_order || c.n_chunks < c.total_waves || n_base64 < 64u || n_base64 > (uint64_t)(kOrderTile * kOrderMaxBlocks) || (c.pool & (c.pool - 1u)) != 0u || c.pool < 16u) return false;
+    if (!d_rays && !host_sample) return false;
     const uint32_t n_base = (uint32_t)n_base64;
     // Keyed by the number of CHUNKS (a batch a few rays shorter or longer has the same chunks in the same places), mode, stream and chunk size.
     rc_scene::ChunkHistory* h = nullptr;
@@ -736,8 +821,8 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
         if (s->histories.size() < (size_t)rc_scene::kMaxHistories) {
             s->histories.emplace_back();
             h = &s->histories.back();
-            const size_t cap = (size_t)kOrderTile * kOrderMaxBlocks;
-            h->cost.reserve(cap); h->order.reserve(cap); h->ctl.reserve(4 + (size_t)kOrderMaxBlocks * (kOrderClasses + 1));
+            h->cost.reserve((size_t)kHistSlots * kHistSlotStride); h->order.reserve(kHistSlotStride); h->ctl.reserve(kHistWords);
+            h->samples.reserve((size_t)kHistSlots * kHistSamples * 8);
         } else {
             if (!seen_before) return false;
             size_t victim = s->histories.size();
@@ -753,21 +838,27 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
             h = &s->histories[victim];
         }
         h->n_items = n; h->any = any_hit; h->stream = stream; h->n_chunks = n_base; h->pool = c.pool;
-        RC_HIP(hipMemsetAsync(h->cost.p, 0, sizeof(uint32_t) * n_base, stream));
-        RC_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->ctl.p), (int)s->opt.cost_thr, 4, stream));  // (threshold, top of the scale) x 2 parities: the scale is learned by the first ordered launch
+        RC_HIP(hipMemsetAsync(h->ctl.p, 0, sizeof(uint32_t) * kHistCounts, stream));  // every batch slot empty (the cost arrays are cleared when a slot is given out)
         h->gen = 0;
     }
     h->last_use = ++s->history_clock;
     h->gen += 1;
-    const uint32_t parity = (uint32_t)(h->gen & 1u);
-    if (h->gen > 1) {  // the previous launch of this shape left its chunk costs: build the claim order from them (and clear them)
-        const uint32_t blocks = (n_base + kOrderTile - 1) / kOrderTile;
-        hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->ctl.p, parity, h->ctl.p + 4, n_base);
-        hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->order.p, h->ctl.p, parity, h->ctl.p + 4, n_base);
-        c.order = h->order.p;
+    HostSample hs{};
+    if (host_sample) for (int k = 0; k < 8; ++k) hs.f[k] = host_sample[k];
+    const float ex = s->root_max[0] - s->root_min[0], ey = s->root_max[1] - s->root_min[1], ez = s->root_max[2] - s->root_min[2];
+    const float l2 = ex * ex + ey * ey + ez * ez;
+    const float inv_l2 = (l2 > 0.f && l2 < 1e30f) ? 1.0f / l2 : 0.f;
+    const uint32_t blocks = (n_base + kOrderTile - 1) / kOrderTile;
+    hipLaunchKernelGGL(k_order_select, dim3(1), dim3(64), 0, stream, d_rays, n, hs, inv_l2, h->ctl.p, h->samples.p, (uint32_t)s->opt.cost_thr);
+    if (h->gen > 1) {  // (count: nothing to do for a fresh batch; scatter: clears the slot a fresh batch was given)
+        hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->ctl.p, n_base);
+        hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->order.p, h->ctl.p, n_base);
+    } else {
+        RC_HIP(hipMemsetAsync(h->cost.p, 0, sizeof(uint32_t) * n_base, stream));  // the very first launch of a shape: slot 0 (the only one an empty table hands out)
     }
+    c.order = h->order.p;
     c.cost = h->cost.p;
-    c.life_thr_ptr = h->ctl.p + 2u * parity;
+    c.hist = h->ctl.p;
     return true;
 }
 
@@ -806,7 +897,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
         a.tlas_k = s->tlas_top_k; a.blas_k = s->opt.blas_top ? s->blas_top_k : 0; a.lds_blas_base = s->tlas_top_k;
     }
     launch.start();
-    if (learn_order && (kernel == 3 || kernel == 5 || kernel == 6) && !launch.capturing) rc_cost_order_setup(s, n, any_hit, stream, a.claim);  // (inside the timed region: the order kernel is part of the launch's cost)
+    if (learn_order && (kernel == 3 || kernel == 5 || kernel == 6) && !launch.capturing) rc_cost_order_setup(s, n, any_hit, stream, a.claim, d_rays);  // (inside the timed region: the order kernel is part of the launch's cost)
     if (any_hit) launch_variant<true>(s, kernel, a, blocks, stream); else launch_variant<false>(s, kernel, a, blocks, stream);
     launch.finish();
 }

@@ -61,12 +61,21 @@ struct RcClaim {
     uint32_t c1, c2, c3;           // position in the claim order of the first chunk dealt in halves / quarters / eighths
     const uint32_t* order;         // position in the claim order -> chunk, a permutation of 0 .. ceil(n_items / pool) - 1; nullptr = natural order
     uint32_t* cost;                // per chunk: the longest time in flight (interior iterations of its wave) of a ray of the chunk this launch; nullptr = not recorded
-    const uint32_t* life_thr_ptr;  // [0] = only rays that were in flight at least this long report (adapted by k_order_scatter so that a minority of the chunks do)
+    const uint32_t* hist;          // the history's header words (kHist*, below), written on the device by k_order_select just before this launch: which of the
+                                   // history's batch slots this launch belongs to -- `cost` is slot 0's array, slot k's lies k * kHistSlotStride words on --, whether
+                                   // `order` holds a permutation for it, and the reporting threshold.  nullptr = no history (order / cost as given)
     uint32_t pool_shift;           // log2(pool) when pool is a power of two (the cost path maps a ray to its chunk with a shift)
 };
+// A history (rc_scene::ChunkHistory) remembers up to kHistSlots different BATCHES of one launch shape, told apart on the device by
+// kHistSamples sample rays (VERDICT r3 #5a: two cameras alternating on one stream each learn from their OWN previous launch, and a
+// batch never seen before runs in natural order instead of in somebody else's).  Header words:
+constexpr int kHistSlots = 4, kHistSamples = 64;
+constexpr uint32_t kHistSlotStride = 1u << 18;  // words between the slots' cost arrays = the most chunks the order kernels handle
+constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 3, kHistFresh = 4, kHistParity = 5,
+              kHistStamp = 8 /* [kHistSlots] */, kHistGen = 12 /* [kHistSlots] */, kHistScale = 16 /* [kHistSlots][4]: (thr, top) x 2 parities */, kHistCounts = 32;
 // Wave-uniform: the next claim of this wave's shard, or false when the shard has run dry.  `wave_id` must be the same in all lanes.
 // (A part that lies beyond the end of the batch -- in the last, incomplete chunk -- comes back empty; the caller simply claims again.)
-__device__ inline bool rc_claim_chunk(const RcClaim& c, uint32_t wave_id, int lane, uint64_t n_items, unsigned long long& pool_next,
+__device__ inline bool rc_claim_chunk(const RcClaim& c, const uint32_t* order, uint32_t wave_id, int lane, uint64_t n_items, unsigned long long& pool_next,
                                       unsigned long long& pool_end) {
     const uint32_t n = 1u << c.shard_shift;
     const uint32_t my_shard = __builtin_amdgcn_readfirstlane(wave_id) & (n - 1u);  // wave-uniform (keeps the claim in scalar registers); neighbouring waves use different counters
@@ -88,7 +97,7 @@ __device__ inline bool rc_claim_chunk(const RcClaim& c, uint32_t wave_id, int la
     else if (v < c.g2) { const uint32_t u = v - c.g1; pos = c.c1 + (u >> 1); part = u & 1u; shift = 1u; }
     else if (v < c.g3) { const uint32_t u = v - c.g2; pos = c.c2 + (u >> 2); part = u & 3u; shift = 2u; }
     else { const uint32_t u = v - c.g3; pos = c.c3 + (u >> 3); part = u & 7u; shift = 3u; }
-    const uint32_t chunk = c.order ? __builtin_amdgcn_readfirstlane(c.order[pos]) : pos;
+    const uint32_t chunk = order ? __builtin_amdgcn_readfirstlane(order[pos]) : pos;
     const uint32_t size = c.pool >> shift;
     pool_next = (unsigned long long)chunk * c.pool + (unsigned long long)part * size;
     pool_end = pool_next + size;
@@ -530,7 +539,16 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     // the ray occupied its lane, in the unit the launch's tail is made of.  The wave's iteration count lives in a scalar register and every
     // lane remembers the count at which its ray started: no per-iteration vector work.
     uint32_t it_total = 0, start_it = 0;
-    const uint32_t life_thr = a.claim.cost ? __builtin_amdgcn_readfirstlane(*a.claim.life_thr_ptr) : 0xFFFFFFFFu;
+    // which batch slot of the history this launch was assigned (k_order_select): its cost array, whether `order` is valid, its threshold
+    const uint32_t* claim_order = a.claim.order;
+    uint32_t* claim_cost = a.claim.cost;
+    uint32_t life_thr = 0xFFFFFFFFu;
+    if (a.claim.hist) {
+        const uint32_t sel = __builtin_amdgcn_readfirstlane(a.claim.hist[kHistSel]);
+        if (__builtin_amdgcn_readfirstlane(a.claim.hist[kHistOrderValid]) == 0u) claim_order = nullptr;
+        claim_cost += (size_t)sel * kHistSlotStride;
+        life_thr = __builtin_amdgcn_readfirstlane(a.claim.hist[kHistLifeThr]);
+    }
     typename LaneStackP<LDS_N, BLOCK>::pos_t sp = st.empty();
     bool live = false;
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0}, st_outer = 0, st_sub[4] = {0, 0, 0, 0}, st_cull = 0;  // st_sub: passes with an exit lane / an entry lane / a result to write / rays to start
@@ -726,7 +744,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                     sink(my_ray, closest_inst >= 0, closest_t, hit_u, hit_v, closest_prim, closest_inst);
                     live = false;
                     const uint32_t life = it_total - start_it;
-                    if (a.claim.cost && life >= life_thr) atomicMax(a.claim.cost + (uint32_t)(my_ray >> a.claim.pool_shift), life);
+                    if (claim_cost && life >= life_thr) atomicMax(claim_cost + (uint32_t)(my_ray >> a.claim.pool_shift), life);
                 }
                 RC_MARK("writeout_end");
                 RC_MARK("finish_begin");
@@ -737,7 +755,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                     if (nf == 0) break;
                     if (pool_next == pool_end) {
                         if (exhausted) break;
-                        if (!rc_claim_chunk(a.claim, (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane, a.n_items, pool_next, pool_end)) { exhausted = true; break; }
+                        if (!rc_claim_chunk(a.claim, claim_order, (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane, a.n_items, pool_next, pool_end)) { exhausted = true; break; }
                     }
                     const unsigned long long left = pool_end - pool_next;
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
@@ -815,7 +833,9 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads);  // rc_travers
 rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads);
 // cost-ordered claiming for a launch inside an RcLaunchGuard: `kind` separates the histories of launches that map items to rays differently
 // (0 closest_hit, 1 any_hit, 2 the get_illumination grid)
-bool rc_cost_order_setup(rc_scene* s, uint64_t n_items, int kind, hipStream_t stream, rc::RcClaim& claim);
+// d_rays: the launch's ray array (the batch is recognised by sample rays read on the device), or nullptr with host_sample[8] = a description of
+// generated rays (o.xyz, t_min, d.xyz, t_max of a stand-in ray: two launches whose stand-ins are close are the same batch)
+bool rc_cost_order_setup(rc_scene* s, uint64_t n_items, int kind, hipStream_t stream, rc::RcClaim& claim, const RcRay* d_rays, const float* host_sample = nullptr);
 bool rc_lds_driver_ok(rc_scene* s);
 bool rc_partial_driver_ok(rc_scene* s);
 void rc_partial_driver_args(rc_scene* s, rc::PersistArgs& p);
