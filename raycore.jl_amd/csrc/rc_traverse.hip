@@ -701,14 +701,20 @@ __global__ __launch_bounds__(64) void k_order_select(const RcRay* rays, uint64_t
         hist[kHistStamp + sel] = clock;
         const uint32_t gen = fresh ? 1u : hist[kHistGen + sel] + 1u;
         hist[kHistGen + sel] = gen;
-        const uint32_t parity = gen & 1u;
-        uint32_t* scale = hist + kHistScale + 4 * sel;
-        if (fresh) { scale[0] = scale[1] = scale[2] = scale[3] = init_thr; }
+        uint32_t* scale = hist + kHistScale + 4 * sel;  // [0], [1]: (threshold, top) of the slot's latest recording; [2], [3]: of its next one (k_order_scatter)
+        if (fresh) { scale[0] = scale[2] = init_thr; scale[1] = scale[3] = init_thr + 8u; hist[kHistPending + sel] = 0u; }
+        // an order is (re)built from what the slot's latest recording launch left, classed with the scale that launch worked with;
+        // this launch records if the slot is young (the threshold needs two rounds to settle) or its turn has come
+        const bool rebuild = hist[kHistPending + sel] != 0u;
+        const bool record = gen <= 3u || gen % kHistRecordEvery == 0u;
         hist[kHistSel] = (uint32_t)sel;
-        hist[kHistParity] = parity;
         hist[kHistFresh] = fresh ? 1u : 0u;
-        hist[kHistOrderValid] = fresh ? 0u : 1u;
-        hist[kHistLifeThr] = scale[2u * parity];
+        hist[kHistRebuild] = rebuild ? 1u : 0u;
+        hist[kHistClassThr] = scale[0]; hist[kHistClassTop] = scale[1];
+        hist[kHistOrderValid] = gen >= 2u ? 1u : 0u;     // (the slot's second launch builds its first order, in this launch's k_order_scatter)
+        hist[kHistLifeThr] = record ? scale[2] : 0xFFFFFFFFu;
+        if (record) { scale[0] = scale[2]; scale[1] = scale[3]; }
+        hist[kHistPending + sel] = record ? 1u : 0u;     // (a pending recording is consumed by this launch's order kernels)
     }
 }
 
@@ -718,13 +724,12 @@ __device__ inline int order_class(uint32_t c, uint32_t thr, uint32_t top) {
     const uint32_t q = above * (uint32_t)(kOrderClasses - 1) / span;  // 0 .. 8 (and beyond when this launch's rays outlived the scale)
     return q >= (uint32_t)(kOrderClasses - 1) ? 0 : (int)(kOrderClasses - 2) - (int)q;
 }
-// the scale a launch's costs are classed with: the slot's own (threshold, top) of this launch's parity
+// the scale the slot's recorded costs are classed with: the (threshold, top) the recording launch worked with (k_order_select)
 __device__ inline void order_scale(const uint32_t* hist, uint32_t& thr, uint32_t& top) {
-    const uint32_t* scale = hist + kHistScale + 4u * hist[kHistSel] + 2u * hist[kHistParity];
-    thr = scale[0]; top = scale[1];
+    thr = hist[kHistClassThr]; top = hist[kHistClassTop];
 }
 __global__ __launch_bounds__(kOrderThreads) void k_order_count(const uint32_t* cost_base, uint32_t* hist, uint32_t n_chunks) {
-    if (hist[kHistOrderValid] == 0u) return;  // a fresh slot: natural order, nothing to count
+    if (hist[kHistRebuild] == 0u) return;  // nothing recorded since the slot's order was built (or a fresh slot): the order stays as it is
     __shared__ uint32_t cnt[kOrderCountWords];
     if (threadIdx.x < kOrderCountWords) cnt[threadIdx.x] = 0u;
     __syncthreads();
@@ -739,11 +744,13 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_count(const uint32_t* c
     __syncthreads();
     if (threadIdx.x < kOrderCountWords) hist[kHistCounts + blockIdx.x * kOrderCountWords + threadIdx.x] = cnt[threadIdx.x];  // [classes ..., block maximum]
 }
-__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_base, uint32_t* order, uint32_t* hist, uint32_t n_chunks) {
+__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_base, uint32_t* order_base, uint32_t* hist, uint32_t n_chunks) {
     uint32_t* cost = cost_base + (size_t)hist[kHistSel] * kHistSlotStride;
+    uint32_t* order = order_base + (size_t)hist[kHistSel] * kHistSlotStride;
     const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
-    if (hist[kHistOrderValid] == 0u) {  // fresh: the slot's array still holds the costs of the batch that was evicted
-        for (int j = 0; j < kOrderPerThread; ++j) if (first + j < n_chunks) cost[first + j] = 0u;
+    if (hist[kHistRebuild] == 0u) {
+        if (hist[kHistFresh])  // the slot's array still holds the costs of the batch that was evicted
+            for (int j = 0; j < kOrderPerThread; ++j) if (first + j < n_chunks) cost[first + j] = 0u;
         return;
     }
     typedef hipcub::BlockScan<unsigned long long, kOrderThreads> Scan;
@@ -776,16 +783,14 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
     for (int k = 0; k < kOrderClasses; ++k) { pos[k] = acc + before[k] + (uint32_t)((prefix[k / 5] >> (12 * (k % 5))) & 0xFFFull); acc += total[k]; }
     for (int j = 0; j < kOrderPerThread; ++j)
         if (cls[j] >= 0) { order[pos[cls[j]]++] = first + j; cost[first + j] = 0u; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the scale of the slot's NEXT launch (nobody reads that pair during this one)
-        uint32_t* next_scale = hist + kHistScale + 4u * hist[kHistSel] + 2u * (hist[kHistParity] ^ 1u);
-        {
-            const uint32_t reported = n_chunks - total[kOrderClasses - 1];
-            uint32_t next = thr;
-            if (reported * 5u > n_chunks * 2u) next += (next >> 2) + 1u;        // more than 40 % of the chunks reported: raise the bar
-            else if (reported * 10u < n_chunks && next > 2u) next -= next >> 2;  // fewer than 10 %: lower it
-            next_scale[0] = next;
-            next_scale[1] = total[kOrderClasses] > next ? total[kOrderClasses] : next + 8u;  // the longest lifetime just seen scales the next launch's classes
-        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the scale of the slot's NEXT recording launch (words nobody reads during this kernel)
+        uint32_t* scale = hist + kHistScale + 4u * hist[kHistSel];
+        uint32_t reported = n_chunks - total[kOrderClasses - 1];
+        uint32_t next = thr;
+        if (reported * 5u > n_chunks * 2u) next += (next >> 2) + 1u;        // more than 40 % of the chunks reported: raise the bar
+        else if (reported * 10u < n_chunks && next > 2u) next -= next >> 2;  // fewer than 10 %: lower it
+        scale[2] = next;
+        scale[3] = total[kOrderClasses] > next ? total[kOrderClasses] : next + 8u;  // the longest lifetime just seen scales the next recording's classes
     }
 }
 }  // namespace
@@ -821,7 +826,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
         if (s->histories.size() < (size_t)rc_scene::kMaxHistories) {
             s->histories.emplace_back();
             h = &s->histories.back();
-            h->cost.reserve((size_t)kHistSlots * kHistSlotStride); h->order.reserve(kHistSlotStride); h->ctl.reserve(kHistWords);
+            h->cost.reserve((size_t)kHistSlots * kHistSlotStride); h->order.reserve((size_t)kHistSlots * kHistSlotStride); h->ctl.reserve(kHistWords);
             h->samples.reserve((size_t)kHistSlots * kHistSamples * 8);
         } else {
             if (!seen_before) return false;
@@ -850,7 +855,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
     const float inv_l2 = (l2 > 0.f && l2 < 1e30f) ? 1.0f / l2 : 0.f;
     const uint32_t blocks = (n_base + kOrderTile - 1) / kOrderTile;
     hipLaunchKernelGGL(k_order_select, dim3(1), dim3(64), 0, stream, d_rays, n, hs, inv_l2, h->ctl.p, h->samples.p, (uint32_t)s->opt.cost_thr);
-    if (h->gen > 1) {  // (count: nothing to do for a fresh batch; scatter: clears the slot a fresh batch was given)
+    if (h->gen > 1) {  // (both return at once unless the batch's slot has a recording to build an order from; scatter also clears the slot a fresh batch was given)
         hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->ctl.p, n_base);
         hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->order.p, h->ctl.p, n_base);
     } else {

@@ -62,8 +62,8 @@ struct RcClaim {
     const uint32_t* order;         // position in the claim order -> chunk, a permutation of 0 .. ceil(n_items / pool) - 1; nullptr = natural order
     uint32_t* cost;                // per chunk: the longest time in flight (interior iterations of its wave) of a ray of the chunk this launch; nullptr = not recorded
     const uint32_t* hist;          // the history's header words (kHist*, below), written on the device by k_order_select just before this launch: which of the
-                                   // history's batch slots this launch belongs to -- `cost` is slot 0's array, slot k's lies k * kHistSlotStride words on --, whether
-                                   // `order` holds a permutation for it, and the reporting threshold.  nullptr = no history (order / cost as given)
+                                   // history's batch slots this launch belongs to -- `cost` / `order` are slot 0's arrays, slot k's lie k * kHistSlotStride words
+                                   // on --, whether the slot has an order, and the reporting threshold (or: do not record).  nullptr = no history
     uint32_t pool_shift;           // log2(pool) when pool is a power of two (the cost path maps a ray to its chunk with a shift)
 };
 // A history (rc_scene::ChunkHistory) remembers up to kHistSlots different BATCHES of one launch shape, told apart on the device by
@@ -71,8 +71,15 @@ struct RcClaim {
 // batch never seen before runs in natural order instead of in somebody else's).  Header words:
 constexpr int kHistSlots = 4, kHistSamples = 64;
 constexpr uint32_t kHistSlotStride = 1u << 18;  // words between the slots' cost arrays = the most chunks the order kernels handle
-constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 3, kHistFresh = 4, kHistParity = 5,
-              kHistStamp = 8 /* [kHistSlots] */, kHistGen = 12 /* [kHistSlots] */, kHistScale = 16 /* [kHistSlots][4]: (thr, top) x 2 parities */, kHistCounts = 32;
+constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 3, kHistFresh = 4, kHistRebuild = 5, kHistClassThr = 6, kHistClassTop = 7,  // of THIS launch
+              kHistStamp = 8 /* [kHistSlots] */, kHistGen = 12 /* [kHistSlots] */,
+              kHistScale = 16 /* [kHistSlots][4]: (threshold, top of the scale) the slot's latest recording launch worked with; the pair its next one will */,
+              kHistPending = 32 /* [kHistSlots]: the slot's cost array holds a recording that no order has been built from yet */, kHistCounts = 40;
+// RECORDING costs: every reporting ray is an atomic whose acknowledgement the wave's next s_waitcnt vmcnt waits for along with its node
+// fetches -- 25-30 us of a 0.37 ms launch (profiles/r04_cost_order_recording.txt: the same learned order WITHOUT recording traces the
+// shadow batch at 5.95 instead of 5.55 Grays/s).  So a batch slot records its first three launches (the reporting threshold needs two
+// rounds to settle) and then one launch in kHistRecordEvery; the launches in between reuse the slot's order as it stands.
+constexpr uint32_t kHistRecordEvery = 8;
 // Wave-uniform: the next claim of this wave's shard, or false when the shard has run dry.  `wave_id` must be the same in all lanes.
 // (A part that lies beyond the end of the batch -- in the last, incomplete chunk -- comes back empty; the caller simply claims again.)
 __device__ inline bool rc_claim_chunk(const RcClaim& c, const uint32_t* order, uint32_t wave_id, int lane, uint64_t n_items, unsigned long long& pool_next,
@@ -546,8 +553,10 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     if (a.claim.hist) {
         const uint32_t sel = __builtin_amdgcn_readfirstlane(a.claim.hist[kHistSel]);
         if (__builtin_amdgcn_readfirstlane(a.claim.hist[kHistOrderValid]) == 0u) claim_order = nullptr;
+        else claim_order += (size_t)sel * kHistSlotStride;
         claim_cost += (size_t)sel * kHistSlotStride;
-        life_thr = __builtin_amdgcn_readfirstlane(a.claim.hist[kHistLifeThr]);
+        life_thr = __builtin_amdgcn_readfirstlane(a.claim.hist[kHistLifeThr]);  // 0xFFFFFFFF: this launch does not record
+        if (life_thr == 0xFFFFFFFFu) claim_cost = nullptr;
     }
     typename LaneStackP<LDS_N, BLOCK>::pos_t sp = st.empty();
     bool live = false;
