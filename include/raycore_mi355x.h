@@ -193,7 +193,7 @@ int rc_trace_any_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, u
  * nodes in LDS; takes effect at the next structural rc_sync), "onesweep_min" (key count from which
  * the builds sort with Onesweep radix passes instead of a merge sort), "stats" (dev counters),
  * "timeline_ptr" (dev: device address of 8 x u64 per wave that kernel 5 fills with its waves' event
- * times, tools/timeline_probe.py; 0 = off).
+ * times, tools/archive/timeline_probe.py; 0 = off).
  * None of them changes a result: every variant and every claim order returns identical hits.
  * Read-only: "n_cus", "blas_top_k", "tlas_top_k", "claim_drift", "stat0".."statf", "stat16".."stat23". */
 int rc_set_option(rc_scene* scene, const char* name, int64_t value);
@@ -261,7 +261,10 @@ int rc_view_factors_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_p
  * rule as view_factors! (src/kernels.jl:93-97), so the vectors equal the sums of rc_view_factors' matrix exactly; u64, n_prims each;
  * either pointer may be NULL.  No N x N array exists anywhere: the call costs the tracing (C5: ~40 ms), not 10 GB over PCIe.
  * _device: rays [ray_begin, ray_end) of the sources with flat primitive indices [src_begin, src_end), ACCUMULATED into device vectors
- *   (the shard unit of a multi-process run: torch.distributed reduce of 2 N int64).
+ *   (the shard unit of a multi-process run: torch.distributed reduce of 2 N int64).  d_received is updated by a plain add at the end of the
+ *   launch (the kernel counts into private copies of the vector: a few large triangles receive most rays of a closed scene, and atomics
+ *   onto a few hundred cache lines run at half the rate of scattered ones): shards on ONE stream accumulate correctly, shards enqueued on
+ *   different streams at the same time need vectors of their own.
  * _multi: scenes[g] = synced copies of one scene on DISTINCT devices; device g shoots ray indices [g R / G, (g+1) R / G) of every
  *   source and ONE ncclReduce (ncclUint64, sum, 2 N elements, over xGMI; librccl.so loaded on first use) brings the vectors to
  *   scenes[0]'s device -- "rays sharded across the GPUs with an RCCL reduce of the per-triangle accumulators" (SURVEY.md 8e).  Scenes

@@ -1100,6 +1100,7 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
             (void)hipSetDevice(s->device);
             std::lock_guard<std::mutex> g(s->launch_mu);
             s->capture_regions.clear();
+            s->capture_scratch.clear();
             s->graph_seq = 0;
         }
     }

@@ -63,7 +63,7 @@ struct GridSource {
     __device__ inline RcRay operator()(uint64_t i) const { return grid_ray(g, first + i); }
 };
 // Counting into an accumulator array from inside a wave.  An atomic on ONE address costs ~12.7 ns on this chip whether or not it
-// returns a value and however many lanes issue it (tools/atomic_probe.hip), so a driver whose rays mostly land on a few large
+// returns a value and however many lanes issue it (tools/archive/atomic_probe.hip), so a driver whose rays mostly land on a few large
 // triangles (a ground plane under get_illumination: 10^5 hits on one counter = milliseconds) would be bound by that one word.
 // The lanes that finish together first combine equal targets: up to four rounds of "the first pending lane's target, everyone
 // with the same target, one atomic of the group's size", stopping at the first group of one (the common case of all-different
@@ -261,12 +261,18 @@ struct ViewFactorSink {
 // use of the matrix reads off it (docs/src/viewfactors_content.md:62-68: sum(view(viewf_matrix, :, i))) -- and the row sums emitted[i] = sum_j
 // result[i, j], accumulated directly: two u64 atomics per counted ray, no N x N array anywhere.  Same rays, same counting rule as
 // ViewFactorSink (:93-97); 64-bit so that N x rays_per_triangle may pass 2^32.
+// `received` is the hot vector: most rays of a closed scene end on a few large triangles, and 2 x 10^8 atomics onto a few hundred cache
+// lines ran at HALF the rate of the matrix's scattered ones (C5: 81 ms against 39).  The kernel therefore counts into kTotalsCopies private
+// copies (by workgroup), each laid out TRANSPOSED in rows of eight (neighbouring triangles -- a wall's two halves, a sphere's ring -- sit in
+// different cache lines), and k_vf_totals_fold adds the copies into the caller's vector afterwards.
+constexpr uint32_t kTotalsCopies = 16;
 struct ViewFactorTotalsSink {
     const RcInstRec* inst;
     const RcPrim* prims;
     uint32_t n_prims, src_begin, n_ray;
-    unsigned long long* received;  // [n_prims] or nullptr
-    unsigned long long* emitted;   // [n_prims] or nullptr
+    unsigned long long* received;  // kTotalsCopies x 8 x n8 scratch counters (zeroed by the launcher), or nullptr
+    uint32_t n8;                   // ceil(n_prims / 8)
+    unsigned long long* emitted;   // [n_prims] or nullptr: per source, nearly wave-uniform -- one atomic per group (wave_count)
     __device__ inline void operator()(uint64_t w, bool hit, float, float, float, uint32_t prim, int instance) const {
         bool counted = false;
         uint32_t hit_meta = 1, src_meta = 1;
@@ -276,28 +282,38 @@ struct ViewFactorTotalsSink {
             hit_meta = prims[m3.y + prim - 1u].meta; src_meta = prims[src].meta;
             counted = hit_meta != src_meta && src_meta >= 1 && src_meta <= n_prims && hit_meta >= 1 && hit_meta <= n_prims;
         }
-        if (received) wave_count(received, (unsigned long long)(hit_meta - 1u), counted);
-        if (emitted) wave_count(emitted, (unsigned long long)(src_meta - 1u), counted);  // lanes of one pass mostly share the source: one atomic per group
+        if (received) {
+            const uint32_t j = hit_meta - 1u;
+            wave_count(received + (size_t)(blockIdx.x & (kTotalsCopies - 1u)) * 8u * n8, (unsigned long long)((j & 7u) * n8 + (j >> 3)), counted);
+        }
+        if (emitted) wave_count(emitted, (unsigned long long)(src_meta - 1u), counted);
     }
 };
+__global__ void k_vf_totals_fold(const unsigned long long* scratch, uint32_t n8, uint32_t n, unsigned long long* received) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    unsigned long long sum = 0;
+    for (uint32_t c = 0; c < kTotalsCopies; ++c) sum += scratch[(size_t)c * 8u * n8 + (j & 7u) * n8 + (j >> 3)];
+    if (sum) received[j] += sum;  // (ACCUMULATES, like the kernel: stream order makes the plain add safe against earlier shards; concurrent shards on other streams need their own vectors)
+}
 __global__ __launch_bounds__(kBlock, 6) void k_vf_totals(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t ray_begin,
-                                                          uint32_t n_ray, unsigned long long* received, unsigned long long* emitted) {
+                                                          uint32_t n_ray, unsigned long long* received, uint32_t n8, unsigned long long* emitted) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     phased_trace<false, kLdsStack, false>(v, p, lds_stack, ViewFactorSource{v.prims, nullptr, k0, k1, src_begin, ray_begin, n_ray},
-                                          ViewFactorTotalsSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, received, emitted});
+                                          ViewFactorTotalsSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, received, n8, emitted});
 }
 __global__ __launch_bounds__(kMidBlock, 6) void k_vf_totals_lds(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t ray_begin,
-                                                                 uint32_t n_ray, unsigned long long* received, unsigned long long* emitted) {
+                                                                 uint32_t n_ray, unsigned long long* received, uint32_t n8, unsigned long long* emitted) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const LdsTop top(smem + (size_t)kMidStack * kMidBlock * 4);
     stage_lds_top<kMidBlock>(top, v, p.blas_k, p.lds_blas_base);
     __syncthreads();
     phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorTotalsSink, kMidBlock, true, true>(
         v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, nullptr, k0, k1, src_begin, ray_begin, n_ray},
-        ViewFactorTotalsSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, received, emitted}, top);
+        ViewFactorTotalsSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, received, n8, emitted}, top);
 }
 __global__ __launch_bounds__(kMidBlock, 6) void k_vf_totals_partial(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t ray_begin,
-                                                                     uint32_t n_ray, unsigned long long* received, unsigned long long* emitted) {
+                                                                     uint32_t n_ray, unsigned long long* received, uint32_t n8, unsigned long long* emitted) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsTop top;
     top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(kMidBlock, 6) void k_vf_totals_partial(SceneView v,
     __syncthreads();
     phased_trace<false, kMidStack, false, ViewFactorSource, ViewFactorTotalsSink, kMidBlock, false, false, true>(
         v, p, reinterpret_cast<uint32_t*>(smem), ViewFactorSource{v.prims, nullptr, k0, k1, src_begin, ray_begin, n_ray},
-        ViewFactorTotalsSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, received, emitted}, top);
+        ViewFactorTotalsSink{v.inst, v.prims, v.n_prims, src_begin, n_ray, received, n8, emitted}, top);
 }
 __global__ __launch_bounds__(kBlock, 6) void k_view_factors(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin,
                                                              uint32_t ray_begin, uint32_t n_ray, uint32_t* matrix, uint64_t row_stride,
@@ -594,6 +610,30 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
     launch.finish();
 }
 
+// Scratch counters of a totals launch (launch_mu held): launches on one stream are ordered and share an area; another stream gets its own (up to
+// 16: then an idle stream's area is taken over, else the oldest stream is waited for); a CAPTURED launch owns its area like its spill region.
+static unsigned long long* rc_totals_scratch(rc_scene* s, hipStream_t stream, bool capturing, size_t words) {
+    if (capturing) {
+        s->capture_scratch.emplace_back(new DevBuf<unsigned long long>());
+        s->capture_scratch.back()->reserve(words);
+        return s->capture_scratch.back()->p;
+    }
+    for (auto& e : s->totals_scratch) if (e.first == stream) { e.second->reserve(words); return e.second->p; }
+    if (s->totals_scratch.size() < 16) {
+        s->totals_scratch.emplace_back(stream, std::unique_ptr<DevBuf<unsigned long long>>(new DevBuf<unsigned long long>()));
+    } else {
+        size_t victim = s->totals_scratch.size();
+        for (size_t i = 0; i < s->totals_scratch.size() && victim == s->totals_scratch.size(); ++i)
+            if (hipStreamQuery(s->totals_scratch[i].first) == hipSuccess) victim = i;
+        (void)hipGetLastError();
+        if (victim == s->totals_scratch.size()) { victim = 0; if (hipStreamSynchronize(s->totals_scratch[0].first) != hipSuccess) (void)hipGetLastError(); }
+        std::rotate(s->totals_scratch.begin() + victim, s->totals_scratch.begin() + victim + 1, s->totals_scratch.end());
+        s->totals_scratch.back().first = stream;
+    }
+    s->totals_scratch.back().second->reserve(words);
+    return s->totals_scratch.back().second->p;
+}
+
 // Totals of rays [ray_begin, ray_end) of the sources with flat indices [src_begin, src_end), ACCUMULATED into d_received / d_emitted
 // (n_prims u64 each, device; either may be nullptr).
 void rc_launch_vf_totals(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end, uint32_t ray_begin,
@@ -610,6 +650,12 @@ void rc_launch_vf_totals(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed,
     const uint32_t blocks = lds ? rc_lds_driver_blocks(s, total) : rc_persistent_blocks(s, total);
     SceneView v = rc_scene_view(s, blocks * bs);
     PersistArgs p = rc_persist_args(s, total, blocks * bs);
+    const uint32_t np = s->n_flat_prims, n8 = (np + 7u) / 8u;
+    unsigned long long* scratch = nullptr;
+    if (d_received) {  // the private copies of the hot vector (see ViewFactorTotalsSink): one scratch area per stream, launches on one stream are ordered
+        scratch = rc_totals_scratch(s, stream, launch.capturing, (size_t)kTotalsCopies * 8u * n8);
+        RC_HIP(hipMemsetAsync(scratch, 0, sizeof(unsigned long long) * kTotalsCopies * 8u * n8, stream));
+    }
     launch.start();
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), n_ray = ray_end - ray_begin;
     if (partial) {
@@ -618,16 +664,17 @@ void rc_launch_vf_totals(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed,
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vf_totals_partial), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartialLdsBytes));
             s->lds_attr_set[11] = true;
         }
-        hipLaunchKernelGGL(k_vf_totals_partial, dim3(blocks), dim3(kMidBlock), kPartialLdsBytes, stream, v, p, k0, k1, src_begin, ray_begin, n_ray, d_received, d_emitted);
+        hipLaunchKernelGGL(k_vf_totals_partial, dim3(blocks), dim3(kMidBlock), kPartialLdsBytes, stream, v, p, k0, k1, src_begin, ray_begin, n_ray, scratch, n8, d_emitted);
     } else if (lds) {
         rc_lds_driver_args(s, p);
         if (!s->lds_attr_set[10]) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vf_totals_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
             s->lds_attr_set[10] = true;
         }
-        hipLaunchKernelGGL(k_vf_totals_lds, dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, v, p, k0, k1, src_begin, ray_begin, n_ray, d_received, d_emitted);
+        hipLaunchKernelGGL(k_vf_totals_lds, dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, v, p, k0, k1, src_begin, ray_begin, n_ray, scratch, n8, d_emitted);
     } else
-    hipLaunchKernelGGL(k_vf_totals, dim3(blocks), dim3(kBlock), 0, stream, v, p, k0, k1, src_begin, ray_begin, n_ray, d_received, d_emitted);
+    hipLaunchKernelGGL(k_vf_totals, dim3(blocks), dim3(kBlock), 0, stream, v, p, k0, k1, src_begin, ray_begin, n_ray, scratch, n8, d_emitted);
+    if (d_received) hipLaunchKernelGGL(k_vf_totals_fold, dim3((np + 255) / 256), dim3(256), 0, stream, scratch, n8, np, d_received);
     launch.finish();
 }
 

@@ -237,6 +237,8 @@ struct rc_scene {
     std::mutex host_call_mu;          // the other host-buffer entry points (illumination, view factors, collisions, exports) run one at a time
 
     DevBuf<float> f32_stage;
+    std::vector<std::pair<hipStream_t, std::unique_ptr<DevBuf<unsigned long long>>>> totals_scratch;  // view-factor totals: private copies of the `received` vector, one area per stream (rc_drivers.hip; launch_mu)
+    std::vector<std::unique_ptr<DevBuf<unsigned long long>>> capture_scratch;                       // ... and one per captured totals launch
     DevBuf<unsigned long long> u64_stage;  // view-factor totals: received[N] then emitted[N] (rc_multi.hip)
     DevBuf<float> vert_stage;
     DevBuf<uint32_t> meta_stage;
@@ -302,7 +304,7 @@ namespace rc { struct SceneView; struct RcClaim; }
 // launch that reuses a slot from another stream first waits for the event its previous user left there); launches that are being
 // captured into a hipGraph rotate over the remaining slots, which eager launches never touch -- a graph bakes its slot in, and a
 // replay must not meet an eager launch on the same counters.  A returning atomic on
-// ONE address costs 12.6 ns on MI355X however many waves issue it (tools/atomic_probe.hip): 6144 waves claiming their first rays
+// ONE address costs 12.6 ns on MI355X however many waves issue it (tools/archive/atomic_probe.hip): 6144 waves claiming their first rays
 // wait up to 77 us, and the 32 768 claims of a 4 M-ray launch keep a single counter busy for 0.41 ms.  Sixteen counters 256 bytes
 // apart run at 0.9 ns per claim.  The counters zero themselves at the end of every launch (rc_claim_chunk).  Words [4] and [8..] of SLOT 0 are the scene's
 // sticky stack-overflow status (set by any launch, read and cleared by check_status / rc_wait: a later launch cannot clear an

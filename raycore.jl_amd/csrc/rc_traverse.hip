@@ -441,7 +441,7 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
     if (s->opt.stats) RC_HIP(hipMemsetAsync(rc_stats_words(s), 0, kStatsWords * sizeof(unsigned long long), stream));
 }
 
-static int rc_event_mode() {  // dev (tools/event_probe.py): RC_EVENT_MODE = 0 default events, 1 hipEventDisableSystemFence, 2 no t0 event, 3 no events at all (single-stream runs only)
+static int rc_event_mode() {  // dev (tools/archive/event_probe.py): RC_EVENT_MODE = 0 default events, 1 hipEventDisableSystemFence, 2 no t0 event, 3 no events at all (single-stream runs only)
     static const int mode = [] { const char* e = getenv("RC_EVENT_MODE"); return e ? atoi(e) : 0; }();
     return mode;
 }
@@ -875,7 +875,7 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     uint32_t total_threads = blocks * kBlock;
     int64_t kernel = s->opt.kernel;  // the fall-back rules below choose for this launch only
     if (kernel < 0)  // auto: tiny batches gain nothing from refilling; a TLAS that fits the LDS planes (<= 256 instances) is read from there
-        kernel = (n < (uint64_t)total_threads * 5 / 4) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 6);  // measured crossover (tools/small_batch_probe.py): ~1.2 rays per resident lane
+        kernel = (n < (uint64_t)total_threads * 5 / 4) ? 0 : (s->n_tlas_nodes <= (uint32_t)kTlasLdsNodes ? 5 : 6);  // measured crossover (tools/archive/small_batch_probe.py): ~1.2 rays per resident lane
     if (kernel == 4 && (s->n_tlas_nodes > (uint32_t)kTlasLdsNodes || s->n_static_instances > (uint32_t)kTlasLdsInst)) kernel = 3;
     if (kernel == 5 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes) kernel = 3;
     if (kernel == 6 && s->tlas_top_k + s->blas_top_k == 0) kernel = 3;  // nothing to stage

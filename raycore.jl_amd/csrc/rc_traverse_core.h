@@ -32,7 +32,7 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
 // of `pool` consecutive items (large claims keep a wave on neighbouring rays: coherent fetches).  The chunks are dealt out by
 // n_shards counters -- in round c of a shard's counter the shards share chunks c * n .. c * n + n - 1, which of them a shard gets
 // rotating with c: with a fixed assignment a shard would own one column band of a 2048-ray-wide image, and bands differ in cost by
-// 2x -- because returning atomics on ONE address serialise at 12.6 ns each however many waves issue them (tools/atomic_probe.hip).
+// 2x -- because returning atomics on ONE address serialise at 12.6 ns each however many waves issue them (tools/archive/atomic_probe.hip).
 // A wave stays with the shard it started on: the shards own the same number of interleaved chunks (+-1) and each is drained by
 // 1/n_shards of the waves, so they run dry together, and probing other counters at the end costs more (every probe of a contended
 // line queues behind the claims) than the few chunks' worth of imbalance it could recover.
@@ -563,7 +563,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0}, st_outer = 0, st_sub[4] = {0, 0, 0, 0}, st_cull = 0;  // st_sub: passes with an exit lane / an entry lane / a result to write / rays to start
     unsigned long long st_t0 = STATS ? wall_clock64() : 0ull, st_tx = 0ull;
     int thr_eff = __builtin_amdgcn_readfirstlane(a.int_thr);  // wave-uniform: keeps the loop-exit compare on the scalar unit
-    // TIMELINE (dev, tools/timeline_probe.py): per-wave event times and scalar counts, cheap enough not to move the schedule
+    // TIMELINE (dev, tools/archive/timeline_probe.py): per-wave event times and scalar counts, cheap enough not to move the schedule
     unsigned long long tl_t0 = TIMELINE ? wall_clock64() : 0ull, tl_tx = 0ull, tl_t16 = 0ull, tl_t4 = 0ull;
     uint32_t tl_outer = 0, tl_outer_x = 0, tl_live_x = 0, tl_int = 0, tl_int_x = 0;
 

@@ -252,6 +252,35 @@ function Raycore.view_factors(accels::Vector{MI355XStaticTLAS}; rays_per_triangl
                                     ptrs, length(ptrs), rays_per_triangle, seed, out, mode === :rays ? 1 : 0))
     return out
 end
+"""
+    view_factor_totals(accel_or_accels; rays_per_triangle, seed) -> (received::Vector{UInt64}, emitted::Vector{UInt64})
+
+The per-triangle totals of `view_factors` without the N x N matrix: `received[j] == sum(view(view_factors(...), :, j))` -- the rays that
+arrive at the triangles with metadata j, what docs/src/viewfactors_content.md:62-68 computes from the matrix -- and `emitted[i] ==
+sum(view(view_factors(...), i, :))`, for the same seed.  With a vector of accels (one per GPU, same meshes) the RAYS are sharded: device g
+shoots ray indices [gR/G, (g+1)R/G) of every source and one RCCL `ncclReduce` (UInt64, 2N elements) over xGMI sums the vectors on
+accels[1]'s device.  Costs the tracing (C5: ~40 ms on one MI355X), not 10 GB over PCIe.
+"""
+function view_factor_totals(a::MI355XStaticTLAS; rays_per_triangle = 10000, seed::UInt64 = rand(UInt64))
+    n = counts(a.owner)[4]
+    received, emitted = Vector{UInt64}(undef, n), Vector{UInt64}(undef, n)
+    check(ccall((:rc_view_factor_totals, LIB), Cint, (Ptr{Cvoid}, UInt32, UInt64, Ptr{UInt64}, Ptr{UInt64}), a.owner.ptr, rays_per_triangle, seed, received, emitted))
+    return received, emitted
+end
+function view_factor_totals(accels::Vector{MI355XStaticTLAS}; rays_per_triangle = 10000, seed::UInt64 = rand(UInt64))
+    n = counts(accels[1].owner)[4]
+    received, emitted = Vector{UInt64}(undef, n), Vector{UInt64}(undef, n)
+    ptrs = Ptr{Cvoid}[a.owner.ptr for a in accels]
+    GC.@preserve accels check(ccall((:rc_view_factor_totals_multi, LIB), Cint, (Ptr{Ptr{Cvoid}}, Cint, UInt32, UInt64, Ptr{UInt64}, Ptr{UInt64}),
+                                    ptrs, length(ptrs), rays_per_triangle, seed, received, emitted))
+    return received, emitted
+end
+"One shard of the totals (sources [src_begin, src_end) x rays [ray_begin, ray_end)), ACCUMULATED into device vectors of N UInt64 each: the
+unit of a multi-process run (MPI.jl / one process per GPU: reduce 2N UInt64)."
+view_factor_totals_device!(a::MI355XStaticTLAS, rays_per_triangle::Integer, seed::UInt64, src_begin::Integer, src_end::Integer, ray_begin::Integer,
+                           ray_end::Integer, d_received::Ptr{UInt64}, d_emitted::Ptr{UInt64}; stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:rc_view_factor_totals_device, LIB), Cint, (Ptr{Cvoid}, UInt32, UInt64, UInt32, UInt32, UInt32, UInt32, Ptr{UInt64}, Ptr{UInt64}, Ptr{Cvoid}),
+                a.owner.ptr, rays_per_triangle, seed, src_begin, src_end, ray_begin, ray_end, d_received, d_emitted, stream))
 "Rows [row_begin, row_end) (0-based, end exclusive) of the matrix into `out` (column-major, any leading dimension >= N): the unit of a
 multi-process run, where every process maps the same shared-memory matrix (`Mmap.mmap` of a file in /dev/shm) and fills its own rows."
 function view_factors_rows!(out::AbstractMatrix{UInt32}, a::MI355XStaticTLAS, row_begin::Integer, row_end::Integer; rays_per_triangle = 10000, seed::UInt64)

@@ -118,3 +118,37 @@ def test_stale_or_missing_counters_claim_nothing():
         assert live["frac"] is not None
     else:
         assert live["frac"] is None and "stale counters" in live["sources"]["note"]
+
+
+def test_workload_rooflines_recompute_from_the_workloads_file():
+    """the extras' workloads (C2, shadow rays, C4, random geometry, C3 1 Mi rays) have counters of the CURRENT kernels
+    (tools/pmc_workloads.sh, fingerprinted like the C3 file) and bench.py derives a roofline object for each; recomputed here from the
+    committed file with the un-profiled kernel-trace average as the launch time."""
+    b = bench_module()
+    wl = json.load(open(os.path.join(ROOT, b.WORKLOADS_FILE)))
+    pmc = json.load(open(os.path.join(ROOT, b.COUNTER_FILE)))
+    assert wl["fingerprint"]["sha256"] == pmc["fingerprint"]["sha256"]          # both captured from the same kernel sources
+    assert set(wl["workloads"]) >= {"c2", "shadow", "c4", "r1m", "c3"}
+    for key, e in wl["workloads"].items():
+        c = e["counters_mean_per_launch"]
+        ms = e["kernel_stats"]["average_ns"] * 1e-6
+        r = b.make_workload_roofline(e, ms, e["n_rays"], True)
+        achieved = c["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9
+        assert r["bound"] == "valu-issue" and r["peak"] == 1228.8 and abs(r["achieved"] - achieved) < 0.1, key
+        assert abs(r["frac"] - achieved / 1228.8) < 1e-3 and 0.1 < r["frac"] < 0.6, (key, r["frac"])
+        lane = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)
+        assert abs(r["lane_utilisation"] - lane) < 1e-3 and 0.2 < lane < 0.7, (key, lane)
+        assert abs(r["lane_throughput_frac"] - r["frac"] * lane) < 1e-3
+        assert abs(r["waiting_frac_of_wave_cycles"] - c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) < 1e-3 and 0.2 < r["waiting_frac_of_wave_cycles"] < 0.95
+        assert abs(r["valu_wave_instructions_per_ray"] - c["SQ_INSTS_VALU"] / e["n_rays"]) < 0.01
+        assert 0.0 < r["td_busy_frac"] <= 1.0 and 0.0 < r["l2_hit_rate"] <= 1.0
+        lo, hi = r["hbm_physical_frac_range"]
+        assert 0.0 < lo <= hi < 1.0
+        assert ("<true" in r["kernel"]) == (key == "shadow")                  # the any_hit instantiation for the shadow rays, closest_hit for the rest
+        assert e["kernel_stats"]["dispatches"] == 3 and e["kernel_stats"]["min_ns"] > 0
+    # counters of other kernel sources, or no counters, claim nothing
+    e = wl["workloads"]["c2"]
+    assert b.make_workload_roofline(e, 0.4, e["n_rays"], False) is None and b.make_workload_roofline({}, 0.4, 1000000, True) is None
+    # the mid-size batches wait more and issue less than the 16 M-ray one: the regime DESIGN 4.1 describes
+    fr = {k: b.make_workload_roofline(e, e["kernel_stats"]["average_ns"] * 1e-6, e["n_rays"], True)["frac"] for k, e in wl["workloads"].items()}
+    assert fr["c4"] > fr["c2"] and fr["c4"] > fr["r1m"]

@@ -318,7 +318,7 @@ def test_drivers_against_closed_forms(rc):
 
 
 def test_timeline_instrumentation_keeps_results(rc):
-    """Option "timeline_ptr" (dev, tools/timeline_probe.py): kernel 5 built with per-wave event stamps writes 8 words per wave into the
+    """Option "timeline_ptr" (dev, tools/archive/timeline_probe.py): kernel 5 built with per-wave event stamps writes 8 words per wave into the
     caller's buffer and returns the same hits."""
     import torch
     cfg = rc.scenes.config_c3(lattice=(3, 3, 2))

@@ -75,6 +75,19 @@ def test_totals_device_entry_point_accumulates_shards(rc, oracle):
     check(lib().rc_view_factor_totals_device(t._h, 96, 11, 0, n, 0, 96, ptr(only.data_ptr()), None, None))
     torch.cuda.synchronize()
     assert np.array_equal(only.cpu().numpy().view(np.uint64), sums(want)[0])
+    # two jobs at once on two streams, each into its own vectors: the kernel's private scratch counters are per stream
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    v1, v2 = torch.zeros(2 * n, dtype=torch.int64, device="cuda"), torch.zeros(2 * n, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        v1.zero_(); v2.zero_()
+        torch.cuda.synchronize()
+        check(lib().rc_view_factor_totals_device(t._h, 96, 11, 0, n, 0, 96, ptr(v1.data_ptr()), ptr(v1.data_ptr() + 8 * n), ptr(s1.cuda_stream)))
+        check(lib().rc_view_factor_totals_device(t._h, 96, 11, 0, n, 0, 96, ptr(v2.data_ptr()), ptr(v2.data_ptr() + 8 * n), ptr(s2.cuda_stream)))
+        torch.cuda.synchronize()
+        for v in (v1, v2):
+            g = v.cpu().numpy().view(np.uint64)
+            assert np.array_equal(g[:n], sums(want)[0]) and np.array_equal(g[n:], sums(want)[1]), rep
     from raycore_jl_amd import distributed as rd
     r, e = rd.view_factor_totals_distributed(t, 96, 11)  # one rank: the whole job, no collective
     assert np.array_equal(r, sums(want)[0]) and np.array_equal(e, sums(want)[1])

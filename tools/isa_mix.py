@@ -14,7 +14,7 @@ with the dynamic histogram built here from three committed inputs:
     VALU opcodes counted per phase;
   * how often a wave runs each phase: the pass counters of the kernel's STATS instantiation (tools/phase_passes.py on the GPU box,
     profiles/r03_phase_passes_kernel5.json);
-  * cycles per opcode: profiles/r02_valu_probe.txt (tools/valu_probe.hip), ns per wave-instruction per SIMD x 2.4 GHz.
+  * cycles per opcode: profiles/r02_valu_probe.txt (tools/archive/valu_probe.hip), ns per wave-instruction per SIMD x 2.4 GHz.
 The prediction sum(passes x static count) is compared with the measured SQ_INSTS_VALU of the counter file: that is the check that the
 histogram describes what ran.
 
@@ -127,7 +127,7 @@ def cycles_of(op, probe):
 
 
 def probe3_tables():
-    """{opcode form: (cycles on static operands, cycles on lane-varying operands)} from profiles/r03_valu_probe3.txt (tools/gen_valu_probe.py:
+    """{opcode form: (cycles on static operands, cycles on lane-varying operands)} from profiles/r03_valu_probe3.txt (tools/archive/gen_valu_probe.py:
     physical registers pinned, destination separate from the sources, 6 waves / SIMD)."""
     table = {}
     path = os.path.join(ROOT, "profiles", "r03_valu_probe3.txt")
@@ -217,7 +217,7 @@ def main():
                       "mix_ceiling_G_wave_instructions_s": round(1024 * CLOCK_GHZ / avg, 1),
                       "mix_ceiling_frac_of_peak": round(2.0 / avg, 4),
                       "peak_G_wave_instructions_s": 1024 * CLOCK_GHZ / 2.0,
-                      "cycles_source": "profiles/r02_valu_probe.txt (tools/valu_probe.hip: ns per wave-instruction per SIMD at 6 waves / SIMD) x 2.4 GHz"}
+                      "cycles_source": "profiles/r02_valu_probe.txt (tools/archive/valu_probe.hip: ns per wave-instruction per SIMD at 6 waves / SIMD) x 2.4 GHz"}
         t3 = probe3_tables()
         if t3:
             rep = {}
@@ -225,7 +225,7 @@ def main():
                 a3 = sum(c * cycles3(op, t3, which) for op, c in dyn.items()) / total
                 rep[name] = {"average_cycles_per_valu_instruction": round(a3, 4), "mix_ceiling_G_wave_instructions_s": round(1024 * CLOCK_GHZ / a3, 1),
                              "mix_ceiling_frac_of_peak": round(2.0 / a3, 4)}
-            rep["source"] = ("profiles/r03_valu_probe3.txt (tools/gen_valu_probe.py -> tools/valu_probe3.hip): the same histogram priced with a probe that pins "
+            rep["source"] = ("profiles/r03_valu_probe3.txt (tools/archive/gen_valu_probe.py -> tools/archive/valu_probe3.hip): the same histogram priced with a probe that pins "
                              "physical registers and separates the destination from the sources, once on operands that never change and once on "
                              "lane-varying ones; the full-rate opcodes (v_mul / v_add / v_sub_f32, v_add_u32, v_and_b32 ...) cost 2.5-2.8 cycles in the "
                              "first setting and 3.8-4.2 in the second in their VOP2 encoding, the quarter-rate ones 4.5-4.7 in both")
