@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
 COUNTER_FILE = os.path.join("profiles", "r04_pmc_c3.json")          # per-launch PMC counters of the bench kernel (tools/capture_profiles.sh)
 WORKLOADS_FILE = os.path.join("profiles", "r04_pmc_workloads_kernel5.json")  # the same counters for the extras' workloads: C2, shadow rays, C4, random geometry, C3 1 Mi rays (tools/pmc_workloads.sh)
-MIX_FILE = os.path.join("profiles", "r03_isa_mix_kernel5.json")     # dynamic opcode histogram of the bench kernel x measured cycles per opcode (tools/isa_mix.py)
+MIX_FILE = os.path.join("profiles", "r04_isa_mix_kernel5.json")     # dynamic opcode histogram of the bench kernel x measured cycles per opcode (tools/isa_mix.py)
 HBM_REGIME_FILE = os.path.join("profiles", "r03_hbm_regime.json")   # tools/gpu_hbm_regime.sh
 COUNTS_FILE = os.path.join("profiles", "c3_reference_counts.json")  # reference-algorithm fetch counts per ray for this workload (written by the N=1 run)
 # Fallback when the counts file is missing (same numbers, measured by the oracle in round 1)
