@@ -614,3 +614,69 @@ def test_changing_batch_sizes_never_block_and_change_no_result(rc, oracle):
         assert_hits_equal(outs[sizes.index(n)].cpu().numpy().view(rc.HIT_DT), want[:n], f"recurring n = {n}")
     assert t.get_option("claim_drift") == 0
     t.free()
+
+
+def test_alternating_batches_keep_their_own_claim_order(rc, oracle):
+    """VERDICT r3 #5a: consecutive launches of ONE shape (size, mode, stream) that trace DIFFERENT rays -- two cameras, N light samples.  The
+    batch is recognised on the device by 64 sample rays (k_order_select): A and B get a slot each and keep alternating between them, a
+    camera that moves a little stays in its slot, a fifth distinct batch evicts the least recently used of the four slots -- and whatever
+    order the chunks are claimed in, every launch returns the oracle's hits."""
+    import ctypes
+    import torch
+    sc = rc.scenes
+    cfg = sc.config_c3(lattice=(4, 4, 2))
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    centre = cfg["lattice_centre"]
+
+    def view(eye):
+        return sc.pinhole_rays(1280, 800, np.asarray(eye, dtype=np.float64), centre, 45.0)   # 1.02 M rays: more chunks than waves, so the claim order applies
+    eyes = [centre + np.array([0.0, 0.0, -12.0]), centre + np.array([11.0, 2.0, -4.0]), centre + np.array([-3.0, 10.0, 5.0]),
+            centre + np.array([0.5, -12.0, 0.5]), centre + np.array([-11.0, -1.0, 2.0])]
+    batches = [view(e) for e in eyes]
+    n = len(batches[0])
+    want = [o.trace(b, nthreads=16) for b in batches]
+    dev = [torch.from_numpy(b.view(np.uint8).reshape(-1)).cuda() for b in batches]
+    out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def header():
+        h = torch.empty(40, dtype=torch.int32, device="cuda")
+        hip.hipMemcpy(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(t.get_option("debug_ctl_ptr")), ctypes.c_size_t(160), 3)
+        torch.cuda.synchronize()
+        return h.cpu().numpy().view(np.uint32)
+
+    def launch(k, what):
+        out.zero_()
+        t.trace_device(dev[k].data_ptr(), out.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), want[k], what)
+        h = header()
+        return int(h[0]), int(h[1]), int(h[4]), [int(g) for g in h[12:16]]   # slot, order valid, fresh, launches per slot
+
+    seen = {}
+    for rep in range(10):                      # A B A B ...: two slots, each counting its own launches; from its second launch on a batch has an order
+        for k in (0, 1):
+            sel, valid, fresh, gens = launch(k, f"alternating rep {rep} batch {k}")
+            seen.setdefault(k, sel)
+            assert sel == seen[k] and fresh == (1 if rep == 0 else 0) and valid == (0 if rep == 0 else 1) and gens[sel] == rep + 1, (rep, k, sel, valid, fresh, gens)
+    assert seen[0] != seen[1]
+    # the same camera, moved a little every frame: one slot (its samples follow the camera), never fresh again
+    moving = [view(eyes[0] + np.array([0.02 * f, 0.01 * f, 0.0])) for f in range(1, 7)]
+    for f, b in enumerate(moving):
+        d = torch.from_numpy(b.view(np.uint8).reshape(-1)).cuda()
+        out.zero_()
+        t.trace_device(d.data_ptr(), out.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), o.trace(b, nthreads=16), f"moving camera frame {f}")
+        h = header()
+        assert int(h[0]) == seen[0] and int(h[4]) == 0, (f, h[:8])
+    # five distinct batches on four slots: the least recently used slot is given away, its batch is fresh when it comes back
+    for k in (2, 3, 4):
+        sel, valid, fresh, gens = launch(k, f"new batch {k}")
+        assert fresh == 1 and valid == 0
+    sel, valid, fresh, gens = launch(1, "batch 1 after its slot was given away")
+    assert fresh == 1
+    sel, valid, fresh, gens = launch(1, "batch 1 again")
+    assert fresh == 0 and valid == 1
+    assert t.get_option("claim_drift") == 0
+    t.free()
