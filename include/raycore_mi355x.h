@@ -184,11 +184,14 @@ int rc_trace_any_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, u
  * "blocks_per_cu", "lds_stack", "refill", "sched_thr", "pool", "claim_shards" (scheduling knobs of the
  * persistent kernels), "taper" (guided claim sizes: towards the end of the claim order a 128-ray chunk is dealt in halves, quarters,
  * eighths; in eighths of (part size x waves) still to hand out per piece, default 12, 0 = whole chunks only), "cost_order" (1 = the
- * chunks that held long-lived rays in the previous launch of the same batch size, mode and stream are claimed first; default 1),
+ * chunks that held long-lived rays in earlier launches of the same BATCH are claimed first: the batch is recognised on the device by sample
+ * rays among up to four remembered per launch shape -- chunk count, mode, stream --, records its chunk costs in its first three launches and
+ * then in one launch of eight; default 1),
  * "cost_thr" (its initial reporting threshold), "entry_cull" (1 = an instance whose conservative sphere the ray's segment misses is
  * not entered: the reference's traversal of it would test no triangle; 0 = off, 1 = closest_hit and the drivers (default),
  * 2 = any_hit batches too), "vf_chunk_bytes" (device block per row chunk of the host-matrix view factors), "vf_first_touch" (ROWS on several devices: each device's
- * host thread joins the device's NUMA node and faults in its own row block; default 1),
+ * host thread joins the device's NUMA node and faults in its own row block; default 1), "release_captures" (set to 1 when the hipGraphs that
+ * captured launches of this scene have been destroyed: frees their stack spill regions and counter slots, 16 per scene; get: how many are held),
  * "blas_top" (1 = a scene with a single BLAS keeps that BLAS's top internal
  * nodes in LDS; takes effect at the next structural rc_sync), "onesweep_min" (key count from which
  * the builds sort with Onesweep radix passes instead of a merge sort), "stats" (dev counters),
