@@ -424,7 +424,7 @@ def main():
                 tb.push_instances(b, xf, ids)
             tb.sync()
             big[str(int(np.prod(lattice)))] = {"triangles": tb.n_primitives() * tb.n_instances(),
-                                               "mrays_s": timed(tb, sc.c3_primary_rays(cfgb, args.res, args.res), "closest"),
+                                               "mrays_s": timed(tb, sc.c3_primary_rays(cfgb, args.res, args.res), "closest", reps=12),
                                                "tlas_top_k": tb.get_option("tlas_top_k"), "blas_top_k": tb.get_option("blas_top_k")}
             tb.free()
         extras["c3_blas_more_instances_closest"] = big
@@ -462,7 +462,7 @@ def main():
         tb.push_instances(1)
         tb.sync()
         del dv
-        rate = timed(tb, inc, "closest", reps=3)
+        rate = timed(tb, inc, "closest", reps=12)
         tb.set_option("kernel", 3); tb.set_option("stats", 1)
         timed(tb, inc, "closest", reps=1)
         st = [tb.get_option(f"stat{i}") for i in range(8)]
