@@ -649,12 +649,15 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
 //     middle ray passes, VERDICT r3 #5b -- was built and measured: reordering the chunks by it is worth 5-12 % of a 1 M-ray launch on C2 and
 //     C3, nothing on random geometry or any_hit rays, and the three extra small kernels it needs in front of the launch cost as much:
 //     profiles/r04_first_launch_predictor.txt.  Not kept.)
-//   k_order_count / k_order_scatter: the reported chunks in nine classes, linear in the lifetime of their longest ray between the
-//     reporting threshold and the longest lifetime seen the launch before, longest first; then the chunks nobody reported; chunk ids
-//     ascending inside a class (a stable counting sort: k_order_count tallies the classes per 1024-chunk block, k_order_scatter places
-//     every chunk, clears its cost for the launch that follows and -- block 0 -- leaves the threshold and the scale of the slot's NEXT
-//     launch: the threshold moves so that roughly 10-40 % of the chunks report).
-// hist[kHistScale + 4 slot + 2 p], [.. + 1] = the threshold / the top of the scale the slot's launch of parity p works with; the other pair is being written.
+//   k_order_count / k_order_scatter (they return at once unless the batch's slot holds a recording no order has been built from yet): the
+//     reported chunks in nine classes, linear in the lifetime of their longest ray between the reporting threshold and the top of the scale
+//     the RECORDING launch worked with, longest first; then the chunks nobody reported; chunk ids ascending inside a class (a stable
+//     counting sort: k_order_count tallies the classes per 1024-chunk block, k_order_scatter places every chunk into the slot's order array,
+//     clears its cost for the slot's next recording and -- block 0 -- leaves the threshold and the scale of that next recording: the
+//     threshold moves so that roughly 10-40 % of the chunks report).
+//   Recording costs 25-30 us of a 0.37 ms launch (kHistRecordEvery, rc_traverse_core.h), so a slot records its launches 1-3 and then one in
+//   eight; the launches in between claim through the slot's order as it stands.
+// hist[kHistScale + 4 slot]: [0], [1] = the threshold / the top of the scale the slot's latest recording launch worked with; [2], [3] = the pair its next one will.
 namespace {
 constexpr int kOrderThreads = 256, kOrderPerThread = 4, kOrderTile = kOrderThreads * kOrderPerThread, kOrderClasses = 10, kOrderMaxBlocks = 256;
 static_assert((uint32_t)(kOrderTile * kOrderMaxBlocks) == kHistSlotStride, "a slot's cost array holds the most chunks the order kernels handle");

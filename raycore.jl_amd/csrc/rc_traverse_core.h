@@ -47,10 +47,10 @@ struct SceneView {  // the StaticTLAS arrays a kernel reads (src/instanced-bvh.j
 // together -- a launch lasts until the LAST claimed part has been traced, and 128 rays are two generations of a wave's lanes (~150 us on
 // C2).  taper = 0: every claim is a whole chunk.
 // Cost-ordered claiming (host side: ChunkHistory, rc_traverse.hip): WHICH chunk the p-th position of the claim order stands for is either p
-// itself or order[p], a permutation built on the device from what the previous launch of the same shape recorded.  A launch lasts until
-// its longest rays are done, and a long ray that sits in a chunk claimed late STARTS late; chunks that held long rays the last time are
-// therefore claimed first, whole (longest-processing-time-first with the previous launch as the predictor: render loops, repeated
-// queries), and the cheap ones end the launch in small parts.
+// itself or order[p], a permutation built on the device from what an earlier launch of the same BATCH recorded (the batch is recognised by
+// sample rays; kHist* below).  A launch lasts until its longest rays are done, and a long ray that sits in a chunk claimed late STARTS late;
+// chunks that held long rays before are therefore claimed first, whole (longest-processing-time-first with the batch's earlier launches as the
+// predictor: render loops, repeated queries), and the cheap ones end the launch in small parts.
 struct RcClaim {
     uint32_t* counters;            // kClaimShards words, kShardStrideWords apart, zero between launches
     uint32_t shard_shift;          // n_shards = 1 << shard_shift <= kClaimShards and <= the waves of the launch (every shard has a wave)
