@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: pytest-timeout's marker (registered here too, so that a box without the plugin only ignores it)")
 
 
 @pytest.fixture(scope="session")

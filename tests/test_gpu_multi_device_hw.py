@@ -10,7 +10,9 @@ import pytest
 from helpers import assert_hits_equal, build_oracle, build_product, random_rays
 from test_gpu_view_factors_host import room_cfg
 
-pytestmark = pytest.mark.gpu
+# Nothing below has ever run (the builder's box has one GPU): a multi-rank RCCL call that never returns must end the run with a stack dump,
+# not hang the suite (pytest-timeout's thread method exits the process; signals do not interrupt a thread blocked inside the library).
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread")]
 
 
 def _n_dev():
