@@ -208,7 +208,9 @@ int rc_generate_ray_grid_device(rc_scene* scene, const float viewdir[3], uint32_
 /* get_illumination(tlas, viewdir; grid_size) (src/kernels.jl:112-124): out_counts = n_prims f32 (host). */
 int rc_get_illumination(rc_scene* scene, const float viewdir[3], uint32_t grid, float* out_counts);
 /* Rays [ray_begin, ray_end) of the grid only, accumulated into a device histogram (n_prims f32) --
- * the shard unit for multi-GPU runs. */
+ * the shard unit for multi-GPU runs.  d_counts is updated by a plain add at the end of the launch (the kernel counts
+ * into private copies of the histogram: a few large, well-lit triangles take most of the hits): shards enqueued on ONE stream add up, shards
+ * enqueued on different streams at the same time need histograms of their own.  A count saturates at 2^24 like the reference's f32 `+= 1`. */
 int rc_get_illumination_device(rc_scene* scene, const float viewdir[3], uint32_t grid, uint64_t ray_begin,
                                uint64_t ray_end, float* d_counts, void* stream);
 

@@ -139,3 +139,31 @@ def test_leaf_tests_cannot_leave_the_critical_path(oracle):
         assert np.array_equal(d["hit"], ref["hit"]) and np.array_equal(d["t"].view(np.uint32), ref["t"].view(np.uint32))  # the same distance ...
         changed.append(int(((d["instance_id"] != ref["instance_id"]) | (d["primitive_id"] != ref["primitive_id"])).sum()))      # ... another winner
     assert changed[0] > 0 and changed[1] > hits // 20, changed
+
+
+def test_step_traces_agree_with_the_event_traces_and_the_counters(oracle):
+    """rco_trace_steps (dev hook behind tools/tlas_subtree_bound.py): the per-step node indices and closest-t values belong to the same steps
+    rco_trace_events records; node indices stay inside their trees, the closest t never grows, triangle tests counted from the events equal
+    what rco_trace_entries reports per instance, and the step count equals the traversal's node-fetch counter."""
+    import raycore_jl_amd as rc
+    from helpers import build_oracle
+    sc = rc.scenes
+    cfg = sc.config_c3(lon=12, bands=7, lattice=(3, 2, 2))
+    o = build_oracle(oracle, cfg)
+    rays = sc.c3_primary_rays(cfg, 24, 16)
+    n_tlas = len(o.tlas_nodes)
+    n_blas = len(o.blas_nodes)
+    for mode in ("closest", "any"):
+        hits, cnt = o.trace(rays, mode=mode, counters=True)
+        for r, c in zip(rays[::7], cnt[::7]):
+            ev, dp, nd, ct = o.trace_steps(r, mode)
+            ev2, dp2 = o.trace_events(r, mode)
+            assert np.array_equal(ev, ev2) and np.array_equal(dp, dp2)
+            assert len(ev) == int(c[0])                                   # one step per node fetch
+            kind = ev & 7
+            top = (kind == 0) | (kind == 2)
+            assert np.all(nd[top] >= 1) and np.all(nd[top] <= n_tlas) and np.all(nd[~top] >= 1) and np.all(nd[~top] <= n_blas)
+            finite = ct[np.isfinite(ct)]
+            assert np.all(np.diff(finite) <= 0)                           # the closest t only shrinks
+            inst, _, leaf_tests = o.trace_entries(r, mode)
+            assert int(((kind == 3) | (kind == 4)).sum()) == int(leaf_tests.sum()) and int((kind == 2).sum()) == len(inst) == int(c[1])
