@@ -377,6 +377,25 @@ def main():
         bounce = sc.c4_bounce_rays(cfg, rays, hits, 4 * n)
         extras["c4_incoherent_16M_closest_mrays_s"] = timed(t, bounce, "closest", reps=12, key="c4")
         del bounce, shadow
+        # A path tracer's bounce rays are NEW every launch: six different 4.19 M-ray incoherent batches in rotation, three rounds.  No batch
+        # comes back before its slot has been given away, so nothing is ever learned -- and nothing must be paid for trying: a batch seen for
+        # the first time does not record (recording costs ~7 % of a launch).
+        fresh = [torch.from_numpy(sc.c4_bounce_rays(cfg, rays, hits, n, seed=0xC400 + k).view(np.uint8).reshape(-1)).cuda() for k in range(6)]
+        dh_f = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+        nr = {}
+        for co in (1, 0):
+            t.set_option("cost_order", co)
+            ms = []
+            for rep in range(3):
+                for f in fresh:
+                    t.trace_device(f.data_ptr(), dh_f.data_ptr(), n, stream=stream.cuda_stream)
+                    if rep:
+                        ms.append(t.last_kernel_ms())
+            nr[f"cost_order_{co}_mrays_s"] = round(n / float(np.mean(ms)) / 1e3, 1)
+        t.set_option("cost_order", 1)
+        nr["note"] = "4.19 M incoherent bounce rays, a different batch every launch (6 in rotation > the 4 batch slots): mean of 12 launches; the two figures should agree"
+        extras["c4_never_repeating_batches"] = nr
+        del fresh, dh_f
         mid = sc.c3_primary_rays(cfg, 1024, 1024)
         extras["c3_1Mi_primary_closest_mrays_s"] = timed(t, mid, "closest", reps=12, key="c3")
         cfg2 = sc.config_c2()
@@ -866,7 +885,7 @@ def main():
             "config": {"workload": "C3: TLAS of 256 rotated/scaled instances of one 4096-triangle BLAS (1 048 576 triangles), "
                                    f"{n} pinhole primary rays per GPU per step, closest_hit",
                        "scheduling": "every step traces every ray from scratch; the ORDER in which the 128-ray chunks are claimed is the one learned from earlier steps of the same batch "
-                                     "(option cost_order: the batch is recognised on the device by sample rays; it records chunk costs in its first 3 launches and then in one launch of 8, "
+                                     "(option cost_order: the batch is recognised on the device by sample rays; it records chunk costs in its launches 2-4 and then in one launch of 8, "
                                      "which runs ~7 % slower -- the K timed steps contain their share of those; extras.c3_cost_order_off = natural order, extras.c3_moving_camera = different rays every launch)",
                        "entry_cull": "on (default): an instance whose conservative sphere the ray's segment misses is not entered -- the reference's traversal of it "
                                      "would test no triangle (DESIGN 4.1); every hit record identical with the option off (gpu_matches_bit_exact below is against the CPU oracle); "

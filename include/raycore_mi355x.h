@@ -185,7 +185,7 @@ int rc_trace_any_device(rc_scene* scene, const rc_ray* d_rays, rc_hit* d_hits, u
  * persistent kernels), "taper" (guided claim sizes: towards the end of the claim order a 128-ray chunk is dealt in halves, quarters,
  * eighths; in eighths of (part size x waves) still to hand out per piece, default 12, 0 = whole chunks only), "cost_order" (1 = the
  * chunks that held long-lived rays in earlier launches of the same BATCH are claimed first: the batch is recognised on the device by sample
- * rays among up to four remembered per launch shape -- chunk count, mode, stream --, records its chunk costs in its first three launches and
+ * rays among up to four remembered per launch shape -- chunk count, mode, stream --, records its chunk costs in its launches 2-4 (never the first: a batch that does not come back pays nothing) and
  * then in one launch of eight; default 1),
  * "cost_thr" (its initial reporting threshold), "entry_cull" (1 = an instance whose conservative sphere the ray's segment misses is
  * not entered: the reference's traversal of it would test no triangle; 0 = off, 1 = closest_hit and the drivers (default),

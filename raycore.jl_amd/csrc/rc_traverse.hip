@@ -655,8 +655,8 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
 //     counting sort: k_order_count tallies the classes per 1024-chunk block, k_order_scatter places every chunk into the slot's order array,
 //     clears its cost for the slot's next recording and -- block 0 -- leaves the threshold and the scale of that next recording: the
 //     threshold moves so that roughly 10-40 % of the chunks report).
-//   Recording costs 25-30 us of a 0.37 ms launch (kHistRecordEvery, rc_traverse_core.h), so a slot records its launches 1-3 and then one in
-//   eight; the launches in between claim through the slot's order as it stands.
+//   Recording costs 25-30 us of a 0.37 ms launch (kHistRecordEvery, rc_traverse_core.h), so a slot records its launches 2-4 (never the first:
+//   a batch that does not come back must not pay for it) and then one in eight; the launches in between claim through the slot's order as it stands.
 // hist[kHistScale + 4 slot]: [0], [1] = the threshold / the top of the scale the slot's latest recording launch worked with; [2], [3] = the pair its next one will.
 namespace {
 constexpr int kOrderThreads = 256, kOrderPerThread = 4, kOrderTile = kOrderThreads * kOrderPerThread, kOrderClasses = 10, kOrderMaxBlocks = 256;
@@ -707,14 +707,16 @@ __global__ __launch_bounds__(64) void k_order_select(const RcRay* rays, uint64_t
         uint32_t* scale = hist + kHistScale + 4 * sel;  // [0], [1]: (threshold, top) of the slot's latest recording; [2], [3]: of its next one (k_order_scatter)
         if (fresh) { scale[0] = scale[2] = init_thr; scale[1] = scale[3] = init_thr + 8u; hist[kHistPending + sel] = 0u; }
         // an order is (re)built from what the slot's latest recording launch left, classed with the scale that launch worked with;
-        // this launch records if the slot is young (the threshold needs two rounds to settle) or its turn has come
+        // this launch records if the batch has just come back (launches 2-4: the threshold needs two rounds to settle) or its turn has
+        // come.  A batch seen for the FIRST time does not record: recording costs 7 % of a launch, and a workload whose batches never
+        // repeat -- a path tracer's bounce rays -- would pay it on every launch for nothing.
         const bool rebuild = hist[kHistPending + sel] != 0u;
-        const bool record = gen <= 3u || gen % kHistRecordEvery == 0u;
+        const bool record = (gen >= 2u && gen <= 4u) || gen % kHistRecordEvery == 0u;
         hist[kHistSel] = (uint32_t)sel;
         hist[kHistFresh] = fresh ? 1u : 0u;
         hist[kHistRebuild] = rebuild ? 1u : 0u;
         hist[kHistClassThr] = scale[0]; hist[kHistClassTop] = scale[1];
-        hist[kHistOrderValid] = gen >= 2u ? 1u : 0u;     // (the slot's second launch builds its first order, in this launch's k_order_scatter)
+        hist[kHistOrderValid] = gen >= 3u ? 1u : 0u;     // (the slot's third launch builds its first order, in this launch's k_order_scatter, from what the second recorded)
         hist[kHistLifeThr] = record ? scale[2] : 0xFFFFFFFFu;
         if (record) { scale[0] = scale[2]; scale[1] = scale[3]; }
         hist[kHistPending + sel] = record ? 1u : 0u;     // (a pending recording is consumed by this launch's order kernels)

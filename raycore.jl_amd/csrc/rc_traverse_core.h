@@ -77,8 +77,9 @@ constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 
               kHistPending = 32 /* [kHistSlots]: the slot's cost array holds a recording that no order has been built from yet */, kHistCounts = 40;
 // RECORDING costs: every reporting ray is an atomic whose acknowledgement the wave's next s_waitcnt vmcnt waits for along with its node
 // fetches -- 25-30 us of a 0.37 ms launch (profiles/r04_cost_order_recording.txt: the same learned order WITHOUT recording traces the
-// shadow batch at 5.95 instead of 5.55 Grays/s).  So a batch slot records its first three launches (the reporting threshold needs two
-// rounds to settle) and then one launch in kHistRecordEvery; the launches in between reuse the slot's order as it stands.
+// shadow batch at 5.95 instead of 5.55 Grays/s).  So a batch slot records its launches 2-4 (the reporting threshold needs two rounds to
+// settle; the FIRST launch of a batch never records: batches that do not come back pay nothing) and then one launch in kHistRecordEvery;
+// the launches in between reuse the slot's order as it stands.
 constexpr uint32_t kHistRecordEvery = 8;
 // Wave-uniform: the next claim of this wave's shard, or false when the shard has run dry.  `wave_id` must be the same in all lanes.
 // (A part that lies beyond the end of the batch -- in the last, incomplete chunk -- comes back empty; the caller simply claims again.)

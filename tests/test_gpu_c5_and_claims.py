@@ -654,11 +654,11 @@ def test_alternating_batches_keep_their_own_claim_order(rc, oracle):
         return int(h[0]), int(h[1]), int(h[4]), [int(g) for g in h[12:16]]   # slot, order valid, fresh, launches per slot
 
     seen = {}
-    for rep in range(10):                      # A B A B ...: two slots, each counting its own launches; from its second launch on a batch has an order
+    for rep in range(10):                      # A B A B ...: two slots, each counting its own launches; from its third launch on a batch has an order (the second recorded)
         for k in (0, 1):
             sel, valid, fresh, gens = launch(k, f"alternating rep {rep} batch {k}")
             seen.setdefault(k, sel)
-            assert sel == seen[k] and fresh == (1 if rep == 0 else 0) and valid == (0 if rep == 0 else 1) and gens[sel] == rep + 1, (rep, k, sel, valid, fresh, gens)
+            assert sel == seen[k] and fresh == (1 if rep == 0 else 0) and valid == (0 if rep < 2 else 1) and gens[sel] == rep + 1, (rep, k, sel, valid, fresh, gens)
     assert seen[0] != seen[1]
     # the same camera, moved a little every frame: one slot (its samples follow the camera), never fresh again
     moving = [view(eyes[0] + np.array([0.02 * f, 0.01 * f, 0.0])) for f in range(1, 7)]
@@ -677,6 +677,8 @@ def test_alternating_batches_keep_their_own_claim_order(rc, oracle):
     sel, valid, fresh, gens = launch(1, "batch 1 after its slot was given away")
     assert fresh == 1
     sel, valid, fresh, gens = launch(1, "batch 1 again")
+    assert fresh == 0 and valid == 0
+    sel, valid, fresh, gens = launch(1, "batch 1, third launch since it came back")
     assert fresh == 0 and valid == 1
     assert t.get_option("claim_drift") == 0
     t.free()

@@ -10,7 +10,7 @@ O=gpurun_out/$R/wl; P=gpurun_out/$R/profiles
 mkdir -p $O $P
 for W in c2 shadow c4 r1m c3; do
   EXTRA=""; [ "$W" = "c3" ] && EXTRA="--c3res 1024"
-  export RC_PROBE_REPS=7   # launches 5-7 of the batch are averaged: the learned order in use, none of them a recording launch (those are launches 1-3 and every 8th)
+  export RC_PROBE_REPS=7   # launches 5-7 of the batch are averaged: the learned order in use, none of them a recording launch (those are launches 2-4 and every 8th)
   CMD="python3 tools/perf_probe.py --variants kernel=-1 --workloads $W $EXTRA"
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/$W/trace -- $CMD > $O/$W.trace.log 2>&1
   i=0
@@ -34,7 +34,7 @@ names = {"c2": ("BASELINE C2: 100 000-triangle BLAS, 1 000 000 coherent grid ray
          "r1m": ("random geometry, 1 000 000 triangles in one BLAS, 1 000 000 coherent grid rays, closest_hit (the reference's published benchmark shape)", 1000000, "<false"),
          "c3": ("C3 scene, 1 048 576 primary rays (1024 x 1024 pinhole), closest_hit: the mid-size batch of the headline scene", 1048576, "<false")}
 out = {"command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 tools/perf_probe.py --variants kernel=-1 --workloads <w> (one process per workload and counter set; tools/pmc_workloads.sh)",
-       "averaged": "the last 3 dispatches of the workload's trace kernel in each pass = launches 5-7 of the same batch: the learned claim order in use, no recording (a batch records its launches 1-3 and then one in 8, which run ~7 % longer)",
+       "averaged": "the last 3 dispatches of the workload's trace kernel in each pass = launches 5-7 of the same batch: the learned claim order in use, no recording (a batch records its launches 2-4 and then one in 8, which run ~7 % longer)",
        "fingerprint": bench.kernel_fingerprint(), "workloads": {}}
 for w, (desc, n_rays, mode_tag) in names.items():
     agg, meta = collections.defaultdict(list), {}
