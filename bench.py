@@ -393,7 +393,7 @@ def main():
                         ms.append(t.last_kernel_ms())
             nr[f"cost_order_{co}_mrays_s"] = round(n / float(np.mean(ms)) / 1e3, 1)
         t.set_option("cost_order", 1)
-        nr["note"] = "4.19 M incoherent bounce rays, a different batch every launch (6 in rotation > the 4 batch slots): mean of 12 launches; the learned-order machinery costs such a workload its three small dispatches per launch (1-2 %) and no recording"
+        nr["note"] = "4.19 M incoherent bounce rays, a different batch every launch (6 in rotation > the 4 batch slots): mean of 12 launches; after eight launches that matched no remembered batch the shape's launches go out without the order kernels (nothing is recorded for a batch's first launch either): the two figures should agree within noise"
         extras["c4_never_repeating_batches"] = nr
         del fresh, dh_f
         mid = sc.c3_primary_rays(cfg, 1024, 1024)

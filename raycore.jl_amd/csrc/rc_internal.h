@@ -26,6 +26,18 @@ struct RcError : std::runtime_error {
                                  std::to_string(__LINE__) + ")");                                         \
     } while (0)
 
+struct PinnedU32 {  // one word of pinned host memory a kernel can write and the host can poll (no synchronisation implied)
+    uint32_t* p = nullptr;
+    PinnedU32() = default;
+    PinnedU32(const PinnedU32&) = delete;
+    PinnedU32& operator=(const PinnedU32&) = delete;
+    PinnedU32(PinnedU32&& o) noexcept : p(o.p) { o.p = nullptr; }
+    PinnedU32& operator=(PinnedU32&& o) noexcept { if (this != &o) { drop(); p = o.p; o.p = nullptr; } return *this; }
+    ~PinnedU32() { drop(); }
+    void drop() { if (p) (void)hipHostFree(p); p = nullptr; }
+    void ensure() { if (!p) { RC_HIP(hipHostMalloc((void**)&p, 64, hipHostMallocDefault)); *p = 0u; } }
+};
+
 template <typename T>
 struct DevBuf {  // owning device buffer, grow-only reuse
     T* p = nullptr;
@@ -217,6 +229,8 @@ struct rc_scene {
         DevBuf<float> samples;              // kHistSlots x kHistSamples sample rays (8 floats each): how a launch's batch is recognised
         uint64_t gen = 0;                   // launches of this shape so far
         uint64_t last_use = 0;
+        PinnedU32 fresh_streak;             // written by k_order_select: consecutive launches of this shape whose batch matched no slot
+        uint32_t skip_left = 0;             // launches still to run without the order kernels (the shape's batches do not repeat)
     };
     static constexpr int kMaxHistories = 8;
     static constexpr int kRecentShapes = 16;

@@ -666,7 +666,7 @@ constexpr size_t kHistWords = kHistCounts + (size_t)kOrderMaxBlocks * kOrderCoun
 
 struct HostSample { float f[8]; };
 
-__global__ __launch_bounds__(64) void k_order_select(const RcRay* rays, uint64_t n, HostSample hs, float inv_l2, uint32_t* hist, float* samples, uint32_t init_thr) {
+__global__ __launch_bounds__(64) void k_order_select(const RcRay* rays, uint64_t n, HostSample hs, float inv_l2, uint32_t* hist, float* samples, uint32_t init_thr, uint32_t* host_streak) {
     const int lane = threadIdx.x;
     float r[8];
     if (rays) {
@@ -720,6 +720,10 @@ __global__ __launch_bounds__(64) void k_order_select(const RcRay* rays, uint64_t
         hist[kHistLifeThr] = record ? scale[2] : 0xFFFFFFFFu;
         if (record) { scale[0] = scale[2]; scale[1] = scale[3]; }
         hist[kHistPending + sel] = record ? 1u : 0u;     // (a pending recording is consumed by this launch's order kernels)
+        // tell the host when this shape's batches do not come back (a path tracer's bounce rays): it then leaves these kernels out for a while
+        const uint32_t streak = fresh ? hist[kHistFreshStreak] + 1u : 0u;
+        hist[kHistFreshStreak] = streak;
+        if (host_streak) __hip_atomic_store(host_streak, streak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -848,10 +852,23 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
             h = &s->histories[victim];
         }
         h->n_items = n; h->any = any_hit; h->stream = stream; h->n_chunks = n_base; h->pool = c.pool;
+        h->skip_left = 0;
+        if (h->fresh_streak.p) *reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p) = 0u;
         RC_HIP(hipMemsetAsync(h->ctl.p, 0, sizeof(uint32_t) * kHistCounts, stream));  // every batch slot empty (the cost arrays are cleared when a slot is given out)
         h->gen = 0;
     }
     h->last_use = ++s->history_clock;
+    // A shape whose batches never repeat learns nothing and should pay nothing: k_order_select reports the run of launches that matched no
+    // slot into a pinned word; once it reads kGiveUpAfter (whenever the kernels that wrote it have run -- nothing here waits) the next
+    // kGiveUpFor launches of the shape go out in natural order without the order kernels, then the shape is tried again.
+    constexpr uint32_t kGiveUpAfter = 8, kGiveUpFor = 64;
+    h->fresh_streak.ensure();
+    if (h->skip_left > 0) { h->skip_left -= 1; return false; }
+    if (*reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p) >= kGiveUpAfter) {
+        *reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p) = 0u;
+        h->skip_left = kGiveUpFor - 1;
+        return false;
+    }
     h->gen += 1;
     HostSample hs{};
     if (host_sample) for (int k = 0; k < 8; ++k) hs.f[k] = host_sample[k];
@@ -859,7 +876,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
     const float l2 = ex * ex + ey * ey + ez * ez;
     const float inv_l2 = (l2 > 0.f && l2 < 1e30f) ? 1.0f / l2 : 0.f;
     const uint32_t blocks = (n_base + kOrderTile - 1) / kOrderTile;
-    hipLaunchKernelGGL(k_order_select, dim3(1), dim3(64), 0, stream, d_rays, n, hs, inv_l2, h->ctl.p, h->samples.p, (uint32_t)s->opt.cost_thr);
+    hipLaunchKernelGGL(k_order_select, dim3(1), dim3(64), 0, stream, d_rays, n, hs, inv_l2, h->ctl.p, h->samples.p, (uint32_t)s->opt.cost_thr, h->fresh_streak.p);
     if (h->gen > 1) {  // (both return at once unless the batch's slot has a recording to build an order from; scatter also clears the slot a fresh batch was given)
         hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->ctl.p, n_base);
         hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->order.p, h->ctl.p, n_base);

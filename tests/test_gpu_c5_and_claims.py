@@ -682,3 +682,49 @@ def test_alternating_batches_keep_their_own_claim_order(rc, oracle):
     assert fresh == 0 and valid == 1
     assert t.get_option("claim_drift") == 0
     t.free()
+
+
+def test_batches_that_never_repeat_stop_paying_for_the_claim_order(rc, oracle):
+    """A path tracer's bounce rays are new every launch: six different batches in rotation on the history's four slots match nothing, ever.
+    k_order_select reports the run of unmatched launches to the host through a pinned word; after eight of them the host leaves the order
+    kernels out (the header's launch clock stops advancing) for the next 64 launches of the shape.  Results are the oracle's throughout."""
+    import ctypes
+    import torch
+    sc = rc.scenes
+    cfg = sc.config_c3(lattice=(4, 4, 2))
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    centre = cfg["lattice_centre"]
+    g = np.random.default_rng(3)
+    eyes = [centre + 13.0 * v / np.linalg.norm(v) for v in g.normal(size=(6, 3))]
+    batches = [sc.pinhole_rays(1280, 800, e, centre, 45.0) for e in eyes]
+    n = len(batches[0])
+    want = [o.trace(b, nthreads=16) for b in batches]
+    dev = [torch.from_numpy(b.view(np.uint8).reshape(-1)).cuda() for b in batches]
+    out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def clock():
+        h = torch.empty(40, dtype=torch.int32, device="cuda")
+        hip.hipMemcpy(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(t.get_option("debug_ctl_ptr")), ctypes.c_size_t(160), 3)
+        torch.cuda.synchronize()
+        h = h.cpu().numpy().view(np.uint32)
+        return int(h[3]), int(h[4]), int(h[36])   # launches seen by k_order_select, fresh, run of unmatched launches
+
+    clocks = []
+    for k in range(14):
+        out.zero_()
+        t.trace_device(dev[k % 6].data_ptr(), out.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), want[k % 6], f"launch {k + 1}")
+        clocks.append(clock())
+    assert [c[0] for c in clocks[:8]] == list(range(1, 9)) and all(c[1] == 1 for c in clocks[:8]) and clocks[7][2] == 8
+    assert all(c[0] == 8 for c in clocks[8:]), clocks                      # launches 9-14: natural order, no order kernels
+    # a batch that DOES repeat on another shape is unaffected (histories are per shape)
+    m = n - 4096
+    for rep in range(4):
+        out.zero_()
+        t.trace_device(dev[0].data_ptr(), out.data_ptr(), m)
+        torch.cuda.synchronize()
+        assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT)[:m], want[0][:m], f"repeating shape, launch {rep + 1}")
+    assert t.get_option("claim_drift") == 0
+    t.free()
