@@ -570,6 +570,12 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     uint32_t tl_outer = 0, tl_outer_x = 0, tl_live_x = 0, tl_int = 0, tl_int_x = 0;
 
     for (;;) {
+#if defined(RC_AGE_PRIO)  // dev experiment (VERDICT r4 #2a): a wave that carries a ray older than RC_AGE_PRIO interior iterations issues ahead of its SIMD's other waves
+        {
+            const bool old_ray = live && (it_total - start_it) > (uint32_t)RC_AGE_PRIO;
+            if (__ballot(old_ray)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         // ---- interior phase: intersect_internal_node (:1807-1832) + push far / descend near / pop (:1946-1960, 1991-1993)
         for (;;) {
             RC_MARK("interior_begin");
@@ -580,6 +586,16 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
             if (STATS) { st_iter[1] += 1; st_lane[1] += is_int ? 1 : 0; }
             if (TIMELINE) { tl_int += 1; if (tl_tx) tl_int_x += 1; }
             if (is_int) {
+#if defined(RC_EXP_VALU)  // dev experiment (tools/probes/build_variants.sh; profiles/r05_bound_probe.txt): RC_EXP_VALU extra slow-class VALU instructions (one dependent chain) per interior pass
+                { float dummy = tmin;
+#pragma unroll
+                  for (int k = 0; k < RC_EXP_VALU; ++k) asm volatile("v_max_f32 %0, %0, %1" : "+v"(dummy) : "v"(closest_t));
+                  if (dummy == 1.2345e-30f) tmin = dummy; }
+#endif
+#if defined(RC_EXP_NOP)   // ... RC_EXP_NOP x 16 idle cycles in the pass
+#pragma unroll
+                for (int k = 0; k < RC_EXP_NOP; ++k) asm volatile("s_nop 15");
+#endif
                 float4 na, nb, nc;
                 u2v ch;
                 constexpr int PS = PARTIAL_LDS ? kPartialPlaneNodes : kLdsPlaneNodes;  // plane stride
