@@ -367,7 +367,10 @@ def main():
         t.set_option("cost_order", 1)
         extras["c3_moving_camera"] = {"mrays_s": round(n / float(np.mean(ms_j)) / 1e3, 1), "frames": len(ms_j), "mrays_s_cost_order_off": round(n / float(np.mean(ms_j0)) / 1e3, 1),
                                       "note": "every launch traces DIFFERENT rays (the eye moves 0.022 per frame, 16 ray buffers of 134 MB in rotation: unlike the headline's one buffer they "
-                                              "do not stay in the Infinity Cache); mean over 32 launches with the learned order on, over 16 with it off"}
+                                              "do not stay in the Infinity Cache); mean over frames 17-48 with cost_order 1, over 16 frames with cost_order 0.  A moving camera's frames are recognised as "
+                                              "the batch of the frame before but are not REPEATS of it: after eight such launches the order kernels are left out for the shape's next 64 "
+                                              "launches (round 5; an order learned from similar rays gained less than its three dispatches cost: -1.5 % in BENCH_r04), so the two figures agree "
+                                              "within noise; the first eight frames -- not in the mean -- pay those ~2 %"}
         del dh_off, frames
         shadow = sc.c3_shadow_rays(cfg, rays, hits)
         extras["c3_any_hit_shadow_mrays_s"] = timed(t, shadow, "any", reps=12, key="shadow")
@@ -883,13 +886,17 @@ def main():
                                  mix=load_json(MIX_FILE), fingerprint=kernel_fingerprint())
         out = {
             "metric": "Mrays/s closest_hit (1M-tri TLAS)", "value": round(world * n * args.steps / elapsed / 1e6, 1), "unit": "Mrays/s",
+            # what a caller sees when the batch is NOT a repeat (filled in from the extras of the same run, same scene, same ray count,
+            # 1 GPU): natural claim order = a batch traced for the first time; a camera that moves every frame, default options
+            "first_touch_value": None, "moving_camera_value": None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: TLAS of 256 rotated/scaled instances of one 4096-triangle BLAS (1 048 576 triangles), "
                                    f"{n} pinhole primary rays per GPU per step, closest_hit",
                        "scheduling": "every step traces every ray from scratch; the ORDER in which the 128-ray chunks are claimed is the one learned from earlier steps of the same batch "
                                      "(option cost_order: the batch is recognised on the device by sample rays; it records chunk costs in its launches 2-4 and then in one launch of 8, "
-                                     "which runs ~7 % slower -- the K timed steps contain their share of those; extras.c3_cost_order_off = natural order, extras.c3_moving_camera = different rays every launch)",
+                                     "which runs ~7 % slower, and one launch in 16 ... 128 goes out in natural order to check that the learned order still pays -- the K timed steps "
+                                     "contain their share of all of those; first_touch_value = natural order, moving_camera_value = different rays every launch)",
                        "entry_cull": "on (default): an instance whose conservative sphere the ray's segment misses is not entered -- the reference's traversal of it "
                                      "would test no triangle (DESIGN 4.1); every hit record identical with the option off (gpu_matches_bit_exact below is against the CPU oracle); "
                                      "the roofline's VALU counters are those of this kernel, the algorithmic bytes are the reference algorithm's",
@@ -912,6 +919,8 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         sys.stdout.flush()
+        out["first_touch_value"] = (extras.get("c3_cost_order_off") or {}).get("mrays_s")
+        out["moving_camera_value"] = (extras.get("c3_moving_camera") or {}).get("mrays_s")
         print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
 
     if not args.no_extras and args.backend == "nccl":

@@ -72,7 +72,7 @@ struct RcClaim {
 constexpr int kHistSlots = 4, kHistSamples = 64;
 constexpr uint32_t kHistSlotStride = 1u << 18;  // words between the slots' cost arrays = the most chunks the order kernels handle
 constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 3, kHistFresh = 4, kHistRebuild = 5, kHistClassThr = 6, kHistClassTop = 7,  // of THIS launch
-              kHistFreshStreak = 36 /* consecutive launches whose batch matched no slot */,
+              kHistFreshStreak = 36 /* consecutive launches that were not a repeat (identical sample rays) of a remembered batch */,
               kHistStamp = 8 /* [kHistSlots] */, kHistGen = 12 /* [kHistSlots] */,
               kHistScale = 16 /* [kHistSlots][4]: (threshold, top of the scale) the slot's latest recording launch worked with; the pair its next one will */,
               kHistPending = 32 /* [kHistSlots]: the slot's cost array holds a recording that no order has been built from yet */, kHistCounts = 40;

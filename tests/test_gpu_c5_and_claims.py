@@ -669,7 +669,10 @@ def test_alternating_batches_keep_their_own_claim_order(rc, oracle):
         torch.cuda.synchronize()
         assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), o.trace(b, nthreads=16), f"moving camera frame {f}")
         h = header()
-        assert int(h[0]) == seen[0] and int(h[4]) == 0, (f, h[:8])
+        assert int(h[0]) == seen[0] and int(h[4]) == 0 and int(h[36]) == f + 1, (f, h[:8])   # (the streak of launches that are not REPEATS grows: eight of them and the host would pause the order kernels)
+    sel, valid, fresh, gens = launch(0, "batch 0, close to where the camera stopped")
+    sel, valid, fresh, gens = launch(0, "batch 0 again: a repeat, the streak starts over")
+    assert int(header()[36]) == 0
     # five distinct batches on four slots: the least recently used slot is given away, its batch is fresh when it comes back
     for k in (2, 3, 4):
         sel, valid, fresh, gens = launch(k, f"new batch {k}")
@@ -719,6 +722,27 @@ def test_batches_that_never_repeat_stop_paying_for_the_claim_order(rc, oracle):
         clocks.append(clock())
     assert [c[0] for c in clocks[:8]] == list(range(1, 9)) and all(c[1] == 1 for c in clocks[:8]) and clocks[7][2] == 8
     assert all(c[0] == 8 for c in clocks[8:]), clocks                      # launches 9-14: natural order, no order kernels
+    # after the pause the shape is really tried again.  The 64 skipped launches pass (6 done above), then a batch that REPEATS must
+    # get its order back: matched from its second launch on, an order in use from its third -- the device's own streak counter was zeroed
+    # with the host's, so one unmatched probe launch does not send the shape straight back into the pause.
+    for k in range(58):
+        t.trace_device(dev[k % 6].data_ptr(), out.data_ptr(), n)
+    torch.cuda.synchronize()
+    assert clock()[0] == 8
+    seen = []
+    for k in range(5):
+        out.zero_()
+        t.trace_device(dev[2].data_ptr(), out.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), want[2], f"after the pause, launch {k + 1}")
+        h = torch.empty(40, dtype=torch.int32, device="cuda")
+        hip.hipMemcpy(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(t.get_option("debug_ctl_ptr")), ctypes.c_size_t(160), 3)
+        torch.cuda.synchronize()
+        w = h.cpu().numpy().view(np.uint32)
+        seen.append((int(w[3]), int(w[1]), int(w[4]), int(w[36])))          # clock, order valid, fresh, streak
+    assert [c[0] for c in seen] == [9, 10, 11, 12, 13], seen               # every one of them went through the order kernels again
+    assert seen[0][3] == 1 and all(c[2] == 0 and c[3] == 0 for c in seen[1:]), seen   # the first is unmatched (streak restarted at 1, not 9), the rest match
+    assert [c[1] for c in seen[2:]] == [1, 1, 1], seen                       # an order from the batch's third launch on
     # a batch that DOES repeat on another shape is unaffected (histories are per shape)
     m = n - 4096
     for rep in range(4):
@@ -726,5 +750,45 @@ def test_batches_that_never_repeat_stop_paying_for_the_claim_order(rc, oracle):
         t.trace_device(dev[0].data_ptr(), out.data_ptr(), m)
         torch.cuda.synchronize()
         assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT)[:m], want[0][:m], f"repeating shape, launch {rep + 1}")
+    assert t.get_option("claim_drift") == 0
+    t.free()
+
+
+
+def test_a_camera_that_moves_every_frame_stops_paying_for_the_claim_order(rc, oracle):
+    """a camera that moves a little every frame is recognised as the batch of the frame before (its slot's order is reused)
+    -- and ran 1.5-2 % SLOWER than with the order switched off, because an order learned from similar rays gains less than the three small
+    dispatches in front of the launch cost.  k_order_select therefore counts the launches that are not REPEATS (identical sample rays) of a
+    remembered batch; after eight of them the shape's launches go out without the order kernels for a while.  A still camera keeps its order."""
+    import ctypes
+    import torch
+    sc = rc.scenes
+    cfg = sc.config_c3(lattice=(4, 4, 2))
+    t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+    centre = cfg["lattice_centre"]
+    eye0 = centre + np.array([0.0, 0.0, -12.0])
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def header():
+        h = torch.empty(40, dtype=torch.int32, device="cuda")
+        hip.hipMemcpy(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(t.get_option("debug_ctl_ptr")), ctypes.c_size_t(160), 3)
+        torch.cuda.synchronize()
+        w = h.cpu().numpy().view(np.uint32)
+        return int(w[3]), int(w[1]), int(w[4]), int(w[36])   # launch clock, order valid, fresh, streak of non-repeats
+
+    def frame(eye, what):
+        rays = sc.pinhole_rays(1280, 800, eye, centre, 45.0)
+        d = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+        out = torch.zeros(len(rays) * 32, dtype=torch.uint8, device="cuda")
+        t.trace_device(d.data_ptr(), out.data_ptr(), len(rays))
+        torch.cuda.synchronize()
+        assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), o.trace(rays, nthreads=16), what)
+        return header()
+    seen = [frame(eye0, f"still camera, launch {k + 1}") for k in range(4)]
+    assert [c[0] for c in seen] == [1, 2, 3, 4] and [c[3] for c in seen] == [1, 0, 0, 0] and seen[3][1] == 1, seen   # repeats: the order is in use, the streak stays at 0
+    seen = [frame(eye0 + np.array([0.02 * f, 0.01 * f, 0.0]), f"moving camera, frame {f}") for f in range(1, 13)]
+    assert [c[0] for c in seen[:8]] == list(range(5, 13)) and all(c[2] == 0 for c in seen[:8]), seen                 # matched (never fresh), through the order kernels
+    assert [c[3] for c in seen[:8]] == list(range(1, 9)), seen                                                        # ... but not repeats
+    assert all(c[0] == 12 for c in seen[8:]), seen                                                                    # frames 9-12: natural order, no order kernels
     assert t.get_option("claim_drift") == 0
     t.free()
