@@ -1,0 +1,115 @@
+"""Python restatement of the batch-slot state machine of cost-ordered claiming (test infrastructure).
+
+The product side is split between the host (rc_cost_order_setup, raycore.jl_amd/csrc/rc_traverse.hip: which launches go through the order
+kernels at all) and the device (k_order_select: which of the history's four batch slots a launch belongs to, and what the launch does with
+it).  A wrong transition cannot change a hit -- the claim order is result-neutral -- but it can silently turn the feature into overhead, so
+the transitions are restated here, driven with scripted launch sequences, and compared word for word with the header words the device
+leaves behind (tests/test_gpu_order_model.py); tests/test_order_model.py checks the restatement's own promises on the CPU.
+
+A launch is described by what k_order_select can see of it: `batch` (any hashable: launches with equal ids trace identical rays) and
+`near` (a set of batch ids whose sample rays are within the matching threshold of this launch's without being identical: the frame before
+of a moving camera).  Data-dependent words (the reporting threshold and the scale of the cost classes, kHistScale / kHistLifeThr's value)
+are outside the model: it says WHETHER a launch records, not with which threshold.
+"""
+
+K_SLOTS = 4                    # kHistSlots
+RECORD_EVERY = 8               # kHistRecordEvery
+GIVE_UP_AFTER, GIVE_UP_FOR = 8, 64   # rc_cost_order_setup
+
+# header words of the history (rc_traverse_core.h kHist*)
+SEL, ORDER_VALID, LIFE_THR, CLOCK, FRESH, REBUILD = 0, 1, 2, 3, 4, 5
+STAMP, GEN, PENDING, STREAK = 8, 12, 32, 36
+
+
+class Mutations:
+    """knobs for the mutants the comparison has to catch"""
+    order_valid_from = 3       # the slot's third launch builds its first order
+    record_first, record_last = 2, 4
+    repeats_only = True        # the streak counts launches that are not exact repeats (False: round 4's rule, unmatched launches only)
+
+
+class History:
+    """One launch shape's history: device header + the host's pause logic.  launch() returns the header words the device holds after the
+    launch (a dict of the modelled words), or None when the host left the order kernels out."""
+
+    def __init__(self, mut=None):
+        self.m = mut or Mutations()
+        self.clock = 0
+        self.stamp = [0] * K_SLOTS
+        self.gen = [0] * K_SLOTS
+        self.pending = [0] * K_SLOTS
+        self.batch = [None] * K_SLOTS      # whose sample rays the slot holds
+        self.streak = 0                    # device copy (kHistFreshStreak)
+        self.host_streak = 0               # the pinned word as the host last saw it
+        self.skip_left = 0
+        self.host_gen = 0                  # launches of the shape that went through the order kernels
+        self.last = None
+
+    def launch(self, batch, near=()):
+        # ---- host: rc_cost_order_setup ----
+        if self.skip_left > 0:
+            self.skip_left -= 1
+            return None
+        if self.host_streak >= GIVE_UP_AFTER:
+            self.host_streak = 0
+            self.streak = 0                # hipMemsetAsync of the device's word
+            self.skip_left = GIVE_UP_FOR - 1
+            return None
+        self.host_gen += 1
+        # ---- device: k_order_select ----
+        best, exact = None, False
+        for k in range(K_SLOTS):           # the closest slot below the threshold; an identical batch has distance 0 and wins
+            if self.stamp[k] == 0:
+                continue
+            if self.batch[k] == batch:
+                best, exact = k, True
+                break
+            if best is None and self.batch[k] in near:
+                best = k
+        fresh = best is None
+        if fresh:                          # an empty slot, else the least recently used (lowest stamp; first of equals)
+            sel = min(range(K_SLOTS), key=lambda k: (self.stamp[k], k))
+        else:
+            sel = best
+        self.batch[sel] = batch            # the slot's samples follow the batch
+        self.clock += 1
+        self.stamp[sel] = self.clock
+        gen = 1 if fresh else self.gen[sel] + 1
+        self.gen[sel] = gen
+        if fresh:
+            self.pending[sel] = 0
+        rebuild = self.pending[sel] != 0
+        record = (self.m.record_first <= gen <= self.m.record_last) or gen % RECORD_EVERY == 0
+        valid = gen >= self.m.order_valid_from
+        self.pending[sel] = 1 if record else 0
+        not_counted = exact if self.m.repeats_only else not fresh
+        self.streak = 0 if not_counted else self.streak + 1
+        self.host_streak = self.streak     # (the test waits for every launch: the pinned word is current at the next one)
+        self.last = {"sel": sel, "order_valid": int(valid), "records": int(record), "clock": self.clock, "fresh": int(fresh), "rebuild": int(rebuild),
+                     "stamp": list(self.stamp), "gen": list(self.gen), "pending": list(self.pending), "streak": self.streak}
+        return dict(self.last)
+
+
+def device_words(w):
+    """the modelled words out of a dump of the first 40 header words (numpy uint32)"""
+    return {"sel": int(w[SEL]), "order_valid": int(w[ORDER_VALID]), "records": int(w[LIFE_THR] != 0xFFFFFFFF), "clock": int(w[CLOCK]), "fresh": int(w[FRESH]),
+            "rebuild": int(w[REBUILD]), "stamp": [int(x) for x in w[STAMP:STAMP + K_SLOTS]], "gen": [int(x) for x in w[GEN:GEN + K_SLOTS]],
+            "pending": [int(x) for x in w[PENDING:PENDING + K_SLOTS]], "streak": int(w[STREAK])}
+
+
+def scripts():
+    """name -> list of (batch, near) launches.  Batches are identified by the index of a camera position; ("m", f) = frame f of a camera that
+    moves a little per frame from position 0 (frame f is near frame f - 1, and frame 1 is near position 0)."""
+    def still(b, n):
+        return [(b, ())] * n
+
+    def moving(first, n):
+        return [(("m", f), ((("m", f - 1),) if f > 1 else (0,))) for f in range(first, first + n)]
+    return {
+        "A x 12": still(0, 12),
+        "A B A B": [(k % 2, ()) for k in range(16)],
+        "A B C D E rotation (five batches, four slots)": [(k % 5, ()) for k in range(15)],
+        "still, then a moving camera, then still again": still(0, 4) + moving(1, 12) + [(0, (("m", 12),))] + still(0, 3),   # (position 0 is still within the threshold of where the camera stopped)
+        "never repeating, the pause, then a repeating batch": [(100 + k, ()) for k in range(10)] + [(200 + k, ()) for k in range(62)] + still(3, 6),
+        "A A B B B A A A A": still(0, 2) + still(1, 3) + still(0, 4),
+    }
