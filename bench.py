@@ -239,20 +239,23 @@ def main():
 
     # Untimed: bring the GPU clocks up before the W warm-up steps (a cold MI355X runs its first few dozen milliseconds of kernels
     # ~10 % slower; with small W and K that would be what gets timed).
-    for _ in range(40):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
+    with rc.profile_range("headline:warmup"):
+        for _ in range(40):
+            step()
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
+    rc.lib().rc_range_push(b"headline:timed_steps")
     for a, b in ev:
         a.record(stream)
         step()
         b.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    rc.lib().rc_range_pop()
     launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -272,7 +275,8 @@ def main():
     def guarded_extra(name, fn):
         """An extra measurement must never cost the headline line: failures are recorded, not raised."""
         try:
-            fn()
+            with rc.profile_range("extra:" + name):   # roctx: `rocprofv3 --marker-trace --kernel-trace` attributes the dispatches to the extras
+                fn()
         except Exception as e:  # noqa: BLE001
             extras[name + "_error"] = f"{type(e).__name__}: {e}"[:300]
 
@@ -282,16 +286,17 @@ def main():
         rooflines = {}
         last_ms = {}
 
-        def timed(scene, rs, mode, reps=3, key=None):
+        def timed(scene, rs, mode, reps=3, key=None, label=None):
             """Rate of the batch repeated on one stream.  reps <= 5: best launch (cost_order off, or one-off measurements).  More: the batch's
             steady state = the MEAN of its last 8 launches -- a whole recording cycle of the learned claim order (one launch in 8 records costs
             and runs ~7 % slower, the next re-sorts) -- so that the figure is what a render loop averages, not its best frame."""
             dr = torch.from_numpy(rs.view(np.uint8).reshape(-1)).cuda()
             dh = torch.empty(len(rs) * 32, dtype=torch.uint8, device="cuda")
             ms = []
-            for _ in range(reps):
-                scene.trace_device(dr.data_ptr(), dh.data_ptr(), len(rs), mode=mode, stream=stream.cuda_stream)
-                ms.append(scene.last_kernel_ms())
+            with rc.profile_range(f"workload:{label or key or mode}:{len(rs)}x{reps}"):
+                for _ in range(reps):
+                    scene.trace_device(dr.data_ptr(), dh.data_ptr(), len(rs), mode=mode, stream=stream.cuda_stream)
+                    ms.append(scene.last_kernel_ms())
             use = float(np.mean(ms[-8:])) if reps > 5 else min(ms)
             if key:
                 last_ms[key] = {"mean_of_last_8_ms": round(float(np.mean(ms[-8:])), 4), "best_ms": round(min(ms), 4), "launches": reps}
@@ -375,7 +380,7 @@ def main():
         shadow = sc.c3_shadow_rays(cfg, rays, hits)
         extras["c3_any_hit_shadow_mrays_s"] = timed(t, shadow, "any", reps=12, key="shadow")
         t.set_option("cost_order", 0)
-        extras["c3_any_hit_shadow_first_launch_mrays_s"] = timed(t, shadow, "any", reps=5)
+        extras["c3_any_hit_shadow_first_launch_mrays_s"] = timed(t, shadow, "any", reps=5, label="shadow_first_launch")
         t.set_option("cost_order", 1)
         bounce = sc.c4_bounce_rays(cfg, rays, hits, 4 * n)
         extras["c4_incoherent_16M_closest_mrays_s"] = timed(t, bounce, "closest", reps=12, key="c4")
@@ -414,7 +419,7 @@ def main():
         # on the chunks are claimed in the order learned from the launch before (cost-ordered claiming).  A batch traced for the
         # first time has nothing to go by: that rate is measured with the option off.
         t2.set_option("cost_order", 0)
-        extras["c2_100k_blas_1M_coherent_closest_first_launch_mrays_s"] = timed(t2, rays2, "closest", reps=5)
+        extras["c2_100k_blas_1M_coherent_closest_first_launch_mrays_s"] = timed(t2, rays2, "closest", reps=5, label="c2_first_launch")
         t2.set_option("cost_order", 1)
         extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(t2, rays2, "closest", reps=12, key="c2")
         extras["c2_100k_blas_1M_coherent_closest_4_in_flight_mrays_s"] = in_flight(t2, rays2)
@@ -449,7 +454,7 @@ def main():
                 tb.push_instances(b, xf, ids)
             tb.sync()
             big[str(int(np.prod(lattice)))] = {"triangles": tb.n_primitives() * tb.n_instances(),
-                                               "mrays_s": timed(tb, sc.c3_primary_rays(cfgb, args.res, args.res), "closest", reps=12),
+                                               "mrays_s": timed(tb, sc.c3_primary_rays(cfgb, args.res, args.res), "closest", reps=12, label=f"c3_{int(np.prod(lattice))}_instances"),
                                                "tlas_top_k": tb.get_option("tlas_top_k"), "blas_top_k": tb.get_option("blas_top_k")}
             tb.free()
         extras["c3_blas_more_instances_closest"] = big
@@ -466,9 +471,9 @@ def main():
             del dv
             rg = rc.generate_ray_grid(tb, (0.3, 0.2, 1.0), 1000)
             tb.set_option("cost_order", 0)
-            first = timed(tb, rg, "closest", reps=3)
+            first = timed(tb, rg, "closest", reps=3, label=f"random_{nt}_first_launch")
             tb.set_option("cost_order", 1)
-            rate = timed(tb, rg, "closest", reps=12, key="r1m" if nt == 1_000_000 else None)
+            rate = timed(tb, rg, "closest", reps=12, key="r1m" if nt == 1_000_000 else None, label=f"random_{nt}")
             ref[str(nt)] = {"mrays_s": rate, "first_launch_mrays_s": first, "ms_per_1M_rays": round(1e3 / rate, 3), "mrays_s_4_in_flight": in_flight(tb, rg), "reference_rx7900xtx_ms": ref_ms}
             tb.free()
         extras["random_geometry_1M_rays_closest"] = ref
@@ -487,9 +492,9 @@ def main():
         tb.push_instances(1)
         tb.sync()
         del dv
-        rate = timed(tb, inc, "closest", reps=12)
+        rate = timed(tb, inc, "closest", reps=12, label="hbm_regime_4M_tris", key="hbm")
         tb.set_option("kernel", 3); tb.set_option("stats", 1)
-        timed(tb, inc, "closest", reps=1)
+        timed(tb, inc, "closest", reps=1, label="hbm_regime_4M_tris_stats_kernel3")
         st = [tb.get_option(f"stat{i}") for i in range(8)]
         tb.set_option("stats", 0); tb.set_option("kernel", -1)
         tb.free()

@@ -101,6 +101,13 @@ typedef struct rc_prim { /* the part of Triangle{UInt32} the path reads (src/tri
 typedef struct rc_scene rc_scene; /* opaque; plays the role of the mutable TLAS (src/instanced-bvh.jl:261-310) */
 
 const char* rc_last_error(void);
+/* Tracing (the reference's method: docs/src/hw_acceleration.md:198-218 times phases by hand; SURVEY.md section 5 asks for roctx ranges).  Every
+ * entry point below is one roctx range named after itself while a marker library (rocprofiler-sdk's roctx, else libroctx64) can be loaded
+ * and RC_ROCTX is not "0"; a caller brackets its own phases with these two, so that `rocprofv3 --marker-trace --kernel-trace` attributes
+ * dispatches to phases.  Both always succeed (no-ops without a marker library); rc_ranges_enabled: 1 when ranges are being emitted. */
+int rc_range_push(const char* name);
+int rc_range_pop(void);
+int rc_ranges_enabled(void);
 /* Number of visible HIP devices (0 when none); never fails. */
 int rc_device_count(void);
 

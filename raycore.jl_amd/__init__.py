@@ -14,3 +14,23 @@ from .api import (BLAS4, CONTACT_DT, CollisionResult, ContactPair, collide_insta
 def device_count():
     """Number of visible HIP devices according to the library (0 without a GPU)."""
     return lib().rc_device_count()
+
+
+class profile_range:
+    """`with profile_range("shade"):` -- one roctx range around a caller's phase (every entry point of the library is a range of its own; see
+    rc_range_push in include/raycore_mi355x.h).  A no-op without a marker library or with RC_ROCTX=0."""
+
+    def __init__(self, name):
+        self.name = name.encode("utf-8")
+
+    def __enter__(self):
+        lib().rc_range_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        lib().rc_range_pop()
+        return False
+
+
+def ranges_enabled():
+    return bool(lib().rc_ranges_enabled())

@@ -39,6 +39,9 @@ _vp, _u32, _u64, _i64, _int = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.c
 _pu32, _pint, _pf = C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_float)
 SYMBOLS = [
     ("rc_last_error", C.c_char_p, []),
+    ("rc_range_push", C.c_int, [C.c_char_p]),
+    ("rc_range_pop", C.c_int, []),
+    ("rc_ranges_enabled", C.c_int, []),
     ("rc_device_count", _int, []),
     ("rc_scene_create", _int, [_int, C.POINTER(_vp)]),
     ("rc_scene_destroy", _int, [_vp]),

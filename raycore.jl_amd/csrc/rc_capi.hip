@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <dlfcn.h>
 #include <sys/mman.h>
 
 #include "../../include/raycore_mi355x.h"
@@ -37,9 +38,40 @@ int fail(int code, const std::string& msg) {
 // capture that would need one.)
 using CaptureRelaxed = RcCaptureRelaxed;  // rc_internal.h
 
+// roctx ranges (SURVEY.md section 5 "Tracing / profiling"): every entry point that goes through guarded() is one range named
+// after the entry point, so that `rocprofv3 --marker-trace --kernel-trace` attributes a run's dispatches to the calls that made them; a
+// caller brackets its own phases with rc_range_push / rc_range_pop (bench.py does, per extra).  The marker library is looked up at run time
+// -- rocprofiler-sdk's roctx first (what rocprofv3 listens to), the legacy libroctx64 second -- and never linked: without it, or with
+// RC_ROCTX=0, a range costs one predictable branch.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* off = getenv("RC_ROCTX");
+        if (off && off[0] == '0') return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(name, RTLD_LAZY | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+struct RcRange {
+    bool on;
+    explicit RcRange(const char* name) : on(roctx().push != nullptr) { if (on) (void)roctx().push(name); }
+    ~RcRange() { if (on) (void)roctx().pop(); }
+    RcRange(const RcRange&) = delete;
+    RcRange& operator=(const RcRange&) = delete;
+};
+
 template <typename F>
-int guarded(F&& f) {
+int guarded(F&& f, const char* entry_point = __builtin_FUNCTION()) {
     CaptureRelaxed relaxed;
+    RcRange range(entry_point);
     try {
         f();
         return RC_OK;
@@ -203,6 +235,17 @@ void bad_file(const char* what) { throw RcError(RC_ERR_INVALID_ARGUMENT, std::st
 extern "C" {
 
 const char* rc_last_error(void) { return g_last_error.c_str(); }
+
+int rc_range_push(const char* name) {
+    if (!name) return fail(RC_ERR_INVALID_ARGUMENT, "rc_range_push: null name");
+    if (roctx().push) (void)roctx().push(name);
+    return RC_OK;
+}
+int rc_range_pop(void) {
+    if (roctx().pop) (void)roctx().pop();
+    return RC_OK;
+}
+int rc_ranges_enabled(void) { return roctx().push != nullptr ? 1 : 0; }
 
 int rc_device_count(void) {
     int n = 0;

@@ -21,6 +21,18 @@ end
 MI355XBackend() = MI355XBackend(0)
 
 last_error() = unsafe_string(ccall((:rc_last_error, LIB), Cstring, ()))
+# roctx ranges around a caller's own phases (every entry point of the library is a range of its own): `range("shade") do ... end`
+range_push(name::AbstractString) = ccall((:rc_range_push, LIB), Cint, (Cstring,), name)
+range_pop() = ccall((:rc_range_pop, LIB), Cint, ())
+ranges_enabled() = ccall((:rc_ranges_enabled, LIB), Cint, ()) != 0
+function range(f, name::AbstractString)
+    range_push(name)
+    try
+        return f()
+    finally
+        range_pop()
+    end
+end
 # every non-zero status becomes ErrorException, the type the reference's tests expect
 # (test/test_tlas_stress.jl:585-617: @test_throws ErrorException update_transform!(tlas, deleted_handle, ...))
 check(status::Cint) = status == 0 ? nothing : error(last_error())
