@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_ACHIEVABLE_GBS = 6300.0  # same guide: ~6.3 TB/s achievable
 # The guide's execution model: a wave64 VALU instruction issues over 2 cycles on the SIMD-32 (157.3 TF f32 vector peak):
 # 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instructions / s.  (Round 2 divided by 4 cycles -- the measured cost of v_mul / v_add /
 # v_mov -- which the builder's own probe contradicts for v_fma_f32; the per-opcode measurements now enter through `mix_ceiling`.)
@@ -43,7 +44,6 @@ VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
 COUNTER_FILE = os.path.join("profiles", "r04_pmc_c3.json")          # per-launch PMC counters of the bench kernel (tools/capture_profiles.sh)
 WORKLOADS_FILE = os.path.join("profiles", "r04_pmc_workloads_kernel5.json")  # the same counters for the extras' workloads: C2, shadow rays, C4, random geometry, C3 1 Mi rays (tools/pmc_workloads.sh)
 MIX_FILE = os.path.join("profiles", "r04_isa_mix_kernel5.json")     # dynamic opcode histogram of the bench kernel x measured cycles per opcode (tools/isa_mix.py)
-HBM_REGIME_FILE = os.path.join("profiles", "r03_hbm_regime.json")   # tools/gpu_hbm_regime.sh
 COUNTS_FILE = os.path.join("profiles", "c3_reference_counts.json")  # reference-algorithm fetch counts per ray for this workload (written by the N=1 run)
 # Fallback when the counts file is missing (same numbers, measured by the oracle in round 1)
 C3_NODE_FETCHES_PER_RAY = 33.006
@@ -118,6 +118,34 @@ def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_
                                       "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "node_fetches_per_ray": round(node_f, 3), "instance_entries_per_ray": round(inst_f, 3),
                                       "note": "SURVEY section 8d's figure; > 1 because the reference algorithm's node / instance bytes are served from LDS, L1 and L2, not HBM"}
     return roofline
+
+
+def make_hbm_regime(rate_mrays_s, node_fetches_per_ray, n_rays, launch_ms, entry, fingerprint_ok, source=WORKLOADS_FILE):
+    """The HBM-bound extra: rate and node fetches measured live; physical HBM bytes per launch from the workload's FETCH_SIZE /
+    WRITE_SIZE passes in the per-workload counter file -- used only when that file's fingerprint matches the kernel sources of this run.
+    `roofline` is the object the bench contract asks for with bound "hbm": achieved = physical bytes / launch time."""
+    alg = (64 + 60.0 * node_fetches_per_ray + 140.0) * n_rays
+    secs = n_rays / (rate_mrays_s * 1e6)
+    out = {"mrays_s": rate_mrays_s, "node_fetches_per_ray": round(node_fetches_per_ray, 2), "algorithmic_GBs": round(alg / secs / 1e9, 1)}
+    h = (entry or {}).get("hbm") if fingerprint_ok else None
+    if not h:
+        out.update({"hbm_physical_GBs": None, "hbm_physical_frac": None, "fetch_amplification": None, "roofline": None,
+                    "note": f"{source} missing, without the 'hbm' workload, or captured from other kernel sources (fingerprint): run tools/pmc_workloads.sh"})
+        return out
+    # FETCH_SIZE counts 64 bytes per request: x1 for this workload's random 64-byte node gathers (profiles/r02_fetch_calibration.txt; the
+    # guide's x2 applies to wide coalesced streams -- here only the 268 MB of rays and hits, which x1 under-counts by at most 134 MB)
+    phys = h["read_bytes_x1"] + h["write_bytes"]
+    gbs = phys / secs / 1e9
+    out.update({"hbm_physical_GBs": round(gbs, 1), "hbm_physical_frac": round(gbs / HBM_PEAK_GBS, 4), "fetch_amplification": round(phys / alg, 3),
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                             "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_GBs": HBM_ACHIEVABLE_GBS, "traffic": phys,
+                             "avg_launch_ms": round(secs * 1e3, 4), "launch_ms_hip_events": launch_ms,
+                             "kernel": ((entry.get("kernel") or {}).get("Kernel_Name")),
+                             "sources": {"traffic": source + " workloads.hbm.hbm: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over tools/perf_probe.py --workloads hbm "
+                                                            "(tools/pmc_workloads.sh), mean of the last three launches; fingerprint matches this run's kernel sources",
+                                         "launch time, node fetches": "this run (mean of the batch's last 8 launches; the STATS build of kernel 3 for the fetch count)",
+                                         "peak / achievable": "MI355X_MICROARCH.md: HBM3E 8 TB/s peak, ~6.3 TB/s achievable"}}})
+    return out
 
 
 def make_workload_roofline(entry, launch_ms, n_rays, fingerprint_ok, source=WORKLOADS_FILE):
@@ -206,10 +234,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         import datetime
         limit = datetime.timedelta(seconds=300)  # a rank that leaves the collective sequence makes the others fail, not hang
+        c0 = time.perf_counter()
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"), timeout=limit)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=limit)
+        comm_init_ms = (time.perf_counter() - c0) * 1e3   # rendezvous + communicator (a fixed cost, printed next to the timed calls, never inside them)
+    else:
+        comm_init_ms = 0.0
 
     import raycore_jl_amd as rc
     sc = rc.scenes
@@ -480,7 +512,7 @@ def main():
         torch.cuda.empty_cache()
         # An HBM-bound regime (the only place BASELINE's "HBM roofline" wording is testable): a 4 M-triangle BLAS -- a 512 MB node array,
         # far beyond L2 + Infinity Cache -- and 4 M incoherent rays.  Rate and node fetches (the product's instrumented kernel) are
-        # measured here; the physical HBM bytes per launch come from the rocprofv3 passes in profiles/r02_hbm_regime.json.
+        # measured here; the physical HBM bytes per launch come from the workload's FETCH_SIZE / WRITE_SIZE passes in WORKLOADS_FILE (make_hbm_regime).
         g = np.random.default_rng(7)
         ro = g.random((n, 3))
         rd = g.standard_normal((n, 3))
@@ -493,6 +525,7 @@ def main():
         tb.sync()
         del dv
         rate = timed(tb, inc, "closest", reps=12, label="hbm_regime_4M_tris", key="hbm")
+        hbm_launch_ms = last_ms["hbm"]["mean_of_last_8_ms"]
         tb.set_option("kernel", 3); tb.set_option("stats", 1)
         timed(tb, inc, "closest", reps=1, label="hbm_regime_4M_tris_stats_kernel3")
         st = [tb.get_option(f"stat{i}") for i in range(8)]
@@ -501,14 +534,7 @@ def main():
         fetches = (st[3] + st[5]) / n + 1.0
         alg = (64 + 60.0 * fetches + 140.0) * n
         secs = n / (rate * 1e6)
-        prof = (load_json(HBM_REGIME_FILE) or load_json(os.path.join("profiles", "r02_hbm_regime.json")) or {}).get("scenes", {}).get("4000000", {})
-        phys = prof.get("hbm_read_bytes_per_launch", 0) + prof.get("hbm_write_bytes_per_launch", 0)
-        extras["hbm_regime_4M_tris_4M_incoherent_rays"] = {
-            "mrays_s": rate, "node_fetches_per_ray": round(fetches, 2), "algorithmic_GBs": round(alg / secs / 1e9, 1),
-            "hbm_physical_GBs": round(phys / secs / 1e9, 1) if phys else None, "hbm_physical_frac": round(phys / secs / 1e9 / HBM_PEAK_GBS, 4) if phys else None,
-            "fetch_amplification": round(phys / alg, 3) if phys else None,
-            "sources": {"hbm bytes per launch": HBM_REGIME_FILE + " (tools/gpu_hbm_regime.sh: rocprofv3 FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE calibrated x1 for random 64-byte gathers, profiles/r02_fetch_calibration.txt)",
-                        "rate, node fetches": "this run"}}
+        extras["hbm_regime_4M_tris_4M_incoherent_rays"] = make_hbm_regime(rate, fetches, n, hbm_launch_ms, (wl_file.get("workloads") or {}).get("hbm"), wl_ok)
         torch.cuda.empty_cache()
         extras["rooflines"] = {"note": "per extra workload: VALU issue against the guide's 2-cycle peak from the per-launch counters of " + WORKLOADS_FILE +
                                        " and the launch time measured in this run (the workload's steady-state mean); recomputed by tests/test_bench_roofline.py",
@@ -600,10 +626,12 @@ def main():
         # u32 = 10 GB) through the multi-GPU driver: every rank takes part; both partitions are timed.
         from raycore_jl_amd import distributed as rd
         cfg5 = sc.config_c5()
+        v0 = time.perf_counter()
         t5 = rc.TLAS(local_rank)
         t5.add_geometry(*cfg5["blas"][0])
         t5.push_instances(1, cfg5["instances"][0][1], cfg5["instances"][0][2])
         t5.sync()
+        replicate_ms = (time.perf_counter() - v0) * 1e3   # every rank uploads and builds its own copy of the scene, side by side
         n5, rpt = t5.n_primitives(), cfg5["rays_per_triangle"]
         vf = {"n_prims": n5, "rays_per_triangle": rpt, "n_rays": n5 * rpt, "matrix_bytes": 4 * n5 * n5}
         t5._prims()  # metadata read-back outside the timed region
@@ -631,7 +659,11 @@ def main():
             torch.cuda.empty_cache()
         # The per-triangle totals (column / row sums of the matrix; what the reference's users read off it) with the RAYS sharded over the
         # ranks and ONE reduce of 2 N int64 (RCCL ncclReduce over xGMI when world > 1): no N x N array, no PCIe floor.
-        rd.view_factor_totals_distributed(t5, 4, 7)
+        fence()
+        v0 = time.perf_counter()
+        rd.view_factor_totals_distributed(t5, 4, 7)       # the first reduce of the process group: RCCL's channel / xGMI connection set-up
+        fence()
+        first_reduce_ms = (time.perf_counter() - v0) * 1e3
         best_tot, tot = 1e30, None
         for _ in range(3):
             fence()
@@ -651,6 +683,9 @@ def main():
             assert np.array_equal(tot[0], one_r) and np.array_equal(tot[1], one_e), "rays-sharded totals differ from the one-GPU totals"
             vf["totals_rays_sharded"] = {"seconds": round(best_tot, 4), "Mrays_s": round(n5 * rpt / best_tot / 1e6, 1), "counted": int(tot[0].sum()), "ranks": world,
                                          "reduce_bytes": 16 * n5, "kernel_ms_rank0": round(t5.last_kernel_ms(), 3),
+                                         # the fixed costs, itemised and OUTSIDE `seconds`
+                                         "totals_ms": round(best_tot * 1e3, 3), "comm_init_ms": round(comm_init_ms, 2), "replicate_ms": round(replicate_ms, 2),
+                                         "first_reduce_ms": round(first_reduce_ms, 2), "rccl_ranks": world if (use_dist and args.backend == "nccl") else 0,
                                          "note": "received[N] + emitted[N] (u64) accumulated on the device, rays sharded over the ranks, one reduce; equals the matrix's column / row sums"}
             vf["totals_rays_sharded"]["equals_one_gpu"] = True  # (asserted above, element by element)
         if world == 1:
@@ -725,11 +760,18 @@ def main():
         # (1) view_factors into a host matrix, ROWS: every device brings its row block home over its own PCIe link, no collective
         cfg5 = sc.config_c5()
         scenes5 = []
+        v0 = time.perf_counter()
         for d in devices:
             t = rc.TLAS(d)
             t.add_geometry(*cfg5["blas"][0])
             t.push_instances(1, cfg5["instances"][0][1], cfg5["instances"][0][2])
             scenes5.append(t.sync())
+        replicate_ms = (time.perf_counter() - v0) * 1e3                # upload + BLAS / TLAS build of the scene, once per device, one after the other
+        # the fixed costs of a set of devices, outside every timed call below and itemised: RCCL + communicator, streams, staging, warm-up collective
+        prep = rc.multi_prepare(scenes5)
+        md["fixed_costs_ms"] = {"replicate_scene_on_all_devices": round(replicate_ms, 2), "comm_init": round(prep["comm_init_ms"], 2),
+                                "streams_and_buffers": round(prep["streams_and_buffers_ms"], 2), "warmup_collective": round(prep["warmup_collective_ms"], 2),
+                                "rccl_ranks": prep["rccl_ranks"]}
         n5, rpt = scenes5[0].n_primitives(), cfg5["rays_per_triangle"]
         out_m = np.empty((n5, n5), dtype=np.uint32, order="F")
         rc.view_factors(scenes5[0], rpt, 7, out=out_m)            # one device; also faults the matrix in
@@ -748,12 +790,14 @@ def main():
         t1 = tn = 1e30
         for _ in range(3):
             v0 = time.perf_counter(); rc.view_factor_totals(scenes5[0], rpt, 7); t1 = min(t1, time.perf_counter() - v0)
-        rc.view_factor_totals_multi(scenes5, 4, 7)                 # communicator set-up outside the timed calls
+        dev_ms = 1e30
         for _ in range(3):
             v0 = time.perf_counter(); rg, eg = rc.view_factor_totals_multi(scenes5, rpt, 7); tn = min(tn, time.perf_counter() - v0)
+            dev_ms = min(dev_ms, scenes5[0].last_kernel_ms())       # first launch -> reduced vectors on device 0, on device 0's clock (trace + reduce only)
         same = bool(np.array_equal(r1, rg) and np.array_equal(e1, eg)) and int(rg.sum()) == want
         md["view_factor_totals_c5"] = {"one_device_s": round(t1, 4), "all_devices_rays_s": round(tn, 4), "speedup": round(t1 / tn, 2), "same_vectors": same,
-                                       "rccl_ranks": 0 if forced > 1 else len(devices), "reduce_bytes": 16 * n5,
+                                       "totals_ms": round(tn * 1e3, 3), "totals_device_ms": round(dev_ms, 3), "comm_init_ms": round(prep["comm_init_ms"], 2), "replicate_ms": round(replicate_ms, 2),
+                                       "rccl_ranks": prep["rccl_ranks"], "reduce_bytes": 16 * n5,
                                        "checksum": zlib.crc32(rg.tobytes() + eg.tobytes()), "checksum_one_device": zlib.crc32(r1.tobytes() + e1.tobytes())}
         assert same, "view_factor_totals_multi differs from one device"
         # (1c) RAYS on the full matrix (the 10 GB ncclReduce, < 1x by DESIGN 5's own budget) only as a correctness run on distinct devices

@@ -215,9 +215,9 @@ int rc_generate_ray_grid_device(rc_scene* scene, const float viewdir[3], uint32_
 /* get_illumination(tlas, viewdir; grid_size) (src/kernels.jl:112-124): out_counts = n_prims f32 (host). */
 int rc_get_illumination(rc_scene* scene, const float viewdir[3], uint32_t grid, float* out_counts);
 /* Rays [ray_begin, ray_end) of the grid only, accumulated into a device histogram (n_prims f32) --
- * the shard unit for multi-GPU runs.  d_counts is updated by a plain add at the end of the launch (the kernel counts
- * into private copies of the histogram: a few large, well-lit triangles take most of the hits): shards enqueued on ONE stream add up, shards
- * enqueued on different streams at the same time need histograms of their own.  A count saturates at 2^24 like the reference's f32 `+= 1`. */
+ * the shard unit for multi-GPU runs.  The kernel counts into private copies of the histogram (a few large, well-lit
+ * triangles take most of the hits) and adds them to d_counts ATOMICALLY at the end of the launch: shards add up whether they are enqueued
+ * on one stream or run concurrently on several.  A count saturates at 2^24 like the reference's f32 `+= 1`. */
 int rc_get_illumination_device(rc_scene* scene, const float viewdir[3], uint32_t grid, uint64_t ray_begin,
                                uint64_t ray_end, float* d_counts, void* stream);
 
@@ -273,10 +273,10 @@ int rc_view_factors_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_p
  * rule as view_factors! (src/kernels.jl:93-97), so the vectors equal the sums of rc_view_factors' matrix exactly; u64, n_prims each;
  * either pointer may be NULL.  No N x N array exists anywhere: the call costs the tracing (C5: ~40 ms), not 10 GB over PCIe.
  * _device: rays [ray_begin, ray_end) of the sources with flat primitive indices [src_begin, src_end), ACCUMULATED into device vectors
- *   (the shard unit of a multi-process run: torch.distributed reduce of 2 N int64).  d_received is updated by a plain add at the end of the
- *   launch (the kernel counts into private copies of the vector: a few large triangles receive most rays of a closed scene, and atomics
- *   onto a few hundred cache lines run at half the rate of scattered ones): shards on ONE stream accumulate correctly, shards enqueued on
- *   different streams at the same time need vectors of their own.
+ *   (the shard unit of a multi-process run: torch.distributed reduce of 2 N int64).  The kernel counts into private copies of the received
+ *   vector (a few large triangles receive most rays of a closed scene, and per-ray atomics onto a few hundred cache lines run at half the
+ *   rate of scattered ones) and adds them to d_received atomically at the end of the launch; d_emitted takes one atomic per wave and source:
+ *   shards accumulate correctly on one stream or concurrently on several.
  * _multi: scenes[g] = synced copies of one scene on DISTINCT devices; device g shoots ray indices [g R / G, (g+1) R / G) of every
  *   source and ONE ncclReduce (ncclUint64, sum, 2 N elements, over xGMI; librccl.so loaded on first use) brings the vectors to
  *   scenes[0]'s device -- "rays sharded across the GPUs with an RCCL reduce of the per-triangle accumulators" (SURVEY.md 8e).  Scenes
@@ -286,6 +286,14 @@ int rc_view_factor_totals_device(rc_scene* scene, uint32_t rays_per_triangle, ui
                                  uint32_t ray_begin, uint32_t ray_end, uint64_t* d_received, uint64_t* d_emitted, void* stream);
 int rc_view_factor_totals_multi(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint64_t* out_received,
                                 uint64_t* out_emitted);
+/* Everything the *_multi entry points need ONCE per set of devices, taken out of the calls that are timed: librccl.so and
+ * the communicator over the scenes' devices (ncclCommInitAll, when they are distinct), each scene's auxiliary streams, its staging vectors
+ * for the totals, and a first tiny collective that makes RCCL set up its xGMI connections.  Optional -- the *_multi calls do the same
+ * lazily -- and idempotent.  out_ms (may be NULL) = 4 floats of host wall time: [0] load RCCL + create the communicator, [1] streams and
+ * staging buffers, [2] the warm-up collective (0 without a communicator), [3] total.  rc_multi_ranks: how many RCCL ranks the scenes form
+ * (0 when they share a device: replicas, partial results added on the host). */
+int rc_multi_prepare(rc_scene* const* scenes, int n_scenes, float* out_ms);
+int rc_multi_ranks(rc_scene* const* scenes, int n_scenes, int* out_ranks);
 /* closest_hit / any_hit over one HOST batch on several devices of one process (rays are independent -- replicas of the
  * scene, contiguous ray shards, no collective): scenes[g] is a synced copy of the same scene on device g; shard g is uploaded, traced
  * and downloaded by device g over its own PCIe link, which is what bounds a host-to-host batch (64 bytes per ray).  hits[i] is what

@@ -7,7 +7,7 @@ from . import scenes  # noqa: F401  (pure numpy; usable without the library)
 from ._capi import HIT_DT, LIB_PATH, RAY_DT, SYMBOLS, TRIANGLE_DT, RaycoreError, lib  # noqa: F401
 from .api import (BLAS4, CONTACT_DT, CollisionResult, ContactPair, collide_instances, collide_instances_any, EMPTY_TRIANGLE, RAYHIT_DT, INVALID_HANDLE, any_hit4, build_blas4, closest_hit4, Bounds3, Ray, RayHit, StaticTLAS, TLAS, TLAS_from_items,  # noqa: F401
                   TLAS_from_meshes, TLASHandle, Triangle, adapt, any_hit, closest_hit, generate_ray_grid,
-                  get_centroid, get_illumination, hits_from_grid, typed_hit_metadata, mat4_to_mat3x4, sync, trace_rays, view_factors, view_factors_multi, view_factor_totals, view_factor_totals_multi, trace_multi, get_illumination_multi,
+                  get_centroid, get_illumination, hits_from_grid, typed_hit_metadata, mat4_to_mat3x4, sync, trace_rays, view_factors, view_factors_multi, view_factor_totals, view_factor_totals_multi, multi_prepare, trace_multi, get_illumination_multi,
                   world_bound, expand_faceviews)
 
 

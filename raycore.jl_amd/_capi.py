@@ -80,6 +80,8 @@ SYMBOLS = [
     ("rc_view_factor_totals", _int, [_vp, _u32, _u64, _vp, _vp]),
     ("rc_view_factor_totals_device", _int, [_vp, _u32, _u64, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     ("rc_view_factor_totals_multi", _int, [C.POINTER(_vp), _int, _u32, _u64, _vp, _vp]),
+    ("rc_multi_prepare", _int, [C.POINTER(_vp), _int, _vp]),
+    ("rc_multi_ranks", _int, [C.POINTER(_vp), _int, _vp]),
     ("rc_trace_closest_multi", _int, [C.POINTER(_vp), _int, _vp, _vp, _u64]),
     ("rc_trace_any_multi", _int, [C.POINTER(_vp), _int, _vp, _vp, _u64]),
     ("rc_get_illumination_multi", _int, [C.POINTER(_vp), _int, _vp, _u32, _vp]),

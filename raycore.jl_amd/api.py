@@ -739,6 +739,19 @@ def view_factor_totals_multi(accels, rays_per_triangle=10000, seed=0):
     return received, emitted
 
 
+def multi_prepare(accels):
+    """Once per set of devices, before the *_multi calls that are timed (rc_multi_prepare): RCCL and its communicator, the scenes' auxiliary
+    streams and staging vectors, a warm-up collective.  Returns the host milliseconds each item took and the number of RCCL ranks the
+    accels form (0: replicas on one device, partial results are added on the host)."""
+    owners = [_owner(a) for a in accels]
+    handles = (C.c_void_p * len(owners))(*[o._h for o in owners])
+    ms = np.zeros(4, np.float32)
+    check(lib().rc_multi_prepare(handles, len(owners), ptr(ms)))
+    ranks = C.c_int(0)
+    check(lib().rc_multi_ranks(handles, len(owners), C.byref(ranks)))
+    return {"comm_init_ms": float(ms[0]), "streams_and_buffers_ms": float(ms[1]), "warmup_collective_ms": float(ms[2]), "total_ms": float(ms[3]), "rccl_ranks": int(ranks.value)}
+
+
 def trace_multi(accels, rays, mode="closest", out=None):
     """One host batch of rays on several devices of ONE process (rc_trace_closest_multi / rc_trace_any_multi): `accels` are synced accels
     holding the same scene, one per device; accel g uploads, traces and downloads the g-th contiguous shard of the batch over its own

@@ -1142,10 +1142,15 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
         if (value) {
             (void)hipSetDevice(s->device);
             std::lock_guard<std::mutex> g(s->launch_mu);
-            s->capture_regions.clear();
-            s->capture_scratch.clear();
-            s->graph_seq = 0;
+            s->capture_slots.clear();
+            s->last_capture = -1;
         }
+    }
+    else if (k == "release_capture") {  // ONE captured launch handed back: value = the token option "last_capture_token" returned right after that capture
+        (void)hipSetDevice(s->device);
+        std::lock_guard<std::mutex> g(s->launch_mu);
+        if (value < 1 || value > (int64_t)s->capture_slots.size() || !s->capture_slots[value - 1].in_use) return fail(RC_ERR_INVALID_ARGUMENT, "release_capture: not the token of a captured launch this scene still holds");
+        s->capture_slots[value - 1] = rc_scene::CaptureSlot();
     }
     else if (k == "vf_chunk_bytes") s->opt.vf_chunk_bytes = value < 4096 ? 4096 : (value > (int64_t(4) << 30) ? (int64_t(4) << 30) : value);
     else if (k == "timeline_ptr") s->opt.timeline_ptr = value;  // dev instrumentation: the caller owns the buffer and its size (8 x u64 per wave of the launch)
@@ -1200,7 +1205,19 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "debug_inst_cull_ptr") *value = (int64_t)(uintptr_t)s->inst_cull.p;  // dev: the entry-cull spheres, 2 x float4 per instance
     else if (k == "cost_thr") *value = s->opt.cost_thr;
     else if (k == "vf_first_touch") *value = s->opt.vf_first_touch;
-    else if (k == "release_captures") { std::lock_guard<std::mutex> g(s->launch_mu); *value = (int64_t)s->graph_seq; }  // captured launches currently holding a region and a slot
+    else if (k == "release_captures") {  // captured launches currently holding a region and a slot
+        std::lock_guard<std::mutex> g(s->launch_mu);
+        int64_t held = 0;
+        for (const auto& c : s->capture_slots) held += c.in_use ? 1 : 0;
+        *value = held;
+    }
+    else if (k == "last_capture_token") { std::lock_guard<std::mutex> g(s->launch_mu); *value = s->last_capture >= 0 && s->capture_slots[s->last_capture].in_use ? s->last_capture + 1 : 0; }  // of the scene's most recent captured launch (0: none held)
+    else if (k == "capture_bytes") {  // device memory held by the scene's captured launches
+        std::lock_guard<std::mutex> g(s->launch_mu);
+        int64_t b = 0;
+        for (const auto& c : s->capture_slots) { b += (int64_t)c.region.cap * 4; for (const auto& x : c.scratch) b += (int64_t)x->cap * 8; }
+        *value = b;
+    }
     else if (k == "vf_chunk_bytes") *value = s->opt.vf_chunk_bytes;
     else if (k == "blas_top_k") *value = s->blas_top_k;
     else if (k == "tlas_top_k") *value = s->tlas_top_k;
@@ -1323,6 +1340,23 @@ int rc_view_factor_totals_multi(rc_scene* const* scenes, int n_scenes, uint32_t 
         for (rc_scene* s : by_address) locks.emplace_back(s->host_call_mu);
         rc_view_factor_totals_multi_impl(scenes, n_scenes, rays_per_triangle, seed, out_received, out_emitted);
     });
+}
+int rc_multi_prepare(rc_scene* const* scenes, int n_scenes, float* out_ms) {
+    if (!scenes || n_scenes < 1) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        check_scene_list(scenes, n_scenes, "rc_multi_prepare");
+        std::vector<rc_scene*> by_address(scenes, scenes + n_scenes);  // (lock order: see rc_view_factors_multi)
+        std::sort(by_address.begin(), by_address.end());
+        std::vector<std::unique_lock<std::mutex>> locks;
+        for (rc_scene* s : by_address) locks.emplace_back(s->host_call_mu);
+        float ms[4] = {0, 0, 0, 0};
+        rc_multi_prepare_impl(scenes, n_scenes, ms);
+        if (out_ms) memcpy(out_ms, ms, sizeof ms);
+    });
+}
+int rc_multi_ranks(rc_scene* const* scenes, int n_scenes, int* out_ranks) {
+    if (!scenes || n_scenes < 1 || !out_ranks) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] { *out_ranks = rc_multi_ranks_impl(scenes, n_scenes); });
 }
 int rc_view_factor_totals(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint64_t* out_received, uint64_t* out_emitted) {
     return rc_view_factor_totals_multi(&s, 1, rays_per_triangle, seed, out_received, out_emitted);

@@ -116,14 +116,23 @@ __global__ void k_illumination_fold(const uint32_t* scratch, uint32_t n8, uint32
     unsigned long long sum = 0;
     for (uint32_t c = 0; c < kHistCopies; ++c) sum += scratch[(size_t)c * 8u * n8 + (j & 7u) * n8 + (j >> 3)];
     if (sum == 0) return;
-    const float before = counts[j];  // (ACCUMULATES: shards enqueued on one stream add up; an integer below 2^24 unless the caller put something else there)
-    if (before >= 0.0f && before <= 16777216.0f && before == (float)(uint32_t)before) {
-        const unsigned long long total = (unsigned long long)(uint32_t)before + sum;
-        counts[j] = total >= 16777216ull ? 16777216.0f : (float)(uint32_t)total;
-    } else {  // not a count: add one by one like the reference would, up to where f32 stops moving
-        float v = before;
-        for (unsigned long long k = 0; k < sum && k < 16777216ull; ++k) { const float nv = v + 1.0f; if (nv == v) break; v = nv; }
-        counts[j] = v;
+    // ACCUMULATES, atomically (shards traced concurrently on several streams into ONE vector used to be safe when the kernel itself
+    // added with atomics; N compare-and-swaps per launch cost nothing): counts = min(counts + hits, 2^24) in integers
+    uint32_t* word = reinterpret_cast<uint32_t*>(counts + j);
+    uint32_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const float before = __uint_as_float(seen);  // an integer below 2^24 unless the caller put something else there
+        float after;
+        if (before >= 0.0f && before <= 16777216.0f && before == (float)(uint32_t)before) {
+            const unsigned long long total = (unsigned long long)(uint32_t)before + sum;
+            after = total >= 16777216ull ? 16777216.0f : (float)(uint32_t)total;
+        } else {  // not a count: add one by one like the reference would, up to where f32 stops moving
+            after = before;
+            for (unsigned long long k = 0; k < sum && k < 16777216ull; ++k) { const float nv = after + 1.0f; if (nv == after) break; after = nv; }
+        }
+        const uint32_t prev = atomicCAS(word, seen, __float_as_uint(after));
+        if (prev == seen) break;
+        seen = prev;
     }
 }
 __global__ __launch_bounds__(kBlock, 6) void k_illumination(SceneView v, PersistArgs p, GridParams g, uint64_t ray_begin, uint32_t* scratch, uint32_t n8) {
@@ -319,7 +328,7 @@ __global__ void k_vf_totals_fold(const unsigned long long* scratch, uint32_t n8,
     if (j >= n) return;
     unsigned long long sum = 0;
     for (uint32_t c = 0; c < kTotalsCopies; ++c) sum += scratch[(size_t)c * 8u * n8 + (j & 7u) * n8 + (j >> 3)];
-    if (sum) received[j] += sum;  // (ACCUMULATES, like the kernel: stream order makes the plain add safe against earlier shards; concurrent shards on other streams need their own vectors)
+    if (sum) atomicAdd(received + j, sum);  // (ACCUMULATES; atomic, so that shards traced concurrently on several streams may share one vector -- ADVICE r4)
 }
 __global__ __launch_bounds__(kBlock, 6) void k_vf_totals(SceneView v, PersistArgs p, uint32_t k0, uint32_t k1, uint32_t src_begin, uint32_t ray_begin,
                                                           uint32_t n_ray, unsigned long long* received, uint32_t n8, unsigned long long* emitted) {
@@ -645,25 +654,31 @@ void rc_launch_view_factors(rc_scene* s, uint32_t rays_per_triangle, uint64_t se
 // 16: then an idle stream's area is taken over, else the oldest stream is waited for); a CAPTURED launch owns its area like its spill region.
 static unsigned long long* rc_totals_scratch(rc_scene* s, hipStream_t stream, bool capturing, size_t words) {
     if (words == 0) words = 1;
-    if (capturing) {
-        s->capture_scratch.emplace_back(new DevBuf<unsigned long long>());
-        s->capture_scratch.back()->reserve(words);
-        return s->capture_scratch.back()->p;
+    if (capturing) {  // (inside an RcLaunchGuard that took a capture slot)
+        auto& owned = s->capture_slots[s->cur_capture].scratch;
+        owned.emplace_back(new DevBuf<unsigned long long>());
+        owned.back()->reserve(words);
+        return owned.back()->p;
     }
-    for (auto& e : s->totals_scratch) if (e.first == stream) { e.second->reserve(words); return e.second->p; }
-    if (s->totals_scratch.size() < 16) {
-        s->totals_scratch.emplace_back(stream, std::unique_ptr<DevBuf<unsigned long long>>(new DevBuf<unsigned long long>()));
-    } else {
-        size_t victim = s->totals_scratch.size();
-        for (size_t i = 0; i < s->totals_scratch.size() && victim == s->totals_scratch.size(); ++i)
-            if (hipStreamQuery(s->totals_scratch[i].first) == hipSuccess) victim = i;
-        (void)hipGetLastError();
-        if (victim == s->totals_scratch.size()) { victim = 0; if (hipStreamSynchronize(s->totals_scratch[0].first) != hipSuccess) (void)hipGetLastError(); }
-        std::rotate(s->totals_scratch.begin() + victim, s->totals_scratch.begin() + victim + 1, s->totals_scratch.end());
-        s->totals_scratch.back().first = stream;
+    size_t idx = 0;
+    for (; idx < s->totals_scratch.size(); ++idx) if (s->totals_scratch[idx].stream == stream) break;
+    if (idx == s->totals_scratch.size()) {
+        if (s->totals_scratch.size() < 16) {
+            s->totals_scratch.emplace_back();
+            s->totals_scratch.back().buf.reset(new DevBuf<unsigned long long>());
+        } else {  // take over the area whose last launch is done (the entry's own event: never the caller's stream handle), else wait for the oldest's
+            size_t victim = s->totals_scratch.size();
+            for (size_t i = 0; i < s->totals_scratch.size() && victim == s->totals_scratch.size(); ++i)
+                if (s->totals_scratch[i].last.idle()) victim = i;
+            if (victim == s->totals_scratch.size()) { victim = 0; s->totals_scratch[0].last.wait(); }
+            std::rotate(s->totals_scratch.begin() + victim, s->totals_scratch.begin() + victim + 1, s->totals_scratch.end());
+        }
+        idx = s->totals_scratch.size() - 1;
+        s->totals_scratch[idx].stream = stream;
     }
-    s->totals_scratch.back().second->reserve(words);
-    return s->totals_scratch.back().second->p;
+    s->totals_scratch[idx].buf->reserve(words);
+    s->cur_scratch = (int)idx;
+    return s->totals_scratch[idx].buf->p;
 }
 
 // Totals of rays [ray_begin, ray_end) of the sources with flat indices [src_begin, src_end), ACCUMULATED into d_received / d_emitted

@@ -64,6 +64,32 @@ struct DevBuf {  // owning device buffer, grow-only reuse
     }
 };
 
+// "Is the last user of this per-stream resource done?" is asked of an event the LIBRARY recorded behind that user, never of the caller's
+// stream handle (hipStreamQuery on a stream another thread is capturing into invalidates the capture, and on a destroyed
+// stream it fails, so an entry keyed by a dead stream was never handed on).
+struct RcEvent {
+    hipEvent_t e = nullptr;
+    bool recorded = false;
+    RcEvent() = default;
+    RcEvent(const RcEvent&) = delete;
+    RcEvent& operator=(const RcEvent&) = delete;
+    RcEvent(RcEvent&& o) noexcept : e(o.e), recorded(o.recorded) { o.e = nullptr; o.recorded = false; }
+    RcEvent& operator=(RcEvent&& o) noexcept { if (this != &o) { drop(); e = o.e; recorded = o.recorded; o.e = nullptr; o.recorded = false; } return *this; }
+    ~RcEvent() { drop(); }
+    void drop() { if (e) (void)hipEventDestroy(e); e = nullptr; recorded = false; }
+    void record(hipStream_t st) {
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return; }
+        if (hipEventRecord(e, st) == hipSuccess) recorded = true; else (void)hipGetLastError();
+    }
+    bool idle() const {  // never blocks
+        if (!recorded) return true;
+        const hipError_t q = hipEventQuery(e);
+        if (q != hipSuccess) (void)hipGetLastError();
+        return q == hipSuccess;
+    }
+    void wait() const { if (recorded && hipEventSynchronize(e) != hipSuccess) (void)hipGetLastError(); }
+};
+
 struct Blas {  // one geometry: build_blas output (src/instanced-bvh.jl:111-118), device resident
     DevBuf<RcNode> nodes;
     DevBuf<RcPrim> prims;  // Morton-sorted
@@ -204,13 +230,19 @@ struct rc_scene {
     // takes over the region of an idle stream, or waits for the oldest).  Launches CAPTURED into a hipGraph never use these: each owns a
     // region of its own (capture_regions).
     static constexpr int kMaxOverflowRegions = 8;  // each is allocated on first use by a new stream
-    struct OverflowRegion { hipStream_t stream = nullptr; DevBuf<uint32_t> buf; };
+    struct OverflowRegion { hipStream_t stream = nullptr; DevBuf<uint32_t> buf; RcEvent last; };  // last: behind the latest launch that used the region
     std::vector<OverflowRegion> overflow_regions;
-    std::vector<std::unique_ptr<DevBuf<uint32_t>>> capture_regions;  // one per CAPTURED launch (graph_seq of them): a graph bakes the address in
-    uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared
+    // CAPTURED launches: each owns a counter slot (kEagerSlots + its index here), a spill region sized for ITS grid and, for the drivers, its
+    // scratch counters -- a graph bakes the addresses in.  Released all at once (option "release_captures") or one by one (option
+    // "release_capture" = the token option "last_capture_token" returned after the capture), once the caller's graph is gone.
+    struct CaptureSlot { bool in_use = false; DevBuf<uint32_t> region; std::vector<std::unique_ptr<DevBuf<unsigned long long>>> scratch; };
+    std::vector<CaptureSlot> capture_slots;  // kCounterSlots - kEagerSlots entries
+    int cur_capture = -1;              // the capture slot of the launch being prepared (-1: an eager launch)
+    int last_capture = -1;
+    int cur_region = -1, cur_history = -1, cur_scratch = -1;  // what the launch being prepared uses: RcLaunchGuard::finish records their events
+    uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared (a captured launch's is allocated by rc_scene_view, which knows the grid)
     DevBuf<uint32_t> counters;        // kCounterSlots slots of claim counters (self-resetting, rc_claim_chunk), the sticky status word, dev statistics; zeroed at rc_scene_create
     uint64_t launch_seq = 0;          // eager launches so far; slot = launch_seq % kEagerSlots
-    uint64_t graph_seq = 0;           // captured launches holding a slot and a spill region; slot = kEagerSlots + its number (option "release_captures" resets)
     int cur_slot = 0;                 // slot of the launch being prepared
     struct LaunchSlot {               // per counter slot: the events of its latest launch
         hipEvent_t t0 = nullptr, t1 = nullptr;  // timing pair; t1 also orders the slot's next user when that one runs on another stream
@@ -229,6 +261,7 @@ struct rc_scene {
         DevBuf<float> samples;              // kHistSlots x kHistSamples sample rays (8 floats each): how a launch's batch is recognised
         uint64_t gen = 0;                   // launches of this shape so far
         uint64_t last_use = 0;
+        RcEvent last;                       // behind the latest launch that used the entry's buffers
         PinnedU32 fresh_streak;             // written by k_order_select: consecutive launches of this shape whose batch matched no slot
         uint32_t skip_left = 0;             // launches still to run without the order kernels (the shape's batches do not repeat)
     };
@@ -251,8 +284,8 @@ struct rc_scene {
     std::mutex host_call_mu;          // the other host-buffer entry points (illumination, view factors, collisions, exports) run one at a time
 
     DevBuf<float> f32_stage;
-    std::vector<std::pair<hipStream_t, std::unique_ptr<DevBuf<unsigned long long>>>> totals_scratch;  // view-factor totals: private copies of the `received` vector, one area per stream (rc_drivers.hip; launch_mu)
-    std::vector<std::unique_ptr<DevBuf<unsigned long long>>> capture_scratch;                       // ... and one per captured totals launch
+    struct TotalsScratch { hipStream_t stream = nullptr; std::unique_ptr<DevBuf<unsigned long long>> buf; RcEvent last; };
+    std::vector<TotalsScratch> totals_scratch;  // view-factor totals / illumination: private copies of the accumulators, one area per stream (rc_drivers.hip; launch_mu); a captured launch's live in its CaptureSlot
     DevBuf<unsigned long long> u64_stage;  // view-factor totals: received[N] then emitted[N] (rc_multi.hip)
     DevBuf<float> vert_stage;
     DevBuf<uint32_t> meta_stage;
@@ -361,6 +394,8 @@ void rc_vf_source_range(rc_scene* s, uint32_t row_begin, uint32_t row_end, uint3
 // rc_multi.hip
 void rc_launch_vf_totals(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t src_begin, uint32_t src_end, uint32_t ray_begin,
                          uint32_t ray_end, unsigned long long* d_received, unsigned long long* d_emitted, hipStream_t stream);
+void rc_multi_prepare_impl(rc_scene* const* scenes, int n_scenes, float out_ms[4]);
+int rc_multi_ranks_impl(rc_scene* const* scenes, int n_scenes);
 void rc_view_factor_totals_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint64_t* out_received, uint64_t* out_emitted);
 float rc_view_factors_rows_to_host(rc_scene* s, uint32_t rays_per_triangle, uint64_t seed, uint32_t row_begin, uint32_t row_end, uint32_t* out, uint64_t ld);
 void rc_view_factors_multi_impl(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_triangle, uint64_t seed, uint32_t* out, int mode);

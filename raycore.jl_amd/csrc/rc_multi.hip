@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <thread>
 
@@ -483,7 +484,16 @@ void rc_view_factor_totals_multi_impl(rc_scene* const* scenes, int n_scenes, uin
     if (use_rccl || n_scenes == 1) {
         RC_HIP(hipEventRecord(t_end, stream[0]));
         RC_HIP(hipMemcpyAsync(total.data(), scenes[0]->u64_stage.p, sizeof(uint64_t) * 2u * n, hipMemcpyDeviceToHost, stream[0]));
-        for (int g = n_scenes - 1; g >= 0; --g) { RC_HIP(hipSetDevice(scenes[g]->device)); RC_HIP(hipStreamSynchronize(stream[g])); status_check(scenes[g]); }
+        // every stream drains BEFORE anything may throw: `total` is the target of the copy in flight on stream[0] (a status_check
+        // that threw for a later device first unwound the vector under the copy)
+        hipError_t first_error = hipSuccess;
+        for (int g = n_scenes - 1; g >= 0; --g) {
+            hipError_t e = hipSetDevice(scenes[g]->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream[g]);
+            if (e != hipSuccess && first_error == hipSuccess) first_error = e;
+        }
+        RC_HIP(first_error);
+        for (int g = n_scenes - 1; g >= 0; --g) { RC_HIP(hipSetDevice(scenes[g]->device)); status_check(scenes[g]); }
     } else {
         std::vector<uint64_t> part((size_t)2 * n);
         for (int g = 0; g < n_scenes; ++g) {
@@ -502,6 +512,51 @@ void rc_view_factor_totals_multi_impl(rc_scene* const* scenes, int n_scenes, uin
     RC_HIP(hipEventSynchronize(t_end));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, t_begin, t_end) == hipSuccess) rc_timing_fixed(scenes[0], ms); else (void)hipGetLastError();
+}
+
+// What a set of scenes needs once before its *_multi calls: see rc_multi_prepare in the header.  Each item is timed on the
+// host clock so that bench.py can print the fixed costs next to the timed call instead of inside it.
+void rc_multi_prepare_impl(rc_scene* const* scenes, int n_scenes, float out_ms[4]) {
+    if (n_scenes < 1 || !scenes) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_multi_prepare: no scenes");
+    check_same_geometry(scenes, n_scenes);
+    struct DeviceRestore { int dev = 0; DeviceRestore() { (void)hipGetDevice(&dev); } ~DeviceRestore() { (void)hipSetDevice(dev); } } restore;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const auto t_all = now();
+    const uint32_t n = scenes[0]->n_flat_prims;
+    const bool use_rccl = n_scenes > 1 && distinct_devices(scenes, n_scenes);
+    std::vector<int> devs(n_scenes);
+    for (int g = 0; g < n_scenes; ++g) devs[g] = scenes[g]->device;
+    auto t0 = now();
+    std::vector<ncclComm_t> comms;
+    if (use_rccl) comms = comms_for(devs);
+    const float ms_comm = ms_since(t0);
+    t0 = now();
+    for_each_scene(scenes, n_scenes, [&](int g) {
+        rc_scene* s = scenes[g];
+        RC_HIP(hipSetDevice(s->device));
+        for (auto& a : s->aux_streams) if (!a) RC_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        s->u64_stage.reserve((size_t)2 * std::max<uint32_t>(n, 1u));
+        RC_HIP(hipMemsetAsync(s->u64_stage.p, 0, sizeof(unsigned long long) * 2u * std::max<uint32_t>(n, 1u), s->aux_streams[0]));
+        RC_HIP(hipStreamSynchronize(s->aux_streams[0]));
+    });
+    const float ms_buffers = ms_since(t0);
+    t0 = now();
+    if (use_rccl && n > 0) {  // the first collective of a communicator sets up its xGMI connections: do it here, on zeros
+        Rccl& r = rccl();
+        nccl_ok(r.GroupStart(), "ncclGroupStart");
+        for (int g = 0; g < n_scenes; ++g)
+            nccl_ok(r.Reduce(scenes[g]->u64_stage.p, scenes[g]->u64_stage.p, (size_t)2 * n, kNcclUint64, kNcclSum, 0, comms[g], scenes[g]->aux_streams[0]), "ncclReduce");
+        nccl_ok(r.GroupEnd(), "ncclGroupEnd");
+        for (int g = 0; g < n_scenes; ++g) { RC_HIP(hipSetDevice(scenes[g]->device)); RC_HIP(hipStreamSynchronize(scenes[g]->aux_streams[0])); }
+    }
+    const float ms_warm = use_rccl ? ms_since(t0) : 0.f;
+    if (out_ms) { out_ms[0] = ms_comm; out_ms[1] = ms_buffers; out_ms[2] = ms_warm; out_ms[3] = ms_since(t_all); }
+}
+int rc_multi_ranks_impl(rc_scene* const* scenes, int n_scenes) {
+    if (n_scenes < 1 || !scenes) throw RcError(RC_ERR_INVALID_ARGUMENT, "rc_multi_ranks: no scenes");
+    for (int g = 0; g < n_scenes; ++g) if (!scenes[g]) throw RcError(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return (n_scenes > 1 && distinct_devices(scenes, n_scenes)) ? n_scenes : 0;
 }
 
 // closest_hit / any_hit over one host batch on several devices (rays are independent units -- replicas of the scene, the

@@ -379,28 +379,26 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
     capturing = cap == hipStreamCaptureStatusActive;
     const size_t region_words = (size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock;  // the largest grid any option can ask for: rc_set_option clamps blocks_per_cu to 8 blocks of 256 threads per CU
+    s->cur_capture = -1; s->cur_region = -1; s->cur_history = -1; s->cur_scratch = -1;
     if (capturing) {
         // A captured launch bakes its addresses into the graph and may be replayed at any time, beside eager launches and beside other
         // graphs: it gets a lane-stack spill region AND a slot of claim counters that no other launch, eager or captured, will ever use
         // (graphs captured on one stream used to share that stream's region, so two of them replayed side by side on a tree
-        // deeper than the LDS stack overwrote each other's entries).  Both come from a pool of kCounterSlots - kEagerSlots per scene;
-        // option "release_captures" returns them once the caller's graphs are gone.  The allocation happens inside the capture: the
-        // entry points run with the thread's capture-interaction mode relaxed, in which hipMalloc is legal.
-        if (s->graph_seq >= (uint64_t)(kCounterSlots - kEagerSlots))
+        // deeper than the LDS stack overwrote each other's entries).  Both come from a pool of kCounterSlots - kEagerSlots capture slots per
+        // scene, handed back by option "release_capture" (one) / "release_captures" (all) once the caller's graphs are gone.  The region
+        // is sized for the launch's own grid and allocated where that is known (rc_scene_view) -- inside the capture: the entry points run
+        // with the thread's capture-interaction mode relaxed, in which hipMalloc is legal.
+        if (s->capture_slots.empty()) s->capture_slots.resize(kCounterSlots - kEagerSlots);
+        int free_slot = -1;
+        for (size_t i = 0; i < s->capture_slots.size() && free_slot < 0; ++i) if (!s->capture_slots[i].in_use) free_slot = (int)i;
+        if (free_slot < 0)
             throw RcError(1, "this scene already holds " + std::to_string(kCounterSlots - kEagerSlots) + " captured launches (each owns a stack spill region and a counter slot): "
-                             "destroy the graphs and set option \"release_captures\" to 1, or capture several launches' worth of rays in one launch");
-        s->capture_regions.emplace_back(new DevBuf<uint32_t>());
-        try {
-            s->capture_regions.back()->reserve(region_words);
-        } catch (const RcError&) {
-            s->capture_regions.pop_back();
-            (void)hipGetLastError();
-            throw RcError(1, "could not allocate the stack spill region of a captured launch inside the capture (capture mode does not allow hipMalloc here): "
-                             "capture with hipStreamCaptureModeRelaxed / ThreadLocal, or run the launch eagerly");
-        }
-        s->cur_overflow = s->capture_regions.back()->p;
-        s->cur_slot = kEagerSlots + (int)s->graph_seq;
-        s->graph_seq += 1;
+                             "destroy a graph and hand its launches back (option \"release_capture\" with the token \"last_capture_token\" gave, or \"release_captures\" for all), "
+                             "or capture several launches' worth of rays in one launch");
+        s->capture_slots[free_slot].in_use = true;
+        s->cur_capture = s->last_capture = free_slot;
+        s->cur_overflow = nullptr;  // (rc_scene_view)
+        s->cur_slot = kEagerSlots + free_slot;
     } else {
         // the lane-stack spill area of the launch's stream (eager launches on one stream are ordered and share it)
         size_t idx = 0;
@@ -408,19 +406,11 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
             if (s->overflow_regions[idx].stream == stream) break;
         if (idx == s->overflow_regions.size() || s->overflow_regions[idx].buf.cap < region_words) {
             if (idx == s->overflow_regions.size()) {
-                if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // one stream too many: take over the region of a stream that is idle (oldest first), else wait for the oldest
+                if (idx == (size_t)rc_scene::kMaxOverflowRegions) {  // one stream too many: take over the region whose last launch is done (oldest first), else wait for the oldest region's
                     size_t victim = idx;
                     for (size_t v = 0; v < idx; ++v)
-                        if (hipStreamQuery(s->overflow_regions[v].stream) == hipSuccess) { victim = v; break; }
-                    (void)hipGetLastError();  // (hipErrorNotReady, or an invalid handle: a stream the caller has destroyed since)
-                    if (victim == idx) {
-                        victim = 0;
-                        if (hipStreamSynchronize(s->overflow_regions[victim].stream) != hipSuccess) {  // destroyed since: its work finished before the destroy returned resources; wait on the slots' events instead of the device
-                            (void)hipGetLastError();
-                            for (auto& slot : s->slots) if (slot.recorded && slot.t1) (void)hipEventSynchronize(slot.t1);
-                            (void)hipGetLastError();
-                        }
-                    }
+                        if (s->overflow_regions[v].last.idle()) { victim = v; break; }
+                    if (victim == idx) { victim = 0; s->overflow_regions[victim].last.wait(); }
                     std::rotate(s->overflow_regions.begin() + victim, s->overflow_regions.begin() + victim + 1, s->overflow_regions.end());
                     idx -= 1;
                     s->overflow_regions[idx].stream = stream;
@@ -431,6 +421,7 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
             }
             s->overflow_regions[idx].buf.reserve(region_words);
         }
+        s->cur_region = (int)idx;
         s->cur_overflow = s->overflow_regions[idx].buf.p;
         // the launch's slot of chunk counters; a launch that reuses an eager slot from another stream waits for the slot's previous user
         s->launch_seq += 1;
@@ -460,6 +451,10 @@ void RcLaunchGuard::finish() {
     if (capturing) return;  // a captured launch has no events of its own: the graph orders it, and its duration is the replay's business
     rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
     if (rc_event_mode() < 3) RC_HIP(hipEventRecord(slot.t1, stream));
+    // the per-stream resources this launch used are busy until here (asked by the next stream that wants to take one over)
+    if (s->cur_region >= 0) s->overflow_regions[s->cur_region].last.record(stream);
+    if (s->cur_history >= 0) s->histories[s->cur_history].last.record(stream);
+    if (s->cur_scratch >= 0) s->totals_scratch[s->cur_scratch].last.record(stream);
     slot.stream = stream;
     slot.recorded = true;
     slot.seq = ++s->timing_seq;
@@ -535,6 +530,18 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
     v.tlas_nodes = s->tlas_nodes.p; v.blas_nodes = s->flat_nodes.p; v.inst = s->inst_recs.p; v.prims = s->flat_prims.p;
     v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims; v.tlas_off = s->n_flat_nodes; v.n_nodes_total = s->n_flat_nodes + s->n_tlas_nodes; v.n_inst = s->n_static_instances;
     v.inst_cull = (s->opt.entry_cull && s->inst_cull.p && s->n_static_instances) ? s->inst_cull.p : nullptr;
+    if (s->cur_capture >= 0 && !s->cur_overflow) {  // a captured launch: its own spill region, sized for its own grid (every capture used to pin the largest grid's 268 MB)
+        rc_scene::CaptureSlot& cs = s->capture_slots[s->cur_capture];
+        try {
+            cs.region.reserve((size_t)kTotalStack * std::max<uint32_t>(total_threads, 64u));
+        } catch (const RcError&) {
+            (void)hipGetLastError();
+            cs.in_use = false;
+            throw RcError(1, "could not allocate the stack spill region of a captured launch inside the capture (capture mode does not allow hipMalloc here): "
+                             "capture with hipStreamCaptureModeRelaxed / ThreadLocal, or run the launch eagerly");
+        }
+        s->cur_overflow = cs.region.p;
+    }
     v.overflow = s->cur_overflow; v.total_threads = total_threads;
     v.status = rc_status_word(s);
     return v;
@@ -825,7 +832,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
         // asynchronous, and a workload whose batch size changes with every launch -- a wavefront tracer compacting its rays bounce by
         // bounce -- misses every time): a free entry is taken at once; a full table gives up an entry only to a shape that has been seen
         // BEFORE (a one-off size learns nothing worth keeping), and only an entry whose buffers nobody can still be using -- its stream
-        // is this launch's stream (stream order protects them) or is idle right now (hipStreamQuery, non-blocking).  Otherwise the
+        // is this launch's stream (stream order protects them) or whose last launch has completed (the entry's own event, queried, never waited for).  Otherwise the
         // launch simply runs in natural order.  Buffers have ONE size (the largest batch the order kernels handle), so re-keying an
         // entry frees and allocates nothing.
         bool seen_before = false;
@@ -848,8 +855,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
             for (size_t i = 0; i < s->histories.size(); ++i) {
                 auto& e = s->histories[i];
                 if (e.last_use >= oldest) continue;
-                const bool reusable = e.stream == stream || hipStreamQuery(e.stream) == hipSuccess;
-                (void)hipGetLastError();
+                const bool reusable = e.stream == stream || e.last.idle();  // (stream order protects a same-stream entry; any other is free once its last launch is done)
                 if (reusable) { victim = i; oldest = e.last_use; }
             }
             if (victim == s->histories.size()) return false;
@@ -862,6 +868,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
         h->gen = 0;
     }
     h->last_use = ++s->history_clock;
+    s->cur_history = (int)(h - s->histories.data());
     // A shape whose batches never repeat learns nothing and should pay nothing: k_order_select reports the run of launches that were not a
     // repeat of a remembered batch (sample rays identical) into a pinned word; once it reads kGiveUpAfter (whenever the kernels that wrote it have run -- nothing here waits) the next
     // kGiveUpFor launches of the shape go out in natural order without the order kernels, then the shape is tried again.

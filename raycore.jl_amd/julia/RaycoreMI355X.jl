@@ -287,6 +287,20 @@ function view_factor_totals(accels::Vector{MI355XStaticTLAS}; rays_per_triangle 
                                     ptrs, length(ptrs), rays_per_triangle, seed, received, emitted))
     return received, emitted
 end
+
+# Once per set of devices, before the *_multi calls that are timed: RCCL + communicator, auxiliary streams, staging vectors, a warm-up
+# collective (rc_multi_prepare).  Returns (comm_init_ms, streams_and_buffers_ms, warmup_collective_ms, total_ms, rccl_ranks).
+function multi_prepare(accels::Vector{MI355XStaticTLAS})
+    handles = Ptr{Cvoid}[a.owner.ptr for a in accels]
+    ms = zeros(Float32, 4)
+    ranks = Ref{Cint}(0)
+    GC.@preserve accels begin
+        check(ccall((:rc_multi_prepare, LIB), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{Float32}), handles, length(handles), ms))
+        check(ccall((:rc_multi_ranks, LIB), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{Cint}), handles, length(handles), ranks))
+    end
+    return (comm_init_ms = ms[1], streams_and_buffers_ms = ms[2], warmup_collective_ms = ms[3], total_ms = ms[4], rccl_ranks = Int(ranks[]))
+end
+
 "One shard of the totals (sources [src_begin, src_end) x rays [ray_begin, ray_end)), ACCUMULATED into device vectors of N UInt64 each: the
 unit of a multi-process run (MPI.jl / one process per GPU: reduce 2N UInt64)."
 view_factor_totals_device!(a::MI355XStaticTLAS, rays_per_triangle::Integer, seed::UInt64, src_begin::Integer, src_end::Integer, ray_begin::Integer,

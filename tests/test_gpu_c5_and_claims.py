@@ -461,6 +461,26 @@ def test_trace_launches_are_hipgraph_capturable(rc, oracle):
     g3.replay()
     torch.cuda.synchronize()
     assert_hits_equal(dh.cpu().numpy().view(rc.HIT_DT), want, "graph captured after release_captures")
+    # a captured launch's spill region is sized for ITS grid (every capture used to pin the largest grid's 268 MB), and launches
+    # are handed back one by one with the token the scene gave right after the capture -- other graphs stay alive
+    tok3, bytes3 = t.get_option("last_capture_token"), t.get_option("capture_bytes")
+    assert tok3 >= 1 and t.get_option("release_captures") == 1 and bytes3 > 0
+    small = 4096
+    g4 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g4, stream=fresh):
+        t.trace_device(dr.data_ptr(), dh.data_ptr(), small, stream=torch.cuda.current_stream().cuda_stream)
+    tok4 = t.get_option("last_capture_token")
+    assert tok4 not in (0, tok3) and t.get_option("release_captures") == 2
+    assert t.get_option("capture_bytes") - bytes3 < bytes3 // 8          # 4096 rays: a few blocks' worth of spill area, not the whole machine's
+    del g3
+    t.set_option("release_capture", tok3)
+    assert t.get_option("release_captures") == 1 and t.get_option("last_capture_token") == tok4
+    with pytest.raises(rc.RaycoreError, match="token"):
+        t.set_option("release_capture", tok3)                            # already handed back
+    dh.zero_()
+    g4.replay()                                                          # the other graph is untouched
+    torch.cuda.synchronize()
+    assert_hits_equal(dh.cpu().numpy().view(rc.HIT_DT)[:small], want[:small], "graph that stayed alive beside a released one")
     assert t.get_option("claim_drift") == 0
     t.free()
 
