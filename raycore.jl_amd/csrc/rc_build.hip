@@ -534,7 +534,7 @@ constexpr int kTopBlock = 1024;
 __global__ __launch_bounds__(kTopBlock) void k_top_remap(const RcNode* nodes, uint32_t n_leaves, uint32_t K, uint32_t* remap) {
     typedef hipcub::BlockScan<uint32_t, kTopBlock> Scan;
     __shared__ typename Scan::TempStorage tmp;
-    __shared__ uint32_t top[rc::kPartialPlaneNodes], in_top[rc::kPartialPlaneNodes + 1], d_list[rc::kPartialPlaneNodes], v_list[rc::kPartialPlaneNodes];  // K <= kPartialPlaneNodes
+    __shared__ uint32_t top[rc::kPartialPlaneNodes16], in_top[rc::kPartialPlaneNodes16 + 1], d_list[rc::kPartialPlaneNodes16], v_list[rc::kPartialPlaneNodes16];  // K <= kPartialPlaneNodes16 < kTopBlock
     const uint32_t t = threadIdx.x;
     if (t == 0) top[0] = 1u;
     if (t <= K) in_top[t] = 0u;
@@ -928,25 +928,41 @@ void rc_build_tlas(rc_scene* s) {
     // (renumbered below, after the TLAS is built) and, for a single BLAS, of the BLAS -- half each when both want more (kernel 6).
     s->blas_top_k = 0;
     s->tlas_top_k = 0;
+    s->blas_top_k32 = 0;
+    s->tlas_top_k32 = 0;
+    // STACK16 (rc_internal.h): every tree below 65 534 nodes => 16-bit lane stacks and larger node planes.  The renumbering below is made for
+    // the larger planes; the 32-bit kernels (option stack16 = 0, the drivers) stage a PREFIX of the same breadth-first order (*_top_k32).
+    s->small_trees = n <= rc::kStack16MaxLeaves;
+    for (uint32_t i = 0; i < nb; ++i) s->small_trees = s->small_trees && s->blas[i].n_prims <= rc::kStack16MaxLeaves;
     const bool full_lds = n > 0 && 2 * n - 1 <= (uint32_t)rc::kTlasLdsNodes;
     const bool small_enough = (uint64_t)tn + 2ull * n < (1ull << 26);  // the LDS kernels address nodes with 32-bit byte offsets
-    uint32_t blas_room = 0;
+    uint32_t blas_room = 0, blas_room32 = 0;
+    auto split = [&](uint32_t P, uint32_t& tk, uint32_t& bk) {  // planes of P entries shared by the TLAS's top and a single BLAS's: half each when both want more
+        const uint32_t t_int = n - 1, b_int = (nb == 1 && s->blas[0].n_prims >= 2) ? s->blas[0].n_prims - 1 : 0;
+        tk = t_int < P ? t_int : P; bk = b_int < P ? b_int : P;
+        if (tk + bk > P) {
+            const uint32_t half = P / 2;
+            if (tk <= half) bk = P - tk; else if (bk <= half) tk = P - bk; else { tk = P - half; bk = half; }
+        }
+    };
     if (s->opt.blas_top && n > 0 && small_enough) {
-        if (full_lds) blas_room = (uint32_t)rc::kLdsPlaneNodes - (n - 1);
-        else {
-            const uint32_t P = (uint32_t)rc::kPartialPlaneNodes, t_int = n - 1, b_int = (nb == 1 && s->blas[0].n_prims >= 2) ? s->blas[0].n_prims - 1 : 0;
-            uint32_t tk = t_int < P ? t_int : P, bk = b_int < P ? b_int : P;
-            if (tk + bk > P) {  // both want more than half: split evenly, hand a short side's slack to the other
-                const uint32_t half = P / 2;
-                if (tk <= half) bk = P - tk; else if (bk <= half) tk = P - bk; else { tk = P - half; bk = half; }
-            }
-            s->tlas_top_k = tk;
-            blas_room = bk;
+        if (full_lds) {
+            blas_room32 = (uint32_t)rc::kLdsPlaneNodes - (n - 1);
+            blas_room = s->small_trees ? (uint32_t)rc::kLdsPlaneNodes16 - (n - 1) : blas_room32;
+        } else {
+            uint32_t tk, bk, tk32, bk32;
+            split((uint32_t)rc::kPartialPlaneNodes, tk32, bk32);
+            if (s->small_trees) split((uint32_t)rc::kPartialPlaneNodes16, tk, bk); else { tk = tk32; bk = bk32; }
+            if (tk32 > tk) tk32 = tk;  // (prefixes of the renumbering that was made)
+            if (bk32 > bk) bk32 = bk;
+            s->tlas_top_k = tk; s->tlas_top_k32 = tk32;
+            blas_room = bk; blas_room32 = bk32;
         }
     }
     if (nb == 1 && blas_room > 0 && s->blas[0].n_prims >= 2) {
         const uint32_t n_leaves = s->blas[0].n_prims, n_int = n_leaves - 1, room = blas_room;
         s->blas_top_k = n_int < room ? n_int : room;
+        s->blas_top_k32 = s->blas_top_k < blas_room32 ? s->blas_top_k : blas_room32;
         s->top_remap.reserve(n_int);
         hipLaunchKernelGGL(k_iota1, dim3(grid_for(n_int)), dim3(kBlock), 0, s->stream, s->top_remap.p, n_int);
         hipLaunchKernelGGL(k_top_remap, dim3(1), dim3(kTopBlock), 0, s->stream, s->blas[0].nodes.p, n_leaves, s->blas_top_k, s->top_remap.p);

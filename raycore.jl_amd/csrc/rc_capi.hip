@@ -1126,6 +1126,7 @@ int rc_set_option(rc_scene* s, const char* name, int64_t value) {
     else if (k == "blocks_per_cu") s->opt.blocks_per_cu = value < 0 ? 0 : (value > 8 ? 8 : value);  // 0 = derive from the stack depth; the stack spill area is sized for 8 blocks of 256 threads per CU
     else if (k == "lds_stack") s->opt.lds_stack = value;
     else if (k == "refill") s->opt.refill = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (k == "stack16") s->opt.stack16 = value != 0;
     else if (k == "stats") s->opt.stats = value;
     else if (k == "pool") s->opt.pool = value <= 0 ? 0 : (value < 16 ? 16 : (value > (1 << 20) ? (1 << 20) : value));  // 0 = default (128 rays per claim)
     else if (k == "onesweep_min") s->opt.onesweep_min = value < 0 ? 0 : value;
@@ -1177,6 +1178,8 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "claim_shards") *value = s->opt.claim_shards;
     else if (k == "sched_thr") *value = s->opt.sched_thr;
     else if (k == "onesweep_min") *value = s->opt.onesweep_min;
+    else if (k == "stack16") *value = s->opt.stack16;
+    else if (k == "stack16_in_use") *value = (s->small_trees && s->opt.stack16) ? 1 : 0;
     else if (k == "blas_top") *value = s->opt.blas_top;
     else if (k == "claim_drift") {
         // dev: chunk counters, over all slots, that are not back at zero once the device is idle -- always 0 unless the

@@ -123,6 +123,11 @@ constexpr int kTlasLdsInst = 256;
 //  * the instance records as seven float2 planes of kTlasLdsInst entries (inverse transform, nodes offset, leaf count).
 constexpr int kLdsPlaneNodes = 310;
 constexpr int kPartialPlaneNodes = 585;  // node planes of the PARTIAL_LDS kernel (no leaf table, no instance planes): 32 760 bytes
+// Scenes whose trees ALL have fewer than 65 534 nodes (every BLAS <= 32 767 triangles, <= 32 767 instances) run the STACK16 shape of the
+// same kernels (round 5): lane-stack entries of 16 bits, and the 24 KiB of LDS that frees per workgroup holds more of the tree.
+constexpr int kLdsPlaneNodes16 = 748;      // 7 x 748 x 8 = 41 888 bytes of node planes (+ 24 576 of stacks + 1 024 + 14 336 = 81 824)
+constexpr int kPartialPlaneNodes16 = 1023; // 7 x 1023 x 8 = 57 288 (+ 24 576 = 81 864)
+constexpr uint32_t kStack16MaxLeaves = 32767;
 }  // namespace rc
 
 struct TraceOptions {
@@ -134,6 +139,7 @@ struct TraceOptions {
     int64_t sched_thr = 36;    // kernel 2: lanes that must wait for a leaf/switch batch; kernel 3: interior lanes below which the wave serves the waiting lanes
     int64_t stats = 0;         // dev instrumentation (persistent kernels only)
     int64_t onesweep_min = 1000000;  // builds: key counts from here up are sorted by Onesweep radix passes, smaller ones by rocPRIM's merge sort (measured: 0.22 vs 0.25 ms at 250 k keys, 0.437 vs 0.425 ms at 1 M)
+    int64_t stack16 = 1;       // scenes whose trees all have fewer than 65 534 nodes: 16-bit lane-stack entries, the freed LDS holds more of the tree (kernels 5 / 6)
     int64_t blas_top = 1;      // single-BLAS scenes: renumber the BLAS's top internal nodes to the front of the traversal copy and let kernel 5 read them from LDS
     int64_t host_pipeline = 1; // host-buffer trace calls of >= 1 Mi rays overlap upload / trace / download in chunks
     int64_t taper = 12;        // persistent kernels: guided chunk sizes at the end of a batch, in eighths of (chunk size x waves) still to hand out per piece (RcClaim); 0 = all chunks of `pool` items
@@ -205,6 +211,8 @@ struct rc_scene {
     uint32_t n_flat_nodes = 0;
     DevBuf<uint32_t> tlas_remap;       // same for the TLAS's internal nodes (top levels too large for the full LDS kernels), kept for refits
     uint32_t tlas_top_k = 0;
+    uint32_t tlas_top_k32 = 0, blas_top_k32 = 0;  // what the kernels with 32-bit lane stacks (smaller node planes) stage of the same renumbering: prefixes of tlas_top_k / blas_top_k
+    bool small_trees = false;          // every tree of the scene has fewer than 65 534 nodes: the STACK16 kernels apply
     DevBuf<uint32_t> top_remap;        // old -> new internal node index of that renumbering (scratch of rc_build_tlas)
     uint32_t blas_top_k = 0;           // single-BLAS scene: internal nodes 1..blas_top_k of the traversal copy are the tree's top in breadth-first order
     DevBuf<RcPrim> flat_prims;
@@ -302,7 +310,7 @@ struct rc_scene {
     DevBuf<uint32_t> collide_counts;  // collide_instances' per-leaf counts / prefix sums (the reference's `cache`)
     DevBuf<uint2> contact_stage;
 
-    bool lds_attr_set[12] = {};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any), illumination, view factors, [6, 7] kernel 6, [8, 9] the partial-LDS drivers, [10, 11] view-factor totals
+    bool lds_attr_set[16] = {};  // hipFuncAttributeMaxDynamicSharedMemorySize done for kernels 4 / 5 (closest, any), illumination, view factors, [6, 7] kernel 6, [8, 9] the partial-LDS drivers, [10, 11] view-factor totals
 
     TraceOptions opt;
 };

@@ -114,30 +114,33 @@ constexpr int kBigBlock = 1024;
 constexpr size_t kBigStackBytes = (size_t)kLdsStack * kBigBlock * 4;
 constexpr size_t kBigLdsBytes = kBigStackBytes + kLdsTopBytes;
 
-template <bool ANY, int BLOCK, int LDS_N, int MINW, bool TIMELINE = false, bool STATS = false>
+template <bool ANY, int BLOCK, int LDS_N, int MINW, bool TIMELINE = false, bool STATS = false, bool STACK16 = false>
 __global__ __launch_bounds__(BLOCK, MINW) void k_trace_phased_lds(TraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr size_t stack_bytes = (size_t)LDS_N * BLOCK * 4;
-    uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem);
-    const LdsTop top(smem + stack_bytes);
-    if (a.v.n_tlas_nodes) stage_lds_top<BLOCK>(top, a.v, a.blas_k, a.lds_blas_base);
+    typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type entry_t;
+    constexpr size_t stack_bytes = (size_t)LDS_N * BLOCK * sizeof(entry_t);
+    constexpr int kPlanes = STACK16 ? kLdsPlaneNodes16 : kLdsPlaneNodes;
+    entry_t* lds_stack = reinterpret_cast<entry_t*>(smem);
+    const LdsTop top(smem + stack_bytes, (size_t)7 * kPlanes * sizeof(float2));
+    if (a.v.n_tlas_nodes) stage_lds_top<BLOCK, kPlanes>(top, a.v, a.blas_k, a.lds_blas_base);
     __syncthreads();
     PersistArgs p{a.n_rays, a.claim, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, 0u, a.timeline};
-    phased_trace<ANY, LDS_N, STATS, ArraySource, HitWriter, BLOCK, true, true, false, TIMELINE>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
+    phased_trace<ANY, LDS_N, STATS, ArraySource, HitWriter, BLOCK, true, true, false, TIMELINE, STACK16>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
 // ---- kernel 6: kernel 5's shape for top levels that do not fit (more than 256 instances): only the breadth-first tops of the TLAS and
 // of a single BLAS are staged (PARTIAL_LDS, rc_traverse_core.h); TLAS leaves and instance records come from memory as in kernel 3.
-template <bool ANY>
+template <bool ANY, bool STACK16 = false>
 __global__ __launch_bounds__(kMidBlock, 6) void k_trace_phased_partial(TraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem);
+    typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type entry_t;
+    entry_t* lds_stack = reinterpret_cast<entry_t*>(smem);
     LdsTop top;
-    top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * 4);
-    stage_partial_top<kMidBlock>(top.tl, a.v, a.tlas_k, a.blas_k, a.lds_blas_base);
+    top.tl = reinterpret_cast<float2*>(smem + (size_t)kMidStack * kMidBlock * sizeof(entry_t));
+    stage_partial_top<kMidBlock, STACK16 ? kPartialPlaneNodes16 : kPartialPlaneNodes>(top.tl, a.v, a.tlas_k, a.blas_k, a.lds_blas_base);
     __syncthreads();
     PersistArgs p{a.n_rays, a.claim, a.refill, a.sched_thr, a.stats, a.blas_k, a.lds_blas_base, a.tlas_k};
-    phased_trace<ANY, kMidStack, false, ArraySource, HitWriter, kMidBlock, false, false, true>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
+    phased_trace<ANY, kMidStack, false, ArraySource, HitWriter, kMidBlock, false, false, true, false, STACK16>(a.v, p, lds_stack, ArraySource{a.rays}, HitWriter{a.v.inst, a.hits}, top);
 }
 
 // ---- kernel 2: persistent waves + per-wave path scheduling --------------------------------------------
@@ -567,14 +570,14 @@ uint32_t rc_lds_driver_blocks(rc_scene* s, uint64_t n_items) {
 }
 // ... and the partial-LDS variants under the conditions of trace kernel 6: a larger top level with something to stage
 bool rc_partial_driver_ok(rc_scene* s) {
-    return s->opt.kernel != 3 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes && s->tlas_top_k + s->blas_top_k > 0 &&
+    return s->opt.kernel != 3 && s->n_tlas_nodes > (uint32_t)kTlasLdsNodes && s->tlas_top_k32 + s->blas_top_k32 > 0 &&
            (uint64_t)(s->n_flat_nodes + s->n_tlas_nodes) * 64u < (1ull << 32);
 }
-void rc_partial_driver_args(rc_scene* s, rc::PersistArgs& p) {
-    p.tlas_k = s->tlas_top_k; p.blas_k = s->opt.blas_top ? s->blas_top_k : 0; p.lds_blas_base = s->tlas_top_k;
+void rc_partial_driver_args(rc_scene* s, rc::PersistArgs& p) {  // (the drivers run the 32-bit shape: prefixes of the renumbered tops)
+    p.tlas_k = s->tlas_top_k32; p.blas_k = s->opt.blas_top ? s->blas_top_k32 : 0; p.lds_blas_base = s->tlas_top_k32;
 }
 void rc_lds_driver_args(rc_scene* s, rc::PersistArgs& p) {
-    if (s->opt.blas_top) { p.blas_k = s->blas_top_k; p.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
+    if (s->opt.blas_top) { p.blas_k = s->blas_top_k32; p.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
 }
 
 uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items) {
@@ -582,6 +585,9 @@ uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items) {
     uint64_t want = (n_items + kBlock - 1) / kBlock, cap = (uint64_t)s->n_cus * per_cu;
     return (uint32_t)(want < cap ? want : cap);
 }
+
+// kernels 5 / 6 in their STACK16 shape: the scene's trees are all small enough, nobody asked for counters or a timeline (dev builds keep the 32-bit shape)
+static bool rc_stack16(rc_scene* s) { return s->small_trees && s->opt.stack16 && !s->opt.stats && !s->opt.timeline_ptr; }
 
 template <bool ANY>
 static void launch_variant(rc_scene* s, int64_t kernel, const TraceArgs& a, uint32_t blocks, hipStream_t stream) {
@@ -608,8 +614,22 @@ static void launch_variant(rc_scene* s, int64_t kernel, const TraceArgs& a, uint
         } else if (a.timeline) {  // dev: the same kernel with per-wave event times written to the caller's buffer (option "timeline_ptr")
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
             hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
+        } else if (rc_stack16(s)) {
+            bool& set16 = s->lds_attr_set[12 + (ANY ? 1 : 0)];
+            if (!set16) {
+                RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes16));
+                set16 = true;
+            }
+            hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, false, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes16, stream, a);
         } else
         hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
+    } else if (kernel == 6 && rc_stack16(s)) {
+        bool& attr_set = s->lds_attr_set[14 + (ANY ? 1 : 0)];
+        if (!attr_set) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_partial<ANY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartialLdsBytes16));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_trace_phased_partial<ANY, true>), dim3(blocks), dim3(kMidBlock), kPartialLdsBytes16, stream, a);
     } else if (kernel == 6) {
         bool& attr_set = s->lds_attr_set[6 + (ANY ? 1 : 0)];
         if (!attr_set) {
@@ -933,9 +953,10 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     a.sched_thr = kernel == 2 ? 32 : (int)s->opt.sched_thr;  // kernel 2's vote threshold is its own (lanes that must wait for a batch), tuned at 32
     a.stats = rc_stats_words(s);
     a.timeline = reinterpret_cast<unsigned long long*>(s->opt.timeline_ptr);
-    if ((kernel == 5 || kernel == 4) && s->opt.blas_top) { a.blas_k = s->blas_top_k; a.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
+    const bool wide = rc_stack16(s);  // the STACK16 shape stages all of the renumbered tops, the 32-bit shape a prefix
+    if ((kernel == 5 || kernel == 4) && s->opt.blas_top) { a.blas_k = (wide && kernel == 5) ? s->blas_top_k : s->blas_top_k32; a.lds_blas_base = (s->n_tlas_nodes + 1) / 2 - 1; }
     if (kernel == 6) {  // a plan made for the full-LDS kernels (<= 256 instances) has no TLAS renumbering: tlas_k = 0, its blas_k still fits
-        a.tlas_k = s->tlas_top_k; a.blas_k = s->opt.blas_top ? s->blas_top_k : 0; a.lds_blas_base = s->tlas_top_k;
+        a.tlas_k = wide ? s->tlas_top_k : s->tlas_top_k32; a.blas_k = s->opt.blas_top ? (wide ? s->blas_top_k : s->blas_top_k32) : 0; a.lds_blas_base = a.tlas_k;
     }
     launch.start();
     if (learn_order && (kernel == 3 || kernel == 5 || kernel == 6) && !launch.capturing) rc_cost_order_setup(s, n, any_hit, stream, a.claim, d_rays);  // (inside the timed region: the order kernel is part of the launch's cost)

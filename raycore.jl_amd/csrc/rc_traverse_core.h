@@ -4,6 +4,8 @@
 // Reference: closest_hit src/instanced-bvh.jl:1902-2024, any_hit :2034-2140, safe_invdir :1742-1748,
 // fast_intersect_bbox :1841-1859, intersect_internal_node :1807-1832, fast_intersect_triangle :1756-1797.
 #pragma once
+#include <type_traits>
+
 #include "rc_internal.h"
 
 namespace rc {
@@ -165,20 +167,25 @@ using LaneStack = LaneStackT<kLdsStack>;
 // ds_write + add, a pop add + compare + ds_read -- the index form pays a 64-bit multiply-add (v_mad_u64_u32, 5 cycles of VALU issue
 // on a kernel bound by exactly that) for every address.  Entries beyond the LDS depth live in the global spill area as before; the
 // entry index is only reconstructed on that rare path.
-template <int LDS_N, int BLOCK>
+typedef uint16_t __attribute__((address_space(3))) lds_u16;
+// E = the type of an LDS entry: uint32_t, or uint16_t for scenes whose trees all have fewer than 65 534 nodes (STACK16 kernels: node values,
+// INVALID and the sentinel are then 16-bit numbers throughout the kernel -- 0xFFFF and 0xFFFE are the low halves of the 32-bit ones -- and
+// the LDS the stacks give up holds more of the tree; entries beyond the LDS depth spill to 32-bit words as before)
+template <int LDS_N, int BLOCK, typename E = uint32_t>
 struct LaneStackP {
-    typedef lds_u32* pos_t;
-    lds_u32* base;       // &lds_stack[threadIdx.x]: entry k at base + k * BLOCK
-    lds_u32* limit;      // base + LDS_N * BLOCK
+    typedef E __attribute__((address_space(3))) lds_e;
+    typedef lds_e* pos_t;
+    lds_e* base;         // &lds_stack[threadIdx.x]: entry k at base + k * BLOCK
+    lds_e* limit;        // base + LDS_N * BLOCK
     glb_u32* ovf;
     uint32_t ovf_stride;
     uint32_t* status;
-    __device__ inline LaneStackP(uint32_t* lds_base, uint32_t* ovf_base, uint32_t stride, uint32_t* st)
-        : base((lds_u32*)lds_base), limit((lds_u32*)lds_base + LDS_N * BLOCK), ovf((glb_u32*)ovf_base), ovf_stride(stride), status(st) {}
+    __device__ inline LaneStackP(E* lds_base, uint32_t* ovf_base, uint32_t stride, uint32_t* st)
+        : base((lds_e*)lds_base), limit((lds_e*)lds_base + LDS_N * BLOCK), ovf((glb_u32*)ovf_base), ovf_stride(stride), status(st) {}
     __device__ inline pos_t empty() const { return base; }
     __device__ inline int depth(pos_t top) const { return (int)(top - base) / BLOCK; }
     __device__ inline void push(pos_t& top, uint32_t v) {
-        if (__builtin_expect(top < limit, 1)) *top = v;
+        if (__builtin_expect(top < limit, 1)) *top = (E)v;
         else {
             const int k = depth(top);
             if (k < kTotalStack) ovf[(size_t)(k - LDS_N) * ovf_stride] = v;
@@ -424,27 +431,31 @@ constexpr size_t kLeafTableBytes = (size_t)kTlasLdsInst * sizeof(uint32_t);
 constexpr size_t kInstPlaneBytes = (size_t)7 * kTlasLdsInst * sizeof(float2);
 constexpr size_t kLdsTopBytes = kNodePlaneBytes + kLeafTableBytes + kInstPlaneBytes;
 constexpr size_t kMidLdsBytes = (size_t)kMidStack * kMidBlock * 4 + kLdsTopBytes;
+// STACK16 shape (scenes whose trees all have fewer than 65 534 nodes: 16-bit lane stacks, 24 KiB instead of 48): kLdsPlaneNodes16 node-plane entries
+constexpr size_t kNodePlaneBytes16 = (size_t)7 * kLdsPlaneNodes16 * sizeof(float2);
+constexpr size_t kMidLdsBytes16 = (size_t)kMidStack * kMidBlock * 2 + kNodePlaneBytes16 + kLeafTableBytes + kInstPlaneBytes;
+static_assert(kMidLdsBytes <= 81920 && kMidLdsBytes16 <= 81920, "two workgroups per CU share 160 KiB of LDS");
 struct LdsTop {
-    float2* tl;    // node planes: plane p of entry e at tl[p * kLdsPlaneNodes + e]
+    float2* tl;    // node planes: plane p of entry e at tl[p * (plane entries) + e]
     uint32_t* lt;  // lt[j] = instance index of TLAS leaf n - 1 + j + 1 (node index n + j)
     float2* il;    // instance planes: plane p of instance i at il[p * kTlasLdsInst + i]; planes 0-5 = inverse transform, 6 = (nodes offset, leaf count)
-    __device__ inline explicit LdsTop(unsigned char* base)
-        : tl(reinterpret_cast<float2*>(base)), lt(reinterpret_cast<uint32_t*>(base + kNodePlaneBytes)),
-          il(reinterpret_cast<float2*>(base + kNodePlaneBytes + kLeafTableBytes)) {}
+    __device__ inline explicit LdsTop(unsigned char* base, size_t node_plane_bytes = kNodePlaneBytes)
+        : tl(reinterpret_cast<float2*>(base)), lt(reinterpret_cast<uint32_t*>(base + node_plane_bytes)),
+          il(reinterpret_cast<float2*>(base + node_plane_bytes + kLeafTableBytes)) {}
     __device__ inline LdsTop() : tl(nullptr), lt(nullptr), il(nullptr) {}
 };
 // Fill it (all threads of the workgroup; caller synchronises).  n_inst <= kTlasLdsInst, blas_k <= kLdsPlaneNodes - (n_inst - 1).
-template <int BLOCK>
+template <int BLOCK, int PLANE_NODES = kLdsPlaneNodes>
 __device__ inline void stage_lds_top(const LdsTop& t, const SceneView& v, uint32_t blas_k, uint32_t lds_blas_base) {
     const RcNode* tnodes = v.blas_nodes + v.tlas_off;
     const uint32_t n_inst = (v.n_tlas_nodes + 1u) >> 1;
     for (uint32_t i = threadIdx.x; i < (n_inst - 1u) * 7u; i += BLOCK) {  // TLAS interior nodes 1..n-1
         const uint32_t nd = i / 7u, p = i % 7u;
-        t.tl[p * kLdsPlaneNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
+        t.tl[p * PLANE_NODES + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
     }
     for (uint32_t i = threadIdx.x; i < blas_k * 7u; i += BLOCK) {  // single-BLAS scene: its top internal nodes sit first in the traversal copy
         const uint32_t nd = i / 7u, p = i % 7u;
-        t.tl[p * kLdsPlaneNodes + lds_blas_base + nd] = reinterpret_cast<const float2*>(v.blas_nodes + nd)[p];
+        t.tl[p * PLANE_NODES + lds_blas_base + nd] = reinterpret_cast<const float2*>(v.blas_nodes + nd)[p];
     }
     for (uint32_t j = threadIdx.x; j < n_inst; j += BLOCK)  // child1 word (dword 13) of leaf node n + j
         t.lt[j] = reinterpret_cast<const uint32_t*>(tnodes + (n_inst - 1u + j))[13];
@@ -461,16 +472,19 @@ __device__ inline void stage_lds_top(const LdsTop& t, const SceneView& v, uint32
 // TLAS leaves, instance records and everything below the tops are read from memory as in the plain kernel.
 constexpr size_t kPartialPlaneBytes = (size_t)7 * kPartialPlaneNodes * sizeof(float2);
 constexpr size_t kPartialLdsBytes = (size_t)kMidStack * kMidBlock * 4 + kPartialPlaneBytes;
-template <int BLOCK>
+constexpr size_t kPartialPlaneBytes16 = (size_t)7 * kPartialPlaneNodes16 * sizeof(float2);
+constexpr size_t kPartialLdsBytes16 = (size_t)kMidStack * kMidBlock * 2 + kPartialPlaneBytes16;
+static_assert(kPartialLdsBytes <= 81920 && kPartialLdsBytes16 <= 81920, "two workgroups per CU share 160 KiB of LDS");
+template <int BLOCK, int PLANE_NODES = kPartialPlaneNodes>
 __device__ inline void stage_partial_top(float2* tl, const SceneView& v, uint32_t tlas_k, uint32_t blas_k, uint32_t lds_blas_base) {
     const RcNode* tnodes = v.blas_nodes + v.tlas_off;
     for (uint32_t i = threadIdx.x; i < tlas_k * 7u; i += BLOCK) {
         const uint32_t nd = i / 7u, p = i % 7u;
-        tl[p * kPartialPlaneNodes + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
+        tl[p * PLANE_NODES + nd] = reinterpret_cast<const float2*>(tnodes + nd)[p];
     }
     for (uint32_t i = threadIdx.x; i < blas_k * 7u; i += BLOCK) {
         const uint32_t nd = i / 7u, p = i % 7u;
-        tl[p * kPartialPlaneNodes + lds_blas_base + nd] = reinterpret_cast<const float2*>(v.blas_nodes + nd)[p];
+        tl[p * PLANE_NODES + lds_blas_base + nd] = reinterpret_cast<const float2*>(v.blas_nodes + nd)[p];
     }
 }
 
@@ -510,14 +524,17 @@ __device__ inline float3_ safe_inv3(const float3_ d) {
 #endif
 
 template <bool ANY, int LDS_N, bool STATS, class Source, class Sink, int BLOCK = kBlock, bool TLAS_LDS = false, bool INST_LDS = TLAS_LDS, bool PARTIAL_LDS = false,
-          bool TIMELINE = false>
-__device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, uint32_t* lds_stack, const Source& src, const Sink& sink,
-                                    const LdsTop top = LdsTop()) {
+          bool TIMELINE = false, bool STACK16 = false>
+__device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, typename std::conditional<STACK16, uint16_t, uint32_t>::type* lds_stack, const Source& src,
+                                    const Sink& sink, const LdsTop top = LdsTop()) {
+    typedef typename std::conditional<STACK16, uint16_t, uint32_t>::type stack_entry_t;
+    // node values that are not nodes: the 32-bit INVALID / sentinel of the reference, or their low halves where everything fits 16 bits
+    constexpr uint32_t kInv = STACK16 ? 0xFFFFu : RC_INVALID_NODE, kSent = STACK16 ? 0xFFFEu : RC_TOP_LEVEL_SENTINEL;
     const float2* const tl = top.tl;
     const uint32_t* const lt = top.lt;
     const float2* const il = top.il;
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
-    LaneStackP<LDS_N, BLOCK> st(lds_stack + threadIdx.x, av.overflow + gtid, av.total_threads, av.status);
+    LaneStackP<LDS_N, BLOCK, stack_entry_t> st(lds_stack + threadIdx.x, av.overflow + gtid, av.total_threads, av.status);
     const int lane = threadIdx.x & 63;
     if (av.n_tlas_nodes == 0) {  // empty TLAS: every ray misses (test/test_tlas_stress.jl:808-831)
         for (uint64_t i = gtid; i < a.n_items; i += av.total_threads) sink(i, false, 0.0f, 0.0f, 0.0f, RC_INVALID_NODE, -1);
@@ -542,7 +559,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
     v2f oyz = {0.f, 0.f}, ozx = {0.f, 0.f}, dyz = {0.f, 0.f}, dzx = {0.f, 0.f};
     float tmin = 0.f, closest_t = 0.f, hit_u = 0.f, hit_v = 0.f;
     uint32_t closest_prim = RC_INVALID_NODE, cur_off = 0, n_level = 0;
-    uint32_t node = RC_INVALID_NODE;  // INVALID + !live = empty lane; INVALID + live = finished, result pending
+    uint32_t node = kInv;  // INVALID + !live = empty lane; INVALID + live = finished, result pending
     int closest_inst = -1, cur_inst = -1;
     // cost-ordered claiming (RcClaim::cost): a ray's cost = the interior-loop iterations its wave ran while the ray was in flight -- the time
     // the ray occupied its lane, in the unit the launch's tail is made of.  The wave's iteration count lives in a scalar register and every
@@ -560,7 +577,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
         life_thr = __builtin_amdgcn_readfirstlane(a.claim.hist[kHistLifeThr]);  // 0xFFFFFFFF: this launch does not record
         if (life_thr == 0xFFFFFFFFu) claim_cost = nullptr;
     }
-    typename LaneStackP<LDS_N, BLOCK>::pos_t sp = st.empty();
+    typename LaneStackP<LDS_N, BLOCK, stack_entry_t>::pos_t sp = st.empty();
     bool live = false;
     unsigned long long st_iter[4] = {0, 0, 0, 0}, st_lane[4] = {0, 0, 0, 0}, st_outer = 0, st_sub[4] = {0, 0, 0, 0}, st_cull = 0;  // st_sub: passes with an exit lane / an entry lane / a result to write / rays to start
     unsigned long long st_t0 = STATS ? wall_clock64() : 0ull, st_tx = 0ull;
@@ -598,7 +615,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
 #endif
                 float4 na, nb, nc;
                 u2v ch;
-                constexpr int PS = PARTIAL_LDS ? kPartialPlaneNodes : kLdsPlaneNodes;  // plane stride
+                constexpr int PS = PARTIAL_LDS ? (STACK16 ? kPartialPlaneNodes16 : kPartialPlaneNodes) : (STACK16 ? kLdsPlaneNodes16 : kLdsPlaneNodes);  // plane stride
                 if ((TLAS_LDS && (cur_inst < 0 || node <= a.blas_k)) || (PARTIAL_LDS && node <= (cur_inst < 0 ? a.tlas_k : a.blas_k))) {
                     const float2* q = tl + ((node - 1u) + (cur_inst < 0 ? 0u : a.lds_blas_base));
                     const float2 p0 = q[0], p1 = q[PS], p2 = q[2 * PS], p3 = q[3 * PS], p4 = q[4 * PS], p5 = q[5 * PS], p6 = q[6 * PS];
@@ -634,7 +651,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
         }
         // ---- leaf phase: fast_intersect_triangle (:1756-1797) on BLAS leaves, then pop
         {
-            const bool is_leaf = cur_inst >= 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
+            const bool is_leaf = cur_inst >= 0 && node >= n_level && node < kSent;
             if (STATS && __ballot(is_leaf)) { st_iter[2] += 1; st_lane[2] += is_leaf ? 1 : 0; }
             RC_MARK("leaf_begin");
             if (is_leaf) {
@@ -662,7 +679,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                 closest_t = hit ? t : closest_t;
                 hit_u = hit ? u : hit_u;
                 hit_v = hit ? v : hit_v;
-                if (ANY && hit) node = RC_INVALID_NODE;  // :2106-2115
+                if (ANY && hit) node = kInv;  // :2106-2115
                 else node = st.pop(sp);
             }
             RC_MARK("leaf_end");
@@ -670,8 +687,8 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
         // ---- switch phase: return to the top level (:1996-2006) or enter an instance (:1961-1977)
         bool was_skipped = false;
         {
-            const bool is_exit = node == RC_TOP_LEVEL_SENTINEL;
-            const bool is_entry = cur_inst < 0 && node >= n_level && node < RC_TOP_LEVEL_SENTINEL;
+            const bool is_exit = node == kSent;
+            const bool is_entry = cur_inst < 0 && node >= n_level && node < kSent;
             if (STATS && __ballot(is_exit || is_entry)) { st_iter[3] += 1; st_lane[3] += (is_exit || is_entry) ? 1 : 0; }
             if (STATS) { if (__ballot(is_exit)) st_sub[0] += 1; if (__ballot(is_entry)) st_sub[1] += 1; }
             RC_MARK("switch_begin");
@@ -724,7 +741,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                     m0 = buf_f4(irs, ioff); m1 = buf_f4(irs, ioff, 16); m2 = buf_f4(irs, ioff, 32);
                     m3 = __builtin_amdgcn_raw_buffer_load_b128(irs, ioff, 48, 0);
                 }
-                st.push(sp, RC_TOP_LEVEL_SENTINEL);
+                st.push(sp, kSent);
                 node = 1;
                 cur_off = m3.x;
                 n_level = m3.w;
@@ -744,7 +761,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
         {
             RC_MARK("finish_begin");
             if (STATS) st_outer += 1;
-            const bool fin = live && node == RC_INVALID_NODE;
+            const bool fin = live && node == kInv;
             const int n_free = __popcll(__ballot(fin || !live));
             const bool can_refill = !(exhausted && pool_next == pool_end);
             if (STATS && !can_refill && st_tx == 0) st_tx = wall_clock64();
@@ -814,7 +831,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, u
                         closest_inst = -1; cur_inst = -1;
                         cur_off = tlas_off; n_level = n_instances;
                         sp = st.empty();
-                        st.push(sp, RC_INVALID_NODE);
+                        st.push(sp, kInv);
                         node = 1;
                         live = true;
                         start_it = it_total;

@@ -264,18 +264,21 @@ def test_blas_top_renumbering(rc, oracle, n_tris, n_inst):
     cfg = {"blas": [(verts, None)], "instances": [(1, xf[:n_inst], np.arange(n_inst, dtype=np.uint32))]}
     t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
     n_int = len(o.blas_prims) - 1
-    assert t.get_option("blas_top_k") == min(n_int, 310 - (n_inst - 1))
+    assert t.get_option("stack16_in_use") == 1   # every tree below 65 534 nodes: 16-bit lane stacks, 748 node-plane entries instead of 310
+    assert t.get_option("blas_top_k") == min(n_int, 748 - (n_inst - 1))
     assert t.adapt().all_blas_nodes.tobytes() == o.blas_nodes.tobytes()
     wb = o.world_bound
     rays = random_rays(rc, 150_000, n_tris, wb[:3], wb[3:])
     want, want_any = o.trace(rays, nthreads=8), o.trace(rays, mode="any", nthreads=8)
     assert want["hit"].any()
-    for kernel, top in ((5, 1), (5, 0), (0, 1), (1, 1), (3, 1), (4, 1), (6, 1), (6, 0)):
+    for kernel, top, s16 in ((5, 1, 1), (5, 0, 1), (0, 1, 1), (1, 1, 1), (3, 1, 1), (4, 1, 1), (6, 1, 1), (6, 0, 1), (5, 1, 0), (6, 1, 0), (-1, 1, 0)):
         t.set_option("kernel", kernel)
         t.set_option("blas_top", top)
-        assert_hits_equal(t.trace(rays), want, f"kernel {kernel} blas_top {top} closest")
-        assert_hits_equal(t.trace(rays, mode="any"), want_any, f"kernel {kernel} blas_top {top} any")
+        t.set_option("stack16", s16)     # 0: the 32-bit shape stages a PREFIX of the same renumbered top
+        assert_hits_equal(t.trace(rays), want, f"kernel {kernel} blas_top {top} stack16 {s16} closest")
+        assert_hits_equal(t.trace(rays, mode="any"), want_any, f"kernel {kernel} blas_top {top} stack16 {s16} any")
     t.set_option("blas_top", 1)
+    t.set_option("stack16", 1)
     t.set_option("kernel", 5)
     h2 = t.push_instances(t.add_geometry(sc.fan_sphere(12, 7)))  # a second BLAS: plain copy again
     t.sync()
@@ -307,8 +310,9 @@ def test_large_top_level_partial_lds(rc, oracle, n_tris, n_inst, n_blas):
     n_int_tlas = n_inst - 1
     n_int_blas = len(o.blas_prims) - 1 if n_blas == 1 else 0
     tk, bk = t.get_option("tlas_top_k"), t.get_option("blas_top_k")
-    assert 0 < tk <= min(n_int_tlas, 585) and bk <= min(n_int_blas, 585) and tk + bk <= 585
-    assert tk + bk == min(585, n_int_tlas + n_int_blas)
+    P = 1023 if t.get_option("stack16_in_use") else 585   # node-plane entries of kernel 6 (16-bit lane stacks leave room for 1023)
+    assert P == 1023 and 0 < tk <= min(n_int_tlas, P) and bk <= min(n_int_blas, P) and tk + bk <= P
+    assert tk + bk == min(P, n_int_tlas + n_int_blas)
     st = t.adapt()
     assert st.nodes.tobytes() == o.tlas_nodes.tobytes() and st.all_blas_nodes.tobytes() == o.blas_nodes.tobytes()
     wb = o.world_bound
@@ -317,11 +321,11 @@ def test_large_top_level_partial_lds(rc, oracle, n_tris, n_inst, n_blas):
     def check_all(what):
         want, want_any = o.trace(rays, nthreads=8), o.trace(rays, mode="any", nthreads=8)
         assert want["hit"].any()
-        for kernel in (6, 3, 0, 1, 5):  # 5 falls back to 3 here (too many instances)
-            t.set_option("kernel", kernel)
-            assert_hits_equal(t.trace(rays), want, f"{what} kernel {kernel} closest")
-            assert_hits_equal(t.trace(rays, mode="any"), want_any, f"{what} kernel {kernel} any")
-        t.set_option("kernel", -1)
+        for kernel, s16 in ((6, 1), (6, 0), (3, 1), (0, 1), (1, 1), (5, 1)):  # 5 falls back to 3 here (too many instances); stack16 0: kernel 6 stages a 585-entry prefix of the renumbered tops
+            t.set_option("kernel", kernel); t.set_option("stack16", s16)
+            assert_hits_equal(t.trace(rays), want, f"{what} kernel {kernel} stack16 {s16} closest")
+            assert_hits_equal(t.trace(rays, mode="any"), want_any, f"{what} kernel {kernel} stack16 {s16} any")
+        t.set_option("kernel", -1); t.set_option("stack16", 1)
 
     check_all("built")
     xf2 = xf.copy()
@@ -498,10 +502,12 @@ def test_deep_trees_use_the_stack_spill_path(rc, oracle):
     max_sp = t.get_option("stat2")
     t.set_option("stats", 0)
     assert max_sp > 24, f"scene too shallow to reach the spill path (max stack {max_sp})"
-    for k in (-1, 0, 2, 3, 4, 5, 6):
-        t.set_option("kernel", k)
-        assert_hits_equal(t.trace(rays), want, f"deep k{k}")
-        assert_hits_equal(t.trace(rays, mode="any"), o.trace(rays, mode="any", nthreads=8), f"deep any k{k}")
+    assert t.get_option("stack16_in_use") == 1   # small trees: kernels 5 / 6 keep 16-bit lane-stack entries in LDS; the spill area beyond the LDS depth holds the same values in 32-bit words
+    want_any = o.trace(rays, mode="any", nthreads=8)
+    for k, s16 in ((-1, 1), (0, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (5, 0), (6, 0)):
+        t.set_option("kernel", k); t.set_option("stack16", s16)
+        assert_hits_equal(t.trace(rays), want, f"deep k{k} stack16 {s16}")
+        assert_hits_equal(t.trace(rays, mode="any"), want_any, f"deep any k{k} stack16 {s16}")
 
 
 def test_full_size_c2_properties(rc, oracle):
@@ -851,3 +857,23 @@ def test_refit_equals_rebuild_boxes(rc, oracle):  # refit_tlas! keeps topology, 
     o.build()
     assert np.array_equal(np.concatenate(t.world_bound()), o.world_bound)
     assert_hits_equal(t.trace(rays), o.trace(rays, nthreads=8), "refit")
+
+
+def test_stack16_applies_only_where_every_node_index_fits(rc, oracle):
+    """Round 5: scenes whose trees ALL have fewer than 65 534 nodes run kernels 5 / 6 with 16-bit lane-stack entries (INVALID and the sentinel
+    are their own low halves there); one BLAS of 32 768 triangles, or 32 768 instances, and the scene keeps the 32-bit shape.  Results are
+    the oracle's on both sides of the limit and with the option off."""
+    sc = rc.scenes
+    for n_tris, expect in ((32767, 1), (32768, 0)):
+        verts = sc.random_triangles(n_tris, 77, lo=-0.5, hi=0.5, edge=0.05)
+        xf, _, _ = sc.lattice_transforms(2, 2, 1, 1.2, 9)
+        cfg = {"blas": [(verts, None)], "instances": [(1, xf, np.arange(len(xf), dtype=np.uint32))]}
+        t, o = build_product(rc, cfg), build_oracle(oracle, cfg)
+        assert t.get_option("stack16_in_use") == expect and t.get_option("blas_top_k") == (748 if expect else 310) - (len(xf) - 1)
+        wb = o.world_bound
+        rays = random_rays(rc, 200_000, n_tris, wb[:3], wb[3:])
+        want = o.trace(rays, nthreads=8)
+        for s16 in (1, 0):
+            t.set_option("stack16", s16)
+            assert_hits_equal(t.trace(rays), want, f"{n_tris} triangles, stack16 {s16}")
+        t.free()

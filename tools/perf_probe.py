@@ -80,7 +80,7 @@ def main():
     wl = {"c2": ("C2 closest", t2, rays2, "closest"), "c3": ("C3 primary", t3, rays3, "closest"),
           "shadow": ("C3 shadow-any", t3, shadow, "any"), "c4": ("C4 bounce", t3, bounce, "closest")}
     wl.update(wl_extra)
-    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 36, "pool": 0, "claim_shards": 16, "taper": 12, "cost_order": 1, "cost_thr": 64, "entry_cull": 1,
+    defaults = {"kernel": -1, "blocks_per_cu": 0, "lds_stack": 24, "refill": 20, "stats": 0, "sched_thr": 36, "pool": 0, "claim_shards": 16, "taper": 12, "cost_order": 1, "cost_thr": 64, "entry_cull": 1, "stack16": 1,
                 }
     first_hits = {}
     for var in args.variants.split(";"):
