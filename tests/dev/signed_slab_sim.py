@@ -119,7 +119,7 @@ class Model:
         return np.array(out, np.int16)
 
 
-def simulate(seq, thr=36, refill=20):
+def simulate(seq, thr=36, refill=20, buf_min=1, buf_wait=0):
     """One wave under the kernel's phase policy; returns the pass statistics of the interior loop + the phase counts."""
     nxt = 0
     cur = [None] * 64
@@ -137,11 +137,21 @@ def simulate(seq, thr=36, refill=20):
 
     while True:
         st["outer"] += 1
+        waited = 0
         while True:
             m = kind == K_INT
             n = int(m.sum())
             if n == 0:
                 break
+            # TD experiment (profiles/r05_td_model.txt): the texture path is charged per wave-INSTRUCTION, so a pass's buffer loads cost the same
+            # for 1 lane as for 64.  Policy: buffer lanes sit a pass out unless >= buf_min of them are ready, nothing else is, or they have waited buf_wait passes
+            nb_ready = int((m & (lds == 0)).sum())
+            if buf_min > 1 and 0 < nb_ready < buf_min and nb_ready < n and waited < buf_wait:
+                m = m & (lds == 1)
+                n = int(m.sum())
+                waited += 1
+            else:
+                waited = 0
             nl = int(lds[m].sum())
             uniform = len(set(octv[m].tolist())) == 1
             st["I"] += 1; st["I_lanes"] += n; st["I_lds_lanes"] += nl
