@@ -41,9 +41,9 @@ HBM_ACHIEVABLE_GBS = 6300.0  # same guide: ~6.3 TB/s achievable
 # 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instructions / s.  (Round 2 divided by 4 cycles -- the measured cost of v_mul / v_add /
 # v_mov -- which the builder's own probe contradicts for v_fma_f32; the per-opcode measurements now enter through `mix_ceiling`.)
 VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
-COUNTER_FILE = os.path.join("profiles", "r04_pmc_c3.json")          # per-launch PMC counters of the bench kernel (tools/capture_profiles.sh)
-WORKLOADS_FILE = os.path.join("profiles", "r04_pmc_workloads_kernel5.json")  # the same counters for the extras' workloads: C2, shadow rays, C4, random geometry, C3 1 Mi rays (tools/pmc_workloads.sh)
-MIX_FILE = os.path.join("profiles", "r04_isa_mix_kernel5.json")     # dynamic opcode histogram of the bench kernel x measured cycles per opcode (tools/isa_mix.py)
+COUNTER_FILE = os.path.join("profiles", "r05_pmc_c3.json")          # per-launch PMC counters of the bench kernel (tools/capture_profiles.sh)
+WORKLOADS_FILE = os.path.join("profiles", "r05_pmc_workloads_kernel5.json")  # the same counters for the extras' workloads: C2, shadow rays, C4, random geometry, C3 1 Mi rays, the HBM-bound regime (tools/pmc_workloads.sh)
+MIX_FILE = os.path.join("profiles", "r05_isa_mix_kernel5.json")     # dynamic opcode histogram of the bench kernel x measured cycles per opcode (tools/isa_mix.py)
 COUNTS_FILE = os.path.join("profiles", "c3_reference_counts.json")  # reference-algorithm fetch counts per ray for this workload (written by the N=1 run)
 # Fallback when the counts file is missing (same numbers, measured by the oracle in round 1)
 C3_NODE_FETCHES_PER_RAY = 33.006
@@ -90,6 +90,13 @@ def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_
                     "lane_throughput_frac": round(frac * lane_util, 4) if lane_util else None,
                     "hbm_physical_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                     "vmem_wave_instructions_per_launch": c.get("SQ_INSTS_VMEM_RD"),
+                    # round 5 (profiles/r05_bound_probe.txt, r05_td_model.txt): what the waves wait for.  TD is busy per fetch INSTRUCTION whatever the exec mask.
+                    "waiting_frac_of_wave_cycles": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES") else None,
+                    "td_busy_frac": round(c["TD_TD_BUSY_sum"] / c["GRBM_GUI_ACTIVE"] / 32.0, 4) if c.get("TD_TD_BUSY_sum") and c.get("GRBM_GUI_ACTIVE") else None,
+                    "ta_busy_frac": round(c["TA_TA_BUSY_sum"] / c["GRBM_GUI_ACTIVE"] / 32.0, 4) if c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE") else None,
+                    "what_bounds_it": "the length of each ray's chain of dependent passes (fetch through the texture path -> ~8 dependent VALU levels -> stack access) at a fixed number of rays "
+                                      "in flight: serial work added to a pass costs 2.3-2.5x its length, VALU work removed beside the chain buys nothing (12 of the 20 min / max of every C2 pass: "
+                                      "SQ_INSTS_VALU -8.7 %, launch time unchanged).  `frac` stays the VALU-issue figure of earlier rounds for continuity; it is not the binding roof.",
                     "sources": {"valu_wave_instructions_per_launch, lane_utilisation, traffic": COUNTER_FILE + " (rocprofv3 --pmc passes over this bench command, tools/capture_profiles.sh; its fingerprint matches the kernel sources of this run; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md: the traffic is the coalesced ray / hit stream)",
                                 "avg_launch_ms": "HIP events around every timed launch, this run",
                                 "peak": "MI355X_MICROARCH.md execution model: a wave64 VALU instruction issues over 2 cycles on the SIMD-32: 256 CUs x 4 SIMDs x 2.4 GHz / 2",

@@ -587,7 +587,7 @@ uint32_t rc_persistent_blocks(rc_scene* s, uint64_t n_items) {
 }
 
 // kernels 5 / 6 in their STACK16 shape: the scene's trees are all small enough, nobody asked for counters or a timeline (dev builds keep the 32-bit shape)
-static bool rc_stack16(rc_scene* s) { return s->small_trees && s->opt.stack16 && !s->opt.stats && !s->opt.timeline_ptr; }
+static bool rc_stack16(rc_scene* s) { return s->small_trees && s->opt.stack16 && !s->opt.timeline_ptr; }
 
 template <bool ANY>
 static void launch_variant(rc_scene* s, int64_t kernel, const TraceArgs& a, uint32_t blocks, hipStream_t stream) {
@@ -608,7 +608,10 @@ static void launch_variant(rc_scene* s, int64_t kernel, const TraceArgs& a, uint
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
             attr_set = true;
         }
-        if (stats) {  // dev: the same kernel with per-phase pass / lane counters (option "stats"; tools/isa_mix.py weights the phases' static opcode histograms with them)
+        if (stats && rc_stack16(s)) {  // dev: the same kernel with per-phase pass / lane counters (option "stats"; tools/isa_mix.py weights the phases' static opcode histograms with them)
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes16));
+            hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes16, stream, a);
+        } else if (stats) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
             hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
         } else if (a.timeline) {  // dev: the same kernel with per-wave event times written to the caller's buffer (option "timeline_ptr")

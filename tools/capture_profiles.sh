@@ -4,7 +4,7 @@
 # Counters are collected in their own passes (--pmc with --kernel-trace only), HBM counters FETCH_SIZE / WRITE_SIZE in separate passes,
 # FETCH_SIZE doubled afterwards (gfx950 reports half of a 16 B/lane coalesced stream; MI355X_MICROARCH.md, HBM section).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/$R; P=$O/profiles
 mkdir -p $O $P
 CMD="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"

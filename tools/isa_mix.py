@@ -13,12 +13,12 @@ with the dynamic histogram built here from three committed inputs:
     switch / finish phases; the marker build must have the same VALU instruction count and register use as the product build -- checked),
     VALU opcodes counted per phase;
   * how often a wave runs each phase: the pass counters of the kernel's STATS instantiation (tools/phase_passes.py on the GPU box,
-    profiles/r04_phase_passes_kernel5.json);
+    profiles/r05_phase_passes_kernel5.json);
   * cycles per opcode: profiles/r02_valu_probe.txt (tools/archive/valu_probe.hip), ns per wave-instruction per SIMD x 2.4 GHz.
 The prediction sum(passes x static count) is compared with the measured SQ_INSTS_VALU of the counter file: that is the check that the
 histogram describes what ran.
 
-    python3 tools/isa_mix.py [--workload c3] > profiles/r04_isa_mix_kernel5.json
+    python3 tools/isa_mix.py [--workload c3] > profiles/r05_isa_mix_kernel5.json
 """
 import argparse
 import collections
@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "raycore.jl_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize"] + os.environ.get("RC_EXTRA_FLAGS", "").split() + [ "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "--cuda-device-only", "-S"]
-KERNEL = "k_trace_phased_ldsILb0ELi768ELi16ELi6ELb0ELb0EE"  # <closest, 768 threads, 16-entry LDS stacks, 6 waves / SIMD, no timeline, no stats>
+KERNEL = "k_trace_phased_ldsILb0ELi768ELi16ELi6ELb0ELb0ELb1EE"  # <closest, 768 threads, 16-entry LDS stacks, 6 waves / SIMD, no timeline, no stats, 16-bit stack entries (C3's trees are small)>
 CLOCK_GHZ = 2.4
 
 
@@ -164,8 +164,8 @@ def cycles3(op, table, which):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c3")
-    ap.add_argument("--passes", default=os.path.join(ROOT, "profiles", "r04_phase_passes_kernel5.json"))
-    ap.add_argument("--counters", default=os.path.join(ROOT, "profiles", "r04_pmc_c3.json"))
+    ap.add_argument("--passes", default=os.path.join(ROOT, "profiles", "r05_phase_passes_kernel5.json"))
+    ap.add_argument("--counters", default=os.path.join(ROOT, "profiles", "r05_pmc_c3.json"))
     args = ap.parse_args()
     marked, meta_m = assembly(True)
     plain, meta_p = assembly(False)
@@ -176,7 +176,7 @@ def main():
             static[region][op] += 1
     n_valu_marked = sum(sum(c.values()) for c in static.values())
     n_valu_plain = sum(1 for _, op in instructions(plain) if op.startswith("v_"))
-    out = {"kernel": "k_trace_phased_lds<false, 768, 16, 6, false, false>", "source": "hipcc -S --cuda-device-only of raycore.jl_amd/csrc/rc_traverse.hip with the Makefile's flags",
+    out = {"kernel": "k_trace_phased_lds<false, 768, 16, 6, false, false, true>", "source": "hipcc -S --cuda-device-only of raycore.jl_amd/csrc/rc_traverse.hip with the Makefile's flags",
            "marker_build_matches_product": {"valu_instructions": [n_valu_marked, n_valu_plain], "registers": [meta_m, meta_p],
                                             "same": n_valu_marked == n_valu_plain and meta_m == meta_p},
            "static_valu_instructions_per_phase": {r: sum(c.values()) for r, c in static.items()},

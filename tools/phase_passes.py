@@ -1,7 +1,7 @@
 """How often a wave of the dominant trace kernel runs each of its phases, per launch (GPU box): kernel 5's STATS instantiation
 (option "stats") counts, per wave and summed over the launch, the interior-loop iterations, the leaf / switch / refill passes that
 had at least one lane to serve, the lanes served, and the outer iterations.  tools/isa_mix.py weights the static opcode histogram of
-each phase with these.  python3 tools/phase_passes.py > profiles/r03_phase_passes_kernel5.json"""
+each phase with these.  python3 tools/phase_passes.py > profiles/r05_phase_passes_kernel5.json"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +21,7 @@ hits3 = t3.trace(rays3)
 cfg2 = sc.config_c2(); t2 = build(cfg2)
 wl = {"c3": (t3, rays3, "closest"), "c3_shadow": (t3, sc.c3_shadow_rays(cfg3, rays3, hits3), "any"),
       "c4": (t3, sc.c4_bounce_rays(cfg3, rays3, hits3, 4 * len(rays3)), "closest"), "c2": (t2, rc.generate_ray_grid(t2, cfg2["viewdir"], cfg2["grid"]), "closest")}
-out = {"kernel": "k_trace_phased_lds<ANY, 768, 16, 6, false, true> (the STATS instantiation of trace kernel 5)", "workloads": {}}
+out = {"kernel": "k_trace_phased_lds<ANY, 768, 16, 6, false, true, STACK16> (the STATS instantiation of trace kernel 5, in the shape the product runs the scene with)", "workloads": {}}
 for t_ in (t2, t3):
     if len(sys.argv) > 1 and sys.argv[1] == "nocull":
         t_.set_option("entry_cull", 0)
