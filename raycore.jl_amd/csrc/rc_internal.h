@@ -35,7 +35,7 @@ struct PinnedU32 {  // one word of pinned host memory a kernel can write and the
     PinnedU32& operator=(PinnedU32&& o) noexcept { if (this != &o) { drop(); p = o.p; o.p = nullptr; } return *this; }
     ~PinnedU32() { drop(); }
     void drop() { if (p) (void)hipHostFree(p); p = nullptr; }
-    void ensure() { if (!p) { RC_HIP(hipHostMalloc((void**)&p, 64, hipHostMallocDefault)); *p = 0u; } }
+    void ensure() { if (!p) { RC_HIP(hipHostMalloc((void**)&p, 64, hipHostMallocDefault)); for (int k = 0; k < 16; ++k) p[k] = 0u; } }  // (a cache line: users keep a few words)
 };
 
 template <typename T>
@@ -69,18 +69,24 @@ struct DevBuf {  // owning device buffer, grow-only reuse
 // stream it fails, so an entry keyed by a dead stream was never handed on).
 struct RcEvent {
     hipEvent_t e = nullptr;
-    bool recorded = false;
+    bool recorded = false, owned = false;
     RcEvent() = default;
     RcEvent(const RcEvent&) = delete;
     RcEvent& operator=(const RcEvent&) = delete;
-    RcEvent(RcEvent&& o) noexcept : e(o.e), recorded(o.recorded) { o.e = nullptr; o.recorded = false; }
-    RcEvent& operator=(RcEvent&& o) noexcept { if (this != &o) { drop(); e = o.e; recorded = o.recorded; o.e = nullptr; o.recorded = false; } return *this; }
+    RcEvent(RcEvent&& o) noexcept : e(o.e), recorded(o.recorded), owned(o.owned) { o.e = nullptr; o.recorded = o.owned = false; }
+    RcEvent& operator=(RcEvent&& o) noexcept { if (this != &o) { drop(); e = o.e; recorded = o.recorded; owned = o.owned; o.e = nullptr; o.recorded = o.owned = false; } return *this; }
     ~RcEvent() { drop(); }
-    void drop() { if (e) (void)hipEventDestroy(e); e = nullptr; recorded = false; }
-    void record(hipStream_t st) {
-        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return; }
+    void drop() { if (e && owned) (void)hipEventDestroy(e); e = nullptr; recorded = owned = false; }
+    void record(hipStream_t st) {  // an event of its own behind the stream's work so far
+        if (e && !owned) drop();
+        if (!e) { if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return; } owned = true; }
         if (hipEventRecord(e, st) == hipSuccess) recorded = true; else (void)hipGetLastError();
     }
+    // ... or the closing event the launch recorded anyway (its counter slot's t1, which lives as long as the scene): one event record per
+    // launch fewer for each resource -- an event record is a packet of its own on the queue, ~3 us between two kernels.  The slot's next
+    // launch records t1 again; that launch runs behind this one (same stream, or it waited for t1 first: RcLaunchGuard), so "t1 is done"
+    // still implies "this launch is done" -- the answer can only come later than with an event of its own, never earlier.
+    void follow(hipEvent_t closing) { drop(); e = closing; recorded = closing != nullptr; }
     bool idle() const {  // never blocks
         if (!recorded) return true;
         const hipError_t q = hipEventQuery(e);
@@ -271,7 +277,10 @@ struct rc_scene {
         uint64_t last_use = 0;
         RcEvent last;                       // behind the latest launch that used the entry's buffers
         PinnedU32 fresh_streak;             // written by k_order_select: consecutive launches of this shape whose batch matched no slot
-        uint32_t skip_left = 0;             // launches still to run without the order kernels (the shape's batches do not repeat)
+        uint32_t skip_left = 0;             // launches still to run without the mechanism (the shape's batches do not repeat)
+        uint32_t rebuild_credit = 0;        // launches that still get the rebuild kernel pair in front (a slot may hold a recording: rc_cost_order_setup)
+        uint64_t next_record = 8;           // the launch of the shape that next asks its batch to record (cadence 7, 8, 9, ...)
+        uint32_t records_asked = 0;
     };
     static constexpr int kMaxHistories = 8;
     static constexpr int kRecentShapes = 16;

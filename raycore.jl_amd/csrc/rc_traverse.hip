@@ -435,7 +435,7 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
     if (s->opt.stats) RC_HIP(hipMemsetAsync(rc_stats_words(s), 0, kStatsWords * sizeof(unsigned long long), stream));
 }
 
-static int rc_event_mode() {  // dev (tools/archive/event_probe.py): RC_EVENT_MODE = 0 default events, 1 hipEventDisableSystemFence, 2 no t0 event, 3 no events at all (single-stream runs only)
+static int rc_event_mode() {  // dev (tools/archive/event_probe.py): RC_EVENT_MODE = 0 product, 1 hipEventDisableSystemFence on t1 too, 2 no t0 event, 3 no events at all (single-stream runs only), 4 system fence on t0 as well (rounds 3-4)
     static const int mode = [] { const char* e = getenv("RC_EVENT_MODE"); return e ? atoi(e) : 0; }();
     return mode;
 }
@@ -443,8 +443,10 @@ void RcLaunchGuard::start() {
     if (capturing) return;
     rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
     if (!slot.t0) {
-        const unsigned flags = rc_event_mode() == 1 ? hipEventDisableSystemFence : hipEventDefault;
-        RC_HIP(hipEventCreateWithFlags(&slot.t0, flags)); RC_HIP(hipEventCreateWithFlags(&slot.t1, flags));
+        // t0 only marks a time in front of the kernel: nothing is published by it, so it skips the system-scope fence (0.5 % of a back-to-back
+        // launch sequence, profiles/r05_launch_fixed_costs.txt); t1 keeps the default -- the host reads pinned words behind it
+        RC_HIP(hipEventCreateWithFlags(&slot.t0, rc_event_mode() == 4 ? hipEventDefault : hipEventDisableSystemFence));
+        RC_HIP(hipEventCreateWithFlags(&slot.t1, rc_event_mode() == 1 ? hipEventDisableSystemFence : hipEventDefault));
     }
     if (rc_event_mode() < 2) RC_HIP(hipEventRecord(slot.t0, stream));
 }
@@ -455,9 +457,11 @@ void RcLaunchGuard::finish() {
     rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
     if (rc_event_mode() < 3) RC_HIP(hipEventRecord(slot.t1, stream));
     // the per-stream resources this launch used are busy until here (asked by the next stream that wants to take one over)
-    if (s->cur_region >= 0) s->overflow_regions[s->cur_region].last.record(stream);
-    if (s->cur_history >= 0) s->histories[s->cur_history].last.record(stream);
-    if (s->cur_scratch >= 0) s->totals_scratch[s->cur_scratch].last.record(stream);
+    const bool closed = rc_event_mode() < 3;  // (they follow the launch's closing event instead of recording their own)
+    auto mark = [&](RcEvent& last) { if (closed) last.follow(slot.t1); else last.record(stream); };
+    if (s->cur_region >= 0) mark(s->overflow_regions[s->cur_region].last);
+    if (s->cur_history >= 0) mark(s->histories[s->cur_history].last);
+    if (s->cur_scratch >= 0) mark(s->totals_scratch[s->cur_scratch].last);
     slot.stream = stream;
     slot.recorded = true;
     slot.seq = ++s->timing_seq;
@@ -524,6 +528,8 @@ void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcCl
     out.g1 = (uint32_t)chunks[0]; out.g2 = (uint32_t)(chunks[0] + 2 * chunks[1]); out.g3 = (uint32_t)(chunks[0] + 2 * chunks[1] + 4 * chunks[2]);
     out.c1 = (uint32_t)chunks[0]; out.c2 = (uint32_t)(chunks[0] + chunks[1]); out.c3 = (uint32_t)(chunks[0] + chunks[1] + chunks[2]);
     out.order = nullptr; out.cost = nullptr; out.hist = nullptr;
+    out.sample_rays = nullptr; out.n_sample = 0; out.inv_l2 = 0.f; out.samples = nullptr; out.host_streak = nullptr; out.init_thr = 0; out.want_record = 0;
+    for (int k = 0; k < 8; ++k) out.sample_host[k] = 0.f;
     out.pool_shift = 0;
     while ((2u << out.pool_shift) <= out.pool) ++out.pool_shift;
 }
@@ -668,98 +674,30 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
 }
 
 // ---- cost-ordered claiming (RcClaim::order / cost / hist) -------------------------------------------------------------------------------
-// Small kernels in front of a launch turn what an earlier launch of the SAME BATCH recorded into this launch's claim order.
-//   k_order_select (one wave): which batch is this?  kHistSamples sample rays of the launch are compared with the samples kept for each of
-//     the history's kHistSlots batch slots (mean squared difference of direction and of origin / scene diagonal); the closest slot below
-//     the threshold is this batch's (its samples are replaced: a camera that moves a little per frame stays in its slot), otherwise the
-//     least recently used slot is given to it and its recorded costs are void ("fresh").  Two cameras, or N light samples, alternating on
-//     one stream therefore each learn from their own previous launch (VERDICT r3 #5a: with ONE history per shape the alternation ran
-//     4-6 % SLOWER than with no ordering at all, profiles/r04_alternating_batches.txt).
-//     A fresh batch runs in natural order.  (A first-launch PREDICTOR -- claim order from the number of top-of-tree boxes each chunk's
-//     middle ray passes, VERDICT r3 #5b -- was built and measured: reordering the chunks by it is worth 5-12 % of a 1 M-ray launch on C2 and
-//     C3, nothing on random geometry or any_hit rays, and the three extra small kernels it needs in front of the launch cost as much:
-//     profiles/r04_first_launch_predictor.txt.  Not kept.)
-//   k_order_count / k_order_scatter (they return at once unless the batch's slot holds a recording no order has been built from yet): the
-//     reported chunks in nine classes, linear in the lifetime of their longest ray between the reporting threshold and the top of the scale
+// Which batch a launch is, whether it claims through a learned order and whether it records is decided INSIDE the launch (order_select /
+// order_commit, rc_traverse_core.h): nothing runs in front of a launch for that (round 5; rounds 3-4 spent three small dispatches per launch,
+// ~3 % of a 4 M-ray step and ~4 % of a 1 M-ray one, profiles/r05_bench_with_extras_by_range.csv).  What is left to separate kernels is turning
+// a finished RECORDING into an order:
+//   k_order_count / k_order_scatter, for every batch slot whose cost array holds a recording no order has been built from yet (kHistPending):
+//     the reported chunks in nine classes, linear in the lifetime of their longest ray between the reporting threshold and the top of the scale
 //     the RECORDING launch worked with, longest first; then the chunks nobody reported; chunk ids ascending inside a class (a stable
 //     counting sort: k_order_count tallies the classes per 1024-chunk block, k_order_scatter places every chunk into the slot's order array,
 //     clears its cost for the slot's next recording and -- block 0 -- leaves the threshold and the scale of that next recording: the
 //     threshold moves so that roughly 10-40 % of the chunks report).
-//   Recording costs 25-30 us of a 0.37 ms launch (kHistRecordEvery, rc_traverse_core.h), so a slot records its launches 2-4 (never the first:
-//   a batch that does not come back must not pay for it) and then one in eight; the launches in between claim through the slot's order as it stands.
+//   The host enqueues the pair only in front of launches that MAY follow a recording (rc_cost_order_setup): the shape's first launches, the
+//   launches after a batch that was not a repeat was reported, and the launch after one the host's cadence asked to record -- one launch in
+//   eight of a repeating batch.  A recording the host misses (it learns of new batches through a pinned word, late when the caller enqueues
+//   far ahead) simply waits for the next pair.
+//   Recording costs 25-30 us of a 0.37 ms launch, so a slot records its launches 2-4 (never the first: a batch that does not come back must
+//   not pay for it) and then one in eight; the launches in between claim through the slot's order as it stands.
+//   (A first-launch PREDICTOR -- claim order from the number of top-of-tree boxes each chunk's middle ray passes -- was built and measured in
+//   round 4: worth 5-12 % of a 1 M-ray launch, and the small kernels it needs cost as much: profiles/r04_first_launch_predictor.txt.  Not kept.)
 // hist[kHistScale + 4 slot]: [0], [1] = the threshold / the top of the scale the slot's latest recording launch worked with; [2], [3] = the pair its next one will.
 namespace {
 constexpr int kOrderThreads = 256, kOrderPerThread = 4, kOrderTile = kOrderThreads * kOrderPerThread, kOrderClasses = 10, kOrderMaxBlocks = 256;
 static_assert((uint32_t)(kOrderTile * kOrderMaxBlocks) == kHistSlotStride, "a slot's cost array holds the most chunks the order kernels handle");
 constexpr int kOrderCountWords = kOrderClasses + 1;  // per block: the classes' chunk counts, the largest cost
-constexpr size_t kHistWords = kHistCounts + (size_t)kOrderMaxBlocks * kOrderCountWords;
-
-struct HostSample { float f[8]; };
-
-__global__ __launch_bounds__(64) void k_order_select(const RcRay* rays, uint64_t n, HostSample hs, float inv_l2, uint32_t* hist, float* samples, uint32_t init_thr, uint32_t* host_streak) {
-    const int lane = threadIdx.x;
-    float r[8];
-    if (rays) {
-        uint64_t idx = (uint64_t)lane * n / (uint64_t)kHistSamples + n / (2u * kHistSamples);
-        if (idx >= n) idx = n - 1;
-        const float4* q = reinterpret_cast<const float4*>(rays + idx);
-        const float4 a = q[0], b = q[1];
-        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
-    } else {
-        for (int k = 0; k < 8; ++k) r[k] = hs.f[k];
-    }
-    int best = -1;
-    float best_d = 0.02f;  // mean over the samples of |dd|^2 / |d|^2 + |do|^2 / diagonal^2: ~0.1 rad of rotation, or a tenth of the scene of travel
-    for (int k = 0; k < kHistSlots; ++k) {
-        if (hist[kHistStamp + k] == 0u) continue;
-        const float* sp = samples + ((size_t)k * kHistSamples + lane) * 8;
-        const float ox = r[0] - sp[0], oy = r[1] - sp[1], oz = r[2] - sp[2], dx = r[4] - sp[4], dy = r[5] - sp[5], dz = r[6] - sp[6];
-        const float na = r[4] * r[4] + r[5] * r[5] + r[6] * r[6], nb = sp[4] * sp[4] + sp[5] * sp[5] + sp[6] * sp[6];
-        float d = (dx * dx + dy * dy + dz * dz) / fmaxf(fmaxf(na, nb), 1e-30f) + (ox * ox + oy * oy + oz * oz) * inv_l2;
-        for (int m = 32; m > 0; m >>= 1) d += __shfl_xor(d, m);  // (a NaN anywhere: the sum is NaN and the comparison fails -- no match)
-        d *= 1.0f / kHistSamples;
-        if (d < best_d) { best_d = d; best = k; }
-    }
-    const bool fresh = best < 0;
-    const bool exact = best >= 0 && best_d == 0.0f;  // the same sample rays bit for bit in direction and origin: a REPEAT of the remembered batch (wave-uniform: best_d is a reduction)
-    int sel = best;
-    if (fresh) {  // an empty slot, else the least recently used one
-        uint32_t oldest = 0xFFFFFFFFu;
-        for (int k = 0; k < kHistSlots; ++k) { const uint32_t st = hist[kHistStamp + k]; if (st < oldest) { oldest = st; sel = k; } }
-    }
-    float* out = samples + ((size_t)sel * kHistSamples + lane) * 8;
-    for (int k = 0; k < 8; ++k) out[k] = r[k];
-    if (lane == 0) {
-        const uint32_t clock = hist[kHistClock] + 1u;
-        hist[kHistClock] = clock;
-        hist[kHistStamp + sel] = clock;
-        const uint32_t gen = fresh ? 1u : hist[kHistGen + sel] + 1u;
-        hist[kHistGen + sel] = gen;
-        uint32_t* scale = hist + kHistScale + 4 * sel;  // [0], [1]: (threshold, top) of the slot's latest recording; [2], [3]: of its next one (k_order_scatter)
-        if (fresh) { scale[0] = scale[2] = init_thr; scale[1] = scale[3] = init_thr + 8u; hist[kHistPending + sel] = 0u; }
-        // an order is (re)built from what the slot's latest recording launch left, classed with the scale that launch worked with;
-        // this launch records if the batch has just come back (launches 2-4: the threshold needs two rounds to settle) or its turn has
-        // come.  A batch seen for the FIRST time does not record: recording costs 7 % of a launch, and a workload whose batches never
-        // repeat -- a path tracer's bounce rays -- would pay it on every launch for nothing.
-        const bool rebuild = hist[kHistPending + sel] != 0u;
-        const bool record = (gen >= 2u && gen <= 4u) || gen % kHistRecordEvery == 0u;
-        hist[kHistSel] = (uint32_t)sel;
-        hist[kHistFresh] = fresh ? 1u : 0u;
-        hist[kHistRebuild] = rebuild ? 1u : 0u;
-        hist[kHistClassThr] = scale[0]; hist[kHistClassTop] = scale[1];
-        hist[kHistOrderValid] = gen >= 3u ? 1u : 0u;     // (the slot's third launch builds its first order, in this launch's k_order_scatter, from what the second recorded)
-        hist[kHistLifeThr] = record ? scale[2] : 0xFFFFFFFFu;
-        if (record) { scale[0] = scale[2]; scale[1] = scale[3]; }
-        hist[kHistPending + sel] = record ? 1u : 0u;     // (a pending recording is consumed by this launch's order kernels)
-        // Tell the host when this shape's batches are not REPEATS of remembered ones -- a path tracer's bounce rays (never matched), but also a
-        // camera that moves every frame: matched, its slot's order reused, and still 1.5-2 % slower than natural order, because the three
-        // small dispatches in front of the launch cost more than an order learned from SIMILAR rays gains (BENCH_r04 c3_moving_camera, VERDICT
-        // r4 #3).  The host then leaves these kernels out for a while.
-        const uint32_t streak = exact ? 0u : hist[kHistFreshStreak] + 1u;
-        hist[kHistFreshStreak] = streak;
-        if (host_streak) __hip_atomic_store(host_streak, streak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
+constexpr size_t kHistWords = kHistCounts + (size_t)kHistSlots * kOrderMaxBlocks * kOrderCountWords;
 
 __device__ inline int order_class(uint32_t c, uint32_t thr, uint32_t top) {
     if (c == 0u) return kOrderClasses - 1;
@@ -767,74 +705,86 @@ __device__ inline int order_class(uint32_t c, uint32_t thr, uint32_t top) {
     const uint32_t q = above * (uint32_t)(kOrderClasses - 1) / span;  // 0 .. 8 (and beyond when this launch's rays outlived the scale)
     return q >= (uint32_t)(kOrderClasses - 1) ? 0 : (int)(kOrderClasses - 2) - (int)q;
 }
-// the scale the slot's recorded costs are classed with: the (threshold, top) the recording launch worked with (k_order_select)
-__device__ inline void order_scale(const uint32_t* hist, uint32_t& thr, uint32_t& top) {
-    thr = hist[kHistClassThr]; top = hist[kHistClassTop];
-}
+__device__ inline uint32_t* order_counts(uint32_t* hist, int slot) { return hist + kHistCounts + (size_t)slot * kOrderMaxBlocks * kOrderCountWords; }
+
 __global__ __launch_bounds__(kOrderThreads) void k_order_count(const uint32_t* cost_base, uint32_t* hist, uint32_t n_chunks) {
-    if (hist[kHistRebuild] == 0u) return;  // nothing recorded since the slot's order was built (or a fresh slot): the order stays as it is
     __shared__ uint32_t cnt[kOrderCountWords];
-    if (threadIdx.x < kOrderCountWords) cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t* cost = cost_base + (size_t)hist[kHistSel] * kHistSlotStride;
-    uint32_t thr, top;
-    order_scale(hist, thr, top);
-    const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
-    uint32_t mx = 0u;
-    for (int j = 0; j < kOrderPerThread; ++j)
-        if (first + j < n_chunks) { const uint32_t c = cost[first + j]; atomicAdd(&cnt[order_class(c, thr, top)], 1u); mx = c > mx ? c : mx; }
-    if (mx) atomicMax(&cnt[kOrderClasses], mx);
-    __syncthreads();
-    if (threadIdx.x < kOrderCountWords) hist[kHistCounts + blockIdx.x * kOrderCountWords + threadIdx.x] = cnt[threadIdx.x];  // [classes ..., block maximum]
-}
-__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_base, uint32_t* order_base, uint32_t* hist, uint32_t n_chunks) {
-    uint32_t* cost = cost_base + (size_t)hist[kHistSel] * kHistSlotStride;
-    uint32_t* order = order_base + (size_t)hist[kHistSel] * kHistSlotStride;
-    const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
-    if (hist[kHistRebuild] == 0u) {
-        if (hist[kHistFresh])  // the slot's array still holds the costs of the batch that was evicted
-            for (int j = 0; j < kOrderPerThread; ++j) if (first + j < n_chunks) cost[first + j] = 0u;
-        return;
+    for (int slot = 0; slot < kHistSlots; ++slot) {
+        if (hist[kHistPending + slot] == 0u) continue;  // (wave-uniform: a header word)
+        if (threadIdx.x < kOrderCountWords) cnt[threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t* cost = cost_base + (size_t)slot * kHistSlotStride;
+        const uint32_t thr = hist[kHistScale + 4 * slot], top = hist[kHistScale + 4 * slot + 1];  // the scale the recording launch worked with
+        const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
+        uint32_t mx = 0u;
+        for (int j = 0; j < kOrderPerThread; ++j)
+            if (first + j < n_chunks) { const uint32_t c = cost[first + j]; atomicAdd(&cnt[order_class(c, thr, top)], 1u); mx = c > mx ? c : mx; }
+        if (mx) atomicMax(&cnt[kOrderClasses], mx);
+        __syncthreads();
+        if (threadIdx.x < kOrderCountWords) order_counts(hist, slot)[blockIdx.x * kOrderCountWords + threadIdx.x] = cnt[threadIdx.x];  // [classes ..., block maximum]
+        __syncthreads();
     }
+}
+__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_base, uint32_t* order_base, uint32_t* hist, uint32_t n_chunks, uint32_t* host_words) {
     typedef hipcub::BlockScan<unsigned long long, kOrderThreads> Scan;
     __shared__ typename Scan::TempStorage scan_tmp;
     __shared__ uint32_t total[kOrderCountWords], before[kOrderClasses];  // chunks of class k in all blocks (last: the largest cost) / in the blocks before this one
-    if (threadIdx.x < kOrderCountWords) { total[threadIdx.x] = 0u; if (threadIdx.x < kOrderClasses) before[threadIdx.x] = 0u; }
-    __syncthreads();
-    const uint32_t* counts = hist + kHistCounts;
-    for (uint32_t b = threadIdx.x; b < gridDim.x; b += kOrderThreads) {
-        for (int k = 0; k < kOrderClasses; ++k) {
-            const uint32_t c = counts[b * kOrderCountWords + k];
-            if (c) { atomicAdd(&total[k], c); if (b < blockIdx.x) atomicAdd(&before[k], c); }
+    const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
+    for (int slot = 0; slot < kHistSlots; ++slot) {
+        if (hist[kHistPending + slot] == 0u) continue;
+        uint32_t* cost = cost_base + (size_t)slot * kHistSlotStride;
+        uint32_t* order = order_base + (size_t)slot * kHistSlotStride;
+        if (threadIdx.x < kOrderCountWords) { total[threadIdx.x] = 0u; if (threadIdx.x < kOrderClasses) before[threadIdx.x] = 0u; }
+        __syncthreads();
+        const uint32_t* counts = order_counts(hist, slot);
+        for (uint32_t b = threadIdx.x; b < gridDim.x; b += kOrderThreads) {
+            for (int k = 0; k < kOrderClasses; ++k) {
+                const uint32_t c = counts[b * kOrderCountWords + k];
+                if (c) { atomicAdd(&total[k], c); if (b < blockIdx.x) atomicAdd(&before[k], c); }
+            }
+            atomicMax(&total[kOrderClasses], counts[b * kOrderCountWords + kOrderClasses]);
         }
-        atomicMax(&total[kOrderClasses], counts[b * kOrderCountWords + kOrderClasses]);
+        __syncthreads();
+        const uint32_t thr = hist[kHistScale + 4 * slot], top = hist[kHistScale + 4 * slot + 1];
+        int cls[kOrderPerThread];
+        unsigned long long packed[2] = {0ull, 0ull};  // this thread's chunks per class, 12 bits each, five classes per word
+        for (int j = 0; j < kOrderPerThread; ++j) {
+            cls[j] = first + j < n_chunks ? order_class(cost[first + j], thr, top) : -1;
+            if (cls[j] >= 0) packed[cls[j] / 5] += 1ull << (12 * (cls[j] % 5));
+        }
+        unsigned long long prefix[2];
+        Scan(scan_tmp).ExclusiveSum(packed[0], prefix[0]);
+        __syncthreads();
+        Scan(scan_tmp).ExclusiveSum(packed[1], prefix[1]);
+        uint32_t pos[kOrderClasses], acc = 0;
+        for (int k = 0; k < kOrderClasses; ++k) { pos[k] = acc + before[k] + (uint32_t)((prefix[k / 5] >> (12 * (k % 5))) & 0xFFFull); acc += total[k]; }
+        for (int j = 0; j < kOrderPerThread; ++j)
+            if (cls[j] >= 0) { order[pos[cls[j]]++] = first + j; cost[first + j] = 0u; }
+        __syncthreads();
     }
+    // the header: every block has read what it needs of it above; the LAST block to get here turns the recordings into orders in use
+    __shared__ uint32_t last_block;
+    __threadfence();
+    if (threadIdx.x == 0) last_block = atomicAdd(hist + kHistTicket, 1u) + 1u == gridDim.x ? 1u : 0u;
     __syncthreads();
-    uint32_t thr, top;
-    order_scale(hist, thr, top);
-    int cls[kOrderPerThread];
-    unsigned long long packed[2] = {0ull, 0ull};  // this thread's chunks per class, 12 bits each, five classes per word
-    for (int j = 0; j < kOrderPerThread; ++j) {
-        cls[j] = first + j < n_chunks ? order_class(cost[first + j], thr, top) : -1;
-        if (cls[j] >= 0) packed[cls[j] / 5] += 1ull << (12 * (cls[j] % 5));
-    }
-    unsigned long long prefix[2];
-    Scan(scan_tmp).ExclusiveSum(packed[0], prefix[0]);
-    __syncthreads();
-    Scan(scan_tmp).ExclusiveSum(packed[1], prefix[1]);
-    uint32_t pos[kOrderClasses], acc = 0;
-    for (int k = 0; k < kOrderClasses; ++k) { pos[k] = acc + before[k] + (uint32_t)((prefix[k / 5] >> (12 * (k % 5))) & 0xFFFull); acc += total[k]; }
-    for (int j = 0; j < kOrderPerThread; ++j)
-        if (cls[j] >= 0) { order[pos[cls[j]]++] = first + j; cost[first + j] = 0u; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the scale of the slot's NEXT recording launch (words nobody reads during this kernel)
-        uint32_t* scale = hist + kHistScale + 4u * hist[kHistSel];
-        uint32_t reported = n_chunks - total[kOrderClasses - 1];
+    if (!last_block || threadIdx.x != 0) return;
+    hist[kHistTicket] = 0u;
+    for (int slot = 0; slot < kHistSlots; ++slot) {
+        if (hist[kHistPending + slot] == 0u) continue;
+        const uint32_t* counts = order_counts(hist, slot);
+        uint32_t unreported = 0u, mx = 0u;
+        for (uint32_t b = 0; b < gridDim.x; ++b) { unreported += counts[b * kOrderCountWords + kOrderClasses - 1]; const uint32_t m = counts[b * kOrderCountWords + kOrderClasses]; mx = m > mx ? m : mx; }
+        uint32_t* scale = hist + kHistScale + 4 * slot;  // the scale of the slot's NEXT recording launch
+        const uint32_t thr = scale[0], reported = n_chunks - unreported;
         uint32_t next = thr;
         if (reported * 5u > n_chunks * 2u) next += (next >> 2) + 1u;        // more than 40 % of the chunks reported: raise the bar
         else if (reported * 10u < n_chunks && next > 2u) next -= next >> 2;  // fewer than 10 %: lower it
         scale[2] = next;
-        scale[3] = total[kOrderClasses] > next ? total[kOrderClasses] : next + 8u;  // the longest lifetime just seen scales the next recording's classes
+        scale[3] = mx > next ? mx : next + 8u;  // the longest lifetime just seen scales the next recording's classes
+        hist[kHistPending + slot] = 0u;
+        hist[kHistHasOrder + slot] = 1u;
     }
+    if (host_words) __hip_atomic_store(host_words + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // nothing waits for a rebuild any more
 }
 }  // namespace
 
@@ -886,7 +836,8 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
         }
         h->n_items = n; h->any = any_hit; h->stream = stream; h->n_chunks = n_base; h->pool = c.pool;
         h->skip_left = 0;
-        if (h->fresh_streak.p) *reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p) = 0u;
+        h->rebuild_credit = 0; h->next_record = 8; h->records_asked = 0;
+        if (h->fresh_streak.p) { reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p)[0] = 0u; reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p)[1] = 0u; }
         RC_HIP(hipMemsetAsync(h->ctl.p, 0, sizeof(uint32_t) * kHistCounts, stream));  // every batch slot empty (the cost arrays are cleared when a slot is given out)
         h->gen = 0;
     }
@@ -907,19 +858,36 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
         return false;
     }
     h->gen += 1;
-    HostSample hs{};
-    if (host_sample) for (int k = 0; k < 8; ++k) hs.f[k] = host_sample[k];
+    // Turning recordings into orders: the pair of rebuild kernels goes in front of this launch only when a slot MAY hold a recording --
+    // the shape's first launches (a batch records its launches 2-4), the launches after the device reported a launch that was not a
+    // repeat (a new batch starts its own launches 2-4), and the launch after one this host asked to record.  Everything else about the
+    // launch's claim order is decided inside the launch itself (order_select).
+    volatile uint32_t* pinned = reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p);  // [0] the run of non-repeats, [1] a recording waits (both as of the latest launch that has FINISHED)
+    if (pinned[0] > 0u) h->rebuild_credit = 6;
+    const uint32_t blocks = (n_base + kOrderTile - 1) / kOrderTile;
+    if (h->gen >= 2 && (h->gen <= 6 || h->rebuild_credit > 0 || pinned[1] != 0u)) {
+        hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->ctl.p, n_base);
+        hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->order.p, h->ctl.p, n_base, h->fresh_streak.p);
+    }
+    if (h->rebuild_credit > 0) h->rebuild_credit -= 1;
+    // the recording cadence of a batch past its fourth launch: one launch in 7, 8, 9, 7, ... of the shape (not a fixed period: two or three
+    // batches alternating on the shape must all get their turn)
+    c.want_record = 0;
+    if (h->gen >= h->next_record) {
+        c.want_record = 1;
+        h->next_record = h->gen + 7 + (h->records_asked % 3);
+        h->records_asked += 1;
+        if (h->rebuild_credit < 1) h->rebuild_credit = 1;  // (the next launch gets the rebuild pair)
+    }
     const float ex = s->root_max[0] - s->root_min[0], ey = s->root_max[1] - s->root_min[1], ez = s->root_max[2] - s->root_min[2];
     const float l2 = ex * ex + ey * ey + ez * ez;
-    const float inv_l2 = (l2 > 0.f && l2 < 1e30f) ? 1.0f / l2 : 0.f;
-    const uint32_t blocks = (n_base + kOrderTile - 1) / kOrderTile;
-    hipLaunchKernelGGL(k_order_select, dim3(1), dim3(64), 0, stream, d_rays, n, hs, inv_l2, h->ctl.p, h->samples.p, (uint32_t)s->opt.cost_thr, h->fresh_streak.p);
-    if (h->gen > 1) {  // (both return at once unless the batch's slot has a recording to build an order from; scatter also clears the slot a fresh batch was given)
-        hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->ctl.p, n_base);
-        hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->order.p, h->ctl.p, n_base);
-    } else {
-        RC_HIP(hipMemsetAsync(h->cost.p, 0, sizeof(uint32_t) * n_base, stream));  // the very first launch of a shape: slot 0 (the only one an empty table hands out)
-    }
+    c.inv_l2 = (l2 > 0.f && l2 < 1e30f) ? 1.0f / l2 : 0.f;
+    c.sample_rays = d_rays;
+    c.n_sample = n;
+    for (int k = 0; k < 8; ++k) c.sample_host[k] = host_sample ? host_sample[k] : 0.f;
+    c.samples = h->samples.p;
+    c.host_streak = h->fresh_streak.p;
+    c.init_thr = (uint32_t)s->opt.cost_thr;
     c.order = h->order.p;
     c.cost = h->cost.p;
     c.hist = h->ctl.p;

@@ -63,21 +63,36 @@ struct RcClaim {
     uint32_t c1, c2, c3;           // position in the claim order of the first chunk dealt in halves / quarters / eighths
     const uint32_t* order;         // position in the claim order -> chunk, a permutation of 0 .. ceil(n_items / pool) - 1; nullptr = natural order
     uint32_t* cost;                // per chunk: the longest time in flight (interior iterations of its wave) of a ray of the chunk this launch; nullptr = not recorded
-    const uint32_t* hist;          // the history's header words (kHist*, below), written on the device by k_order_select just before this launch: which of the
-                                   // history's batch slots this launch belongs to -- `cost` / `order` are slot 0's arrays, slot k's lie k * kHistSlotStride words
-                                   // on --, whether the slot has an order, and the reporting threshold (or: do not record).  nullptr = no history
+    uint32_t* hist;                // the history's header words (kHist*, below).  Every wave of the launch works out by itself which of the history's batch slots
+                                   // the launch belongs to (order_select: a pure function of the header and the launch's sample rays) -- `cost` / `order` are slot
+                                   // 0's arrays, slot k's lie k * kHistSlotStride words on --; the LAST workgroup to finish writes the header's next state.  nullptr = no history
     uint32_t pool_shift;           // log2(pool) when pool is a power of two (the cost path maps a ray to its chunk with a shift)
+    // what order_select needs to recognise the batch
+    const RcRay* sample_rays;      // the launch's ray array, or nullptr: generated rays, described by sample_host
+    uint64_t n_sample;             // rays in it
+    float sample_host[8];
+    float inv_l2;                  // 1 / (scene diagonal)^2: origins are compared relative to the scene
+    float* samples;                // kHistSlots x kHistSamples remembered sample rays (8 floats each)
+    uint32_t* host_streak;         // pinned word: the run of launches that were not repeats, for the host's pause logic
+    uint32_t init_thr;             // reporting threshold a batch starts with
+    uint32_t want_record;          // the host's cadence: a slot past its fourth launch records in this launch
 };
 // A history (rc_scene::ChunkHistory) remembers up to kHistSlots different BATCHES of one launch shape, told apart on the device by
 // kHistSamples sample rays (VERDICT r3 #5a: two cameras alternating on one stream each learn from their OWN previous launch, and a
 // batch never seen before runs in natural order instead of in somebody else's).  Header words:
 constexpr int kHistSlots = 4, kHistSamples = 64;
 constexpr uint32_t kHistSlotStride = 1u << 18;  // words between the slots' cost arrays = the most chunks the order kernels handle
-constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 3, kHistFresh = 4, kHistRebuild = 5, kHistClassThr = 6, kHistClassTop = 7,  // of THIS launch
+constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 3, kHistFresh = 4, kHistRecorded = 5,  // of the latest launch (written at its end: tests, tools)
               kHistFreshStreak = 36 /* consecutive launches that were not a repeat (identical sample rays) of a remembered batch */,
+              kHistTicket = 37 /* workgroups of the running launch that have finished (the last one updates the header and puts this back to 0) */,
               kHistStamp = 8 /* [kHistSlots] */, kHistGen = 12 /* [kHistSlots] */,
               kHistScale = 16 /* [kHistSlots][4]: (threshold, top of the scale) the slot's latest recording launch worked with; the pair its next one will */,
-              kHistPending = 32 /* [kHistSlots]: the slot's cost array holds a recording that no order has been built from yet */, kHistCounts = 40;
+              kHistPending = 32 /* [kHistSlots]: the slot's cost array holds a recording that no order has been built from yet */,
+              kHistHasOrder = 40 /* [kHistSlots]: the slot's order array holds an order built from a recording of the slot's batch */, kHistCounts = 48;
+// Round 5: nothing runs in front of a launch to prepare its claim order.  order_select (below) is evaluated by every wave of the launch itself;
+// the header's next state is written by the last workgroup to finish (all others have started, hence read the old state, before it can);
+// the one thing left to separate dispatches is turning a finished RECORDING into an order (k_order_count / k_order_scatter, rc_traverse.hip),
+// which the host enqueues only in front of launches that may follow a recording -- one launch in eight of a repeating batch.
 // RECORDING costs: every reporting ray is an atomic whose acknowledgement the wave's next s_waitcnt vmcnt waits for along with its node
 // fetches -- 25-30 us of a 0.37 ms launch (profiles/r04_cost_order_recording.txt: the same learned order WITHOUT recording traces the
 // shadow batch at 5.95 instead of 5.55 Grays/s).  So a batch slot records its launches 2-4 (the reporting threshold needs two rounds to
@@ -115,6 +130,81 @@ __device__ inline bool rc_claim_chunk(const RcClaim& c, const uint32_t* order, u
     if (pool_end > n_items) pool_end = n_items;
     if (pool_next > pool_end) pool_next = pool_end;
     return true;
+}
+
+// Which batch is this launch, and what does it do with the batch's slot?  A pure function of the history's header, the remembered sample
+// rays and the launch's own: every wave evaluates it (64 lanes, one sample ray each) and gets the same answer.  The closest slot below the
+// threshold is the batch's; none: the least recently used slot is given to it ("fresh": natural order, nothing recorded).  A slot records in
+// its launches 2-4 (never the first: a batch that does not come back pays nothing; the reporting threshold needs two rounds to settle) and
+// then when the host's cadence says so (one launch in eight).
+struct OrderDecision {
+    uint32_t sel, fresh, exact, gen, record, valid, life_thr;
+};
+__device__ inline OrderDecision order_select(const RcClaim& c, int lane, float r[8]) {
+    if (c.sample_rays) {
+        uint64_t idx = (uint64_t)lane * c.n_sample / (uint64_t)kHistSamples + c.n_sample / (2u * kHistSamples);
+        if (idx >= c.n_sample) idx = c.n_sample - 1;
+        const float4* q = reinterpret_cast<const float4*>(c.sample_rays + idx);
+        const float4 a = q[0], b = q[1];
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    } else {
+        for (int k = 0; k < 8; ++k) r[k] = c.sample_host[k];
+    }
+    // (Loading all four slots' samples and header words up front -- one memory round trip instead of two or three -- was measured 0.7 %
+    // SLOWER on C3: the launch's first claims wait behind 8 more vector loads per lane of every wave.)
+    const uint32_t* hist = c.hist;
+    int best = -1;
+    float best_d = 0.02f;  // mean over the samples of |dd|^2 / |d|^2 + |do|^2 / diagonal^2: ~0.1 rad of rotation, or a tenth of the scene of travel
+    for (int k = 0; k < kHistSlots; ++k) {
+        if (hist[kHistStamp + k] == 0u) continue;
+        const float* sp = c.samples + ((size_t)k * kHistSamples + lane) * 8;
+        const float ox = r[0] - sp[0], oy = r[1] - sp[1], oz = r[2] - sp[2], dx = r[4] - sp[4], dy = r[5] - sp[5], dz = r[6] - sp[6];
+        const float na = r[4] * r[4] + r[5] * r[5] + r[6] * r[6], nb = sp[4] * sp[4] + sp[5] * sp[5] + sp[6] * sp[6];
+        float d = (dx * dx + dy * dy + dz * dz) / fmaxf(fmaxf(na, nb), 1e-30f) + (ox * ox + oy * oy + oz * oz) * c.inv_l2;
+        for (int m = 32; m > 0; m >>= 1) d += __shfl_xor(d, m);  // (a NaN anywhere: the sum is NaN and the comparison fails -- no match)
+        d *= 1.0f / kHistSamples;
+        if (d < best_d) { best_d = d; best = k; }
+    }
+    OrderDecision o;
+    o.fresh = best < 0 ? 1u : 0u;
+    o.exact = (best >= 0 && best_d == 0.0f) ? 1u : 0u;  // the same sample rays bit for bit: a REPEAT of the remembered batch
+    int sel = best;
+    if (best < 0) {  // an empty slot, else the least recently used one
+        uint32_t oldest = 0xFFFFFFFFu;
+        for (int k = 0; k < kHistSlots; ++k) { const uint32_t st = hist[kHistStamp + k]; if (st < oldest) { oldest = st; sel = k; } }
+    }
+    o.sel = (uint32_t)__builtin_amdgcn_readfirstlane(sel);
+    o.gen = o.fresh ? 1u : hist[kHistGen + o.sel] + 1u;
+    o.record = ((o.gen >= 2u && o.gen <= 4u) || (c.want_record && o.gen >= 5u)) ? 1u : 0u;
+    o.valid = (!o.fresh && hist[kHistHasOrder + o.sel] != 0u) ? 1u : 0u;
+    o.life_thr = o.record ? hist[kHistScale + 4u * o.sel + 2u] : 0xFFFFFFFFu;
+    return o;
+}
+// The header after the launch (one wave of the last workgroup to finish; `r` = this lane's sample ray of the launch).
+__device__ inline void order_commit(const RcClaim& c, const OrderDecision& o, int lane, const float r[8]) {
+    float* out = c.samples + ((size_t)o.sel * kHistSamples + lane) * 8;  // the slot's samples follow its batch
+    for (int k = 0; k < 8; ++k) out[k] = r[k];
+    if (lane != 0) return;
+    uint32_t* hist = c.hist;
+    const uint32_t clock = hist[kHistClock] + 1u;
+    hist[kHistClock] = clock;
+    hist[kHistStamp + o.sel] = clock;
+    hist[kHistGen + o.sel] = o.gen;
+    uint32_t* scale = hist + kHistScale + 4u * o.sel;  // [0], [1]: (threshold, top) of the slot's latest recording; [2], [3]: of its next one (k_order_scatter)
+    if (o.fresh) { scale[0] = scale[2] = c.init_thr; scale[1] = scale[3] = c.init_thr + 8u; hist[kHistPending + o.sel] = 0u; hist[kHistHasOrder + o.sel] = 0u; }
+    if (o.record) { scale[0] = scale[2]; scale[1] = scale[3]; hist[kHistPending + o.sel] = 1u; }  // the rebuild classes the costs with the scale they were recorded under
+    hist[kHistSel] = o.sel; hist[kHistFresh] = o.fresh; hist[kHistOrderValid] = o.valid; hist[kHistLifeThr] = o.life_thr; hist[kHistRecorded] = o.record;
+    // Tell the host when this shape's batches are not REPEATS of remembered ones -- a path tracer's bounce rays (never matched), but also a
+    // camera that moves every frame: matched, its slot's order reused, and still slower than natural order in round 4, because an order
+    // learned from SIMILAR rays gained less than the mechanism cost (BENCH_r04 c3_moving_camera).  The host then pauses the mechanism.
+    const uint32_t streak = o.exact ? 0u : hist[kHistFreshStreak] + 1u;
+    hist[kHistFreshStreak] = streak;
+    if (c.host_streak) {
+        __hip_atomic_store(c.host_streak, streak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t any_pending = 0u;  // ... and whether a recording waits for the rebuild kernels
+        for (int k = 0; k < kHistSlots; ++k) any_pending |= hist[kHistPending + k];
+        __hip_atomic_store(c.host_streak + 1, any_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 struct TraceArgs {
@@ -570,12 +660,17 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, t
     uint32_t* claim_cost = a.claim.cost;
     uint32_t life_thr = 0xFFFFFFFFu;
     if (a.claim.hist) {
-        const uint32_t sel = __builtin_amdgcn_readfirstlane(a.claim.hist[kHistSel]);
-        if (__builtin_amdgcn_readfirstlane(a.claim.hist[kHistOrderValid]) == 0u) claim_order = nullptr;
-        else claim_order += (size_t)sel * kHistSlotStride;
-        claim_cost += (size_t)sel * kHistSlotStride;
-        life_thr = __builtin_amdgcn_readfirstlane(a.claim.hist[kHistLifeThr]);  // 0xFFFFFFFF: this launch does not record
-        if (life_thr == 0xFFFFFFFFu) claim_cost = nullptr;
+        float smp[8];
+        const OrderDecision od = order_select(a.claim, lane, smp);
+        const uint32_t sel = od.sel;
+        claim_order = __builtin_amdgcn_readfirstlane(od.valid) ? claim_order + (size_t)sel * kHistSlotStride : nullptr;
+        life_thr = __builtin_amdgcn_readfirstlane(od.life_thr);  // 0xFFFFFFFF: this launch does not record
+        claim_cost = life_thr == 0xFFFFFFFFu ? nullptr : claim_cost + (size_t)sel * kHistSlotStride;
+        if (__builtin_amdgcn_readfirstlane(od.fresh)) {  // the slot's cost array still holds what the evicted batch recorded: nobody reads or records it during a batch's first launch
+            uint32_t* stale = a.claim.cost + (size_t)sel * kHistSlotStride;
+            const uint64_t n_base = (a.n_items + a.claim.pool - 1u) / a.claim.pool;
+            for (uint64_t i = gtid; i < n_base; i += av.total_threads) stale[i] = 0u;
+        }
     }
     typename LaneStackP<LDS_N, BLOCK, stack_entry_t>::pos_t sp = st.empty();
     bool live = false;
@@ -866,6 +961,22 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, t
             atomicAdd(&a.stats[14], st_outer);  // outer iterations (one pass over the phases each)
             for (int k = 0; k < 4; ++k) atomicAdd(&a.stats[15 + k], st_sub[k]);
             atomicAdd(&a.stats[19], st_cull);  // instance entries skipped by the entry cull (counted once per wave-pass: lane 0's copy of the wave total)
+        }
+    }
+    // The history's next state: written once, by the last workgroup of the launch to get here (every other workgroup has read the old one).
+    // (Writing it at the START of the launch instead -- by the last workgroup to have made its decision, which still holds it in registers --
+    // was measured slower: 512 ticket atomics on one address while every wave claims its first chunk, +10 us on a 1 M-ray launch.)
+    if (a.claim.hist) {
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            uint32_t ticket = 0;
+            if (lane == 0) ticket = atomicAdd(a.claim.hist + kHistTicket, 1u);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane(ticket) + 1u == gridDim.x) {
+                float smp[8];
+                const OrderDecision od = order_select(a.claim, lane, smp);
+                order_commit(a.claim, od, lane, smp);
+                if (lane == 0) a.claim.hist[kHistTicket] = 0u;
+            }
         }
     }
 }

@@ -1,36 +1,40 @@
 """Python restatement of the batch-slot state machine of cost-ordered claiming (test infrastructure).
 
-The product side is split between the host (rc_cost_order_setup, raycore.jl_amd/csrc/rc_traverse.hip: which launches go through the order
-kernels at all) and the device (k_order_select: which of the history's four batch slots a launch belongs to, and what the launch does with
-it).  A wrong transition cannot change a hit -- the claim order is result-neutral -- but it can silently turn the feature into overhead, so
-the transitions are restated here, driven with scripted launch sequences, and compared word for word with the header words the device
-leaves behind (tests/test_gpu_order_model.py); tests/test_order_model.py checks the restatement's own promises on the CPU.
+The product side is split between the host (rc_cost_order_setup, raycore.jl_amd/csrc/rc_traverse.hip: which launches take part at all, when a
+batch is asked to record, when the rebuild kernels run) and the device (order_select / order_commit, rc_traverse_core.h: which of the
+history's four batch slots a launch belongs to and what the launch does with it -- evaluated INSIDE the launch since round 5; k_order_scatter:
+a recording becomes an order).  A wrong transition cannot change a hit -- the claim order is result-neutral -- but it can silently turn the
+feature into overhead, so the transitions are restated here, driven with scripted launch sequences, and compared word for word with the
+header words the device leaves behind (tests/test_gpu_order_model.py); tests/test_order_model.py checks the restatement's own promises on
+the CPU.
 
-A launch is described by what k_order_select can see of it: `batch` (any hashable: launches with equal ids trace identical rays) and
-`near` (a set of batch ids whose sample rays are within the matching threshold of this launch's without being identical: the frame before
-of a moving camera).  Data-dependent words (the reporting threshold and the scale of the cost classes, kHistScale / kHistLifeThr's value)
-are outside the model: it says WHETHER a launch records, not with which threshold.
+A launch is described by what order_select can see of it: `batch` (any hashable: launches with equal ids trace identical rays) and `near`
+(a set of batch ids whose sample rays are within the matching threshold of this launch's without being identical: the frame before of a
+moving camera).  Data-dependent words (the reporting threshold and the scale of the cost classes) are outside the model: it says WHETHER a
+launch records, not with which threshold.  The model assumes the caller waits for every launch (the pinned words the host reads are then
+current); a caller that enqueues far ahead sees them late, which delays a rebuild or the pause and changes no result.
 """
 
 K_SLOTS = 4                    # kHistSlots
-RECORD_EVERY = 8               # kHistRecordEvery
 GIVE_UP_AFTER, GIVE_UP_FOR = 8, 64   # rc_cost_order_setup
+EARLY_LAUNCHES, CREDIT_AFTER_NON_REPEAT = 6, 6
 
 # header words of the history (rc_traverse_core.h kHist*)
-SEL, ORDER_VALID, LIFE_THR, CLOCK, FRESH, REBUILD = 0, 1, 2, 3, 4, 5
-STAMP, GEN, PENDING, STREAK = 8, 12, 32, 36
+SEL, ORDER_VALID, LIFE_THR, CLOCK, FRESH, RECORDED = 0, 1, 2, 3, 4, 5
+STAMP, GEN, PENDING, STREAK, HAS_ORDER = 8, 12, 32, 36, 40
 
 
 class Mutations:
     """knobs for the mutants the comparison has to catch"""
-    order_valid_from = 3       # the slot's third launch builds its first order
-    record_first, record_last = 2, 4
-    repeats_only = True        # the streak counts launches that are not exact repeats (False: round 4's rule, unmatched launches only)
+    record_first, record_last = 2, 4   # a slot records its launches 2-4 ...
+    first_cadence_record = 8           # ... and then when the host's cadence asks (launches 8, 15, 23, 32, 39, ... of the shape)
+    repeats_only = True                # the streak counts launches that are not exact repeats (False: round 4's rule, unmatched launches only)
+    rebuild_on_pending_word = True     # the host runs the rebuild kernels when the device reported a waiting recording
 
 
 class History:
-    """One launch shape's history: device header + the host's pause logic.  launch() returns the header words the device holds after the
-    launch (a dict of the modelled words), or None when the host left the order kernels out."""
+    """One launch shape's history: device header + the host's logic.  launch() returns the header words the device holds after the launch (a
+    dict of the modelled words), or None when the host left the mechanism out."""
 
     def __init__(self, mut=None):
         self.m = mut or Mutations()
@@ -38,12 +42,17 @@ class History:
         self.stamp = [0] * K_SLOTS
         self.gen = [0] * K_SLOTS
         self.pending = [0] * K_SLOTS
+        self.has_order = [0] * K_SLOTS
         self.batch = [None] * K_SLOTS      # whose sample rays the slot holds
         self.streak = 0                    # device copy (kHistFreshStreak)
-        self.host_streak = 0               # the pinned word as the host last saw it
+        self.host_streak = 0               # pinned word 0 as the host last saw it
+        self.host_pending = 0              # pinned word 1
         self.skip_left = 0
-        self.host_gen = 0                  # launches of the shape that went through the order kernels
-        self.last = None
+        self.host_gen = 0                  # launches of the shape that took part
+        self.credit = 0
+        self.next_record = self.m.first_cadence_record
+        self.records_asked = 0
+        self.rebuilds = 0                  # how often the rebuild pair was enqueued (not a device word)
 
     def launch(self, batch, near=()):
         # ---- host: rc_cost_order_setup ----
@@ -56,7 +65,23 @@ class History:
             self.skip_left = GIVE_UP_FOR - 1
             return None
         self.host_gen += 1
-        # ---- device: k_order_select ----
+        if self.host_streak > 0:
+            self.credit = CREDIT_AFTER_NON_REPEAT
+        if self.host_gen >= 2 and (self.host_gen <= EARLY_LAUNCHES or self.credit > 0 or (self.m.rebuild_on_pending_word and self.host_pending)):
+            self.rebuilds += 1             # k_order_count + k_order_scatter: every waiting recording becomes an order
+            for k in range(K_SLOTS):
+                if self.pending[k]:
+                    self.pending[k], self.has_order[k] = 0, 1
+            self.host_pending = 0
+        if self.credit > 0:
+            self.credit -= 1
+        want_record = 0
+        if self.host_gen >= self.next_record:
+            want_record = 1
+            self.next_record = self.host_gen + 7 + self.records_asked % 3
+            self.records_asked += 1
+            self.credit = max(self.credit, 1)
+        # ---- device: order_select, evaluated by the launch itself ----
         best, exact = None, False
         for k in range(K_SLOTS):           # the closest slot below the threshold; an identical batch has distance 0 and wins
             if self.stamp[k] == 0:
@@ -67,34 +92,33 @@ class History:
             if best is None and self.batch[k] in near:
                 best = k
         fresh = best is None
-        if fresh:                          # an empty slot, else the least recently used (lowest stamp; first of equals)
-            sel = min(range(K_SLOTS), key=lambda k: (self.stamp[k], k))
-        else:
-            sel = best
+        sel = min(range(K_SLOTS), key=lambda k: (self.stamp[k], k)) if fresh else best   # an empty slot, else the least recently used
+        gen = 1 if fresh else self.gen[sel] + 1
+        record = (self.m.record_first <= gen <= self.m.record_last) or (want_record and gen >= 5)
+        valid = (not fresh) and self.has_order[sel] != 0
+        # ---- device: order_commit, by the last workgroup of the launch ----
         self.batch[sel] = batch            # the slot's samples follow the batch
         self.clock += 1
         self.stamp[sel] = self.clock
-        gen = 1 if fresh else self.gen[sel] + 1
         self.gen[sel] = gen
         if fresh:
             self.pending[sel] = 0
-        rebuild = self.pending[sel] != 0
-        record = (self.m.record_first <= gen <= self.m.record_last) or gen % RECORD_EVERY == 0
-        valid = gen >= self.m.order_valid_from
-        self.pending[sel] = 1 if record else 0
+            self.has_order[sel] = 0
+        if record:
+            self.pending[sel] = 1
         not_counted = exact if self.m.repeats_only else not fresh
         self.streak = 0 if not_counted else self.streak + 1
-        self.host_streak = self.streak     # (the test waits for every launch: the pinned word is current at the next one)
-        self.last = {"sel": sel, "order_valid": int(valid), "records": int(record), "clock": self.clock, "fresh": int(fresh), "rebuild": int(rebuild),
-                     "stamp": list(self.stamp), "gen": list(self.gen), "pending": list(self.pending), "streak": self.streak}
-        return dict(self.last)
+        self.host_streak = self.streak     # (the test waits for every launch: the pinned words are current at the next one)
+        self.host_pending = int(any(self.pending))
+        return {"sel": sel, "order_valid": int(valid), "records": int(record), "clock": self.clock, "fresh": int(fresh),
+                "stamp": list(self.stamp), "gen": list(self.gen), "pending": list(self.pending), "has_order": list(self.has_order), "streak": self.streak}
 
 
 def device_words(w):
-    """the modelled words out of a dump of the first 40 header words (numpy uint32)"""
-    return {"sel": int(w[SEL]), "order_valid": int(w[ORDER_VALID]), "records": int(w[LIFE_THR] != 0xFFFFFFFF), "clock": int(w[CLOCK]), "fresh": int(w[FRESH]),
-            "rebuild": int(w[REBUILD]), "stamp": [int(x) for x in w[STAMP:STAMP + K_SLOTS]], "gen": [int(x) for x in w[GEN:GEN + K_SLOTS]],
-            "pending": [int(x) for x in w[PENDING:PENDING + K_SLOTS]], "streak": int(w[STREAK])}
+    """the modelled words out of a dump of the first 48 header words (numpy uint32)"""
+    return {"sel": int(w[SEL]), "order_valid": int(w[ORDER_VALID]), "records": int(w[RECORDED]), "clock": int(w[CLOCK]), "fresh": int(w[FRESH]),
+            "stamp": [int(x) for x in w[STAMP:STAMP + K_SLOTS]], "gen": [int(x) for x in w[GEN:GEN + K_SLOTS]],
+            "pending": [int(x) for x in w[PENDING:PENDING + K_SLOTS]], "has_order": [int(x) for x in w[HAS_ORDER:HAS_ORDER + K_SLOTS]], "streak": int(w[STREAK])}
 
 
 def scripts():
@@ -106,10 +130,11 @@ def scripts():
     def moving(first, n):
         return [(("m", f), ((("m", f - 1),) if f > 1 else (0,))) for f in range(first, first + n)]
     return {
-        "A x 12": still(0, 12),
-        "A B A B": [(k % 2, ()) for k in range(16)],
+        "A x 20": still(0, 20),
+        "A B A B": [(k % 2, ()) for k in range(24)],
         "A B C D E rotation (five batches, four slots)": [(k % 5, ()) for k in range(15)],
         "still, then a moving camera, then still again": still(0, 4) + moving(1, 12) + [(0, (("m", 12),))] + still(0, 3),   # (position 0 is still within the threshold of where the camera stopped)
         "never repeating, the pause, then a repeating batch": [(100 + k, ()) for k in range(10)] + [(200 + k, ()) for k in range(62)] + still(3, 6),
         "A A B B B A A A A": still(0, 2) + still(1, 3) + still(0, 4),
+        "A B C rotation (three batches, each with a slot)": [(k % 3, ()) for k in range(21)],   # their launches 4 record late: only the device's "a recording waits" word brings the rebuild
     }

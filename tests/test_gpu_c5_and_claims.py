@@ -614,14 +614,19 @@ def test_changing_batch_sizes_never_block_and_change_no_result(rc, oracle):
     t.trace_device(dr.data_ptr(), outs[0].data_ptr(), sizes[0], stream=s.cuda_stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    stamps = []
     for n, out in zip(sizes, outs):
         t.trace_device(dr.data_ptr(), out.data_ptr(), n, stream=s.cuda_stream)
-    enqueue_s = time.perf_counter() - t0
+        stamps.append(time.perf_counter())
+    enqueue_s = stamps[-1] - t0
     torch.cuda.synchronize()
     total_s = time.perf_counter() - t0
     for n, out in zip(sizes, outs):
         assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), want[:n], f"n = {n}")
-    assert enqueue_s < 0.5 * total_s or enqueue_s < 2e-3, f"enqueueing 24 launches took {enqueue_s * 1e3:.2f} ms of {total_s * 1e3:.2f} ms: the enqueue waited for the device"
+    # the first eight shapes allocate their history buffers (hipMalloc, no synchronisation); from the ninth on a launch only enqueues: a
+    # stream synchronise or an eviction that waited would cost at least the ~3 ms of device work queued in front of it
+    late_s = stamps[-1] - stamps[7]
+    assert late_s < 1.5e-3, f"enqueueing launches 9-24 took {late_s * 1e3:.2f} ms (all 24: {enqueue_s * 1e3:.2f} of {total_s * 1e3:.2f} ms): the enqueue waited for the device"
     # two shapes that keep coming back after the table is full of one-offs: they are recognised and learn (third launch runs ordered)
     a, b = sizes[20], sizes[22]
     for rep in range(4):

@@ -1,4 +1,5 @@
-"""GPU: the batch-slot state machine of cost-ordered claiming (k_order_select + the host's pause logic, raycore.jl_amd/csrc/rc_traverse.hip) against
+"""GPU: the batch-slot state machine of cost-ordered claiming (order_select / order_commit inside the trace kernels, k_order_scatter, and the host's
+pause / cadence / rebuild logic in rc_cost_order_setup, raycore.jl_amd/csrc/rc_traverse.hip) against
 its Python restatement (tests/order_model.py), word for word after every launch of scripted sequences.  Every launch's hits are
 the oracle's as well -- the claim order never changes a result -- but that alone would not notice a state machine that never learns."""
 import ctypes
@@ -49,8 +50,8 @@ class Rig:
         return self.cache[batch]
 
     def header(self, t):
-        h = self.torch.empty(40, dtype=self.torch.int32, device="cuda")
-        self.hip.hipMemcpy(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(t.get_option("debug_ctl_ptr")), ctypes.c_size_t(160), 3)
+        h = self.torch.empty(48, dtype=self.torch.int32, device="cuda")
+        self.hip.hipMemcpy(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(t.get_option("debug_ctl_ptr")), ctypes.c_size_t(192), 3)
         self.torch.cuda.synchronize()
         return om.device_words(h.cpu().numpy().view(np.uint32))
 

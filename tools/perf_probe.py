@@ -22,6 +22,19 @@ def time_trace(t, rays, mode, reps=int(os.environ.get("RC_PROBE_REPS", "5"))):
     d_rays = to_dev(rays)
     d_hits = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
     best = 1e9
+    loop = int(os.environ.get("RC_PROBE_LOOP", "0"))
+    if loop:  # like bench.py's steps: `loop` launches back to back between two events (what a launch costs INCLUDING whatever the library enqueues around the kernel)
+        for _ in range(12):
+            t.trace_device(d_rays.data_ptr(), d_hits.data_ptr(), n, mode=mode)
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(loop):
+                t.trace_device(d_rays.data_ptr(), d_hits.data_ptr(), n, mode=mode, stream=torch.cuda.current_stream().cuda_stream)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / loop)
+        reps = 0
     for _ in range(reps):
         t.trace_device(d_rays.data_ptr(), d_hits.data_ptr(), n, mode=mode)
         best = min(best, t.last_kernel_ms())
