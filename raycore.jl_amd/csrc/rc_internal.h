@@ -276,7 +276,7 @@ struct rc_scene {
         uint64_t gen = 0;                   // launches of this shape so far
         uint64_t last_use = 0;
         RcEvent last;                       // behind the latest launch that used the entry's buffers
-        PinnedU32 fresh_streak;             // written by k_order_select: consecutive launches of this shape whose batch matched no slot
+        PinnedU32 fresh_streak;             // written by the launches (order_commit): [0] consecutive launches of this shape that were not repeats of a remembered batch, [1] a recording waits for the rebuild kernels
         uint32_t skip_left = 0;             // launches still to run without the mechanism (the shape's batches do not repeat)
         uint32_t rebuild_credit = 0;        // launches that still get the rebuild kernel pair in front (a slot may hold a recording: rc_cost_order_setup)
         uint64_t next_record = 8;           // the launch of the shape that next asks its batch to record (cadence 7, 8, 9, ...)

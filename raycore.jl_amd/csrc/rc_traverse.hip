@@ -695,7 +695,7 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
 // hist[kHistScale + 4 slot]: [0], [1] = the threshold / the top of the scale the slot's latest recording launch worked with; [2], [3] = the pair its next one will.
 namespace {
 constexpr int kOrderThreads = 256, kOrderPerThread = 4, kOrderTile = kOrderThreads * kOrderPerThread, kOrderClasses = 10, kOrderMaxBlocks = 256;
-static_assert((uint32_t)(kOrderTile * kOrderMaxBlocks) == kHistSlotStride, "a slot's cost array holds the most chunks the order kernels handle");
+static_assert((uint32_t)(kOrderTile * kOrderMaxBlocks) == kHistSlotStride, "a slot's cost array holds the most chunks the rebuild kernels handle");
 constexpr int kOrderCountWords = kOrderClasses + 1;  // per block: the classes' chunk counts, the largest cost
 constexpr size_t kHistWords = kHistCounts + (size_t)kHistSlots * kOrderMaxBlocks * kOrderCountWords;
 
@@ -806,7 +806,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
         // bounce -- misses every time): a free entry is taken at once; a full table gives up an entry only to a shape that has been seen
         // BEFORE (a one-off size learns nothing worth keeping), and only an entry whose buffers nobody can still be using -- its stream
         // is this launch's stream (stream order protects them) or whose last launch has completed (the entry's own event, queried, never waited for).  Otherwise the
-        // launch simply runs in natural order.  Buffers have ONE size (the largest batch the order kernels handle), so re-keying an
+        // launch simply runs in natural order.  Buffers have ONE size (the largest batch the rebuild kernels handle), so re-keying an
         // entry frees and allocates nothing.
         bool seen_before = false;
         for (const auto& r : s->recent_shapes) if (r.n_chunks == n_base && r.any == any_hit && r.stream == stream && r.pool == c.pool) { seen_before = true; break; }
@@ -843,9 +843,10 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
     }
     h->last_use = ++s->history_clock;
     s->cur_history = (int)(h - s->histories.data());
-    // A shape whose batches never repeat learns nothing and should pay nothing: k_order_select reports the run of launches that were not a
-    // repeat of a remembered batch (sample rays identical) into a pinned word; once it reads kGiveUpAfter (whenever the kernels that wrote it have run -- nothing here waits) the next
-    // kGiveUpFor launches of the shape go out in natural order without the order kernels, then the shape is tried again.
+    // A shape whose batches never repeat learns nothing and should pay nothing: the launch itself (order_commit) reports the run of launches
+    // that were not a repeat of a remembered batch (sample rays identical) into a pinned word; once it reads kGiveUpAfter (whenever the
+    // launches that wrote it have run -- nothing here waits) the next kGiveUpFor launches of the shape go out in natural order, outside the
+    // mechanism altogether, then the shape is tried again.
     constexpr uint32_t kGiveUpAfter = 8, kGiveUpFor = 64;
     h->fresh_streak.ensure();
     if (h->skip_left > 0) { h->skip_left -= 1; return false; }

@@ -81,7 +81,7 @@ struct RcClaim {
 // kHistSamples sample rays (VERDICT r3 #5a: two cameras alternating on one stream each learn from their OWN previous launch, and a
 // batch never seen before runs in natural order instead of in somebody else's).  Header words:
 constexpr int kHistSlots = 4, kHistSamples = 64;
-constexpr uint32_t kHistSlotStride = 1u << 18;  // words between the slots' cost arrays = the most chunks the order kernels handle
+constexpr uint32_t kHistSlotStride = 1u << 18;  // words between the slots' cost arrays = the most chunks the rebuild kernels handle
 constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 3, kHistFresh = 4, kHistRecorded = 5,  // of the latest launch (written at its end: tests, tools)
               kHistFreshStreak = 36 /* consecutive launches that were not a repeat (identical sample rays) of a remembered batch */,
               kHistTicket = 37 /* workgroups of the running launch that have finished (the last one updates the header and puts this back to 0) */,
@@ -655,7 +655,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, t
     // the ray occupied its lane, in the unit the launch's tail is made of.  The wave's iteration count lives in a scalar register and every
     // lane remembers the count at which its ray started: no per-iteration vector work.
     uint32_t it_total = 0, start_it = 0;
-    // which batch slot of the history this launch was assigned (k_order_select): its cost array, whether `order` is valid, its threshold
+    // which batch slot of the history this launch belongs to (order_select): its cost array, whether `order` is valid, its threshold
     const uint32_t* claim_order = a.claim.order;
     uint32_t* claim_cost = a.claim.cost;
     uint32_t life_thr = 0xFFFFFFFFu;
