@@ -279,6 +279,7 @@ int rc_scene_create(int device, rc_scene** out) {
         RC_HIP(hipStreamSynchronize(s->stream));
         s->slots.assign(kCounterSlots + 1, rc_scene::LaunchSlot());
         if (const char* e = getenv("RC_ENTRY_CULL")) s->opt.entry_cull = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);  // test campaigns: the default of option "entry_cull" for every scene of the process
+        if (const char* e = getenv("RC_STACK16")) s->opt.stack16 = e[0] == '0' ? 0 : 1;  // ... and of option "stack16"
     });
     if (rc != RC_OK) { delete s; return rc; }
     *out = s;

@@ -25,20 +25,27 @@ for name, t, o, r, mode in work:
     for k in (0, 1, 2, 3, 4, 5, 6):
         t.set_option("kernel", k)
         assert_hits_equal(t.trace(r, mode=mode), w, f"{name} kernel {k}")
-    # device-resident repeats: launches 1-10 of the same batch on one stream -- fresh slot, recording launches (1-3, 8), orders rebuilt (2-4, 9),
-    # orders reused (5-7, 10) -- for the three kernels that claim in a learned order, entry cull on and off
+    # device-resident repeats: launches 1-17 of the same batch on one stream -- fresh slot (1), recording launches (2-4, then the host's cadence:
+    # 8, 15), orders rebuilt behind them (the rebuild pair in front of launches 2-6, 9, 16), orders reused in between -- for the kernels
+    # that claim in a learned order, entry cull on and off, 16-bit and 32-bit lane stacks (round 5: the batch's slot is worked out inside
+    # the launch, the header is written by its last workgroup)
     d_r = torch.from_numpy(r.view(np.uint8).reshape(-1)).cuda()
     d_h = torch.empty(len(r) * 32, dtype=torch.uint8, device="cuda")
-    for cull in (1, 0):
-        t.set_option("entry_cull", cull if mode == "closest" else 2 * cull)
-        for k in (3, 5, 6, -1):
-            t.set_option("kernel", k)
-            m = len(r) - 128 * (k + 2)   # another launch shape (chunk count) per kernel setting: a history of its own
-            for rep in range(10):
-                d_h.zero_()
-                t.trace_device(d_r.data_ptr(), d_h.data_ptr(), m, mode=mode)
-                torch.cuda.synchronize()
-                assert_hits_equal(d_h.cpu().numpy().view(rc.HIT_DT)[:m], w[:m], f"{name} kernel {k} entry_cull {cull} launch {rep + 1}")
+    shape = 0
+    for s16 in (1, 0):
+        t.set_option("stack16", s16)
+        for cull in (1, 0):
+            t.set_option("entry_cull", cull if mode == "closest" else 2 * cull)
+            for k in (3, 5, 6, -1):
+                t.set_option("kernel", k)
+                shape += 1
+                m = len(r) - 128 * shape   # another launch shape (chunk count) per setting: a history of its own (eight at most: the ninth takes over the oldest)
+                for rep in range(17):
+                    d_h.zero_()
+                    t.trace_device(d_r.data_ptr(), d_h.data_ptr(), m, mode=mode)
+                    torch.cuda.synchronize()
+                    assert_hits_equal(d_h.cpu().numpy().view(rc.HIT_DT)[:m], w[:m], f"{name} kernel {k} entry_cull {cull} stack16 {s16} launch {rep + 1}")
+    t.set_option("stack16", 1)
     t.set_option("entry_cull", 1); t.set_option("kernel", -1)
     assert t.get_option("claim_drift") == 0
-    print(f"{name}: {len(r)} rays x 7 kernels identical; launches 1-10 of the batch x 4 kernel settings x entry cull on / off identical (oracle {dt:.1f} s, hit fraction {w['hit'].mean():.3f})", flush=True)
+    print(f"{name}: {len(r)} rays x 7 kernels identical; launches 1-17 of the batch x 4 kernel settings x entry cull on / off x 16- / 32-bit lane stacks identical (oracle {dt:.1f} s, hit fraction {w['hit'].mean():.3f})", flush=True)
