@@ -96,7 +96,8 @@ def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_
                     "ta_busy_frac": round(c["TA_TA_BUSY_sum"] / c["GRBM_GUI_ACTIVE"] / 32.0, 4) if c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE") else None,
                     "what_bounds_it": "the length of each ray's chain of dependent passes (fetch through the texture path -> ~8 dependent VALU levels -> stack access) at a fixed number of rays "
                                       "in flight: serial work added to a pass costs 2.3-2.5x its length, VALU work removed beside the chain buys nothing (12 of the 20 min / max of every C2 pass: "
-                                      "SQ_INSTS_VALU -8.7 %, launch time unchanged).  `frac` stays the VALU-issue figure of earlier rounds for continuity; it is not the binding roof.",
+                                      "SQ_INSTS_VALU -8.7 %, launch time unchanged).  Right behind it: the texture-data path, busy `td_busy_frac` of the launch with the four fetch instructions of every node visit (~22 cycles each "
+                                      "whatever the exec mask) -- a shorter chain could buy at most 1 / td_busy_frac.  `frac` stays the VALU-issue figure of earlier rounds for continuity; it is not the binding roof.",
                     "sources": {"valu_wave_instructions_per_launch, lane_utilisation, traffic": COUNTER_FILE + " (rocprofv3 --pmc passes over this bench command, tools/capture_profiles.sh; its fingerprint matches the kernel sources of this run; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md: the traffic is the coalesced ray / hit stream)",
                                 "avg_launch_ms": "HIP events around every timed launch, this run",
                                 "peak": "MI355X_MICROARCH.md execution model: a wave64 VALU instruction issues over 2 cycles on the SIMD-32: 256 CUs x 4 SIMDs x 2.4 GHz / 2",
