@@ -402,33 +402,42 @@ def main():
         # the headline repeats ONE ray buffer, so its claim order is learned from bit-identical rays.  (a) the same batch with the
         # order switched off (what a never-seen batch gets); (b) a camera that moves a little every frame: 16 different batches, eye shifted
         # by 0.02 per frame -- the device recognises them as the same batch (sample rays compared) and keeps reusing / refreshing ONE order
+        def back_to_back(buffers, out_buf, rounds=1):
+            """ms per launch of the given ray buffers traced one after the other on the stream, between two events: measured like the headline's steps"""
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(rounds):
+                for b in buffers:
+                    t.trace_device(b.data_ptr(), out_buf.data_ptr(), n, stream=stream.cuda_stream)
+            e1.record(stream)
+            e1.synchronize()
+            return e0.elapsed_time(e1) / (rounds * len(buffers))
         t.set_option("cost_order", 0)
         ms_off = []
         for _ in range(8):
             t.trace_device(d_rays.data_ptr(), dh_off.data_ptr(), n, stream=stream.cuda_stream)
             ms_off.append(t.last_kernel_ms())
+        b2b_off = back_to_back([d_rays], dh_off, rounds=args.steps)
         t.set_option("cost_order", 1)
-        extras["c3_cost_order_off"] = {"mrays_s": round(n / float(np.mean(ms_off)) / 1e3, 1), "best_mrays_s": round(n / min(ms_off) / 1e3, 1), "hits_identical_to_the_default_run": bool(torch.equal(dh_off, d_hits)),
-                                       "note": "natural claim order: the rate of a batch traced for the first time (mean of 8 launches)"}
+        extras["c3_cost_order_off"] = {"mrays_s": round(n / b2b_off / 1e3, 1), "kernel_mean_mrays_s": round(n / float(np.mean(ms_off)) / 1e3, 1), "kernel_best_mrays_s": round(n / min(ms_off) / 1e3, 1),
+                                       "hits_identical_to_the_default_run": bool(torch.equal(dh_off, d_hits)),
+                                       "note": f"natural claim order -- what a batch traced for the first time gets: {args.steps} launches back to back between two events, like the headline's steps "
+                                               "(kernel_mean: the mean of 8 single launches' own events with the host waiting in between, rounds 3-4's figure; the rays of this one buffer are cache-warm "
+                                               "either way -- c3_moving_camera has rays that are new every launch)"}
         frames = [torch.from_numpy(sc.pinhole_rays(args.res, args.res, cfg["eye"] + np.array([0.02 * k, 0.01 * k, 0.0]), cfg["lattice_centre"], 45.0).view(np.uint8).reshape(-1)).cuda() for k in range(16)]
-        ms_j = []
-        for rep in range(3):
-            for f in frames:
-                t.trace_device(f.data_ptr(), dh_off.data_ptr(), n, stream=stream.cuda_stream)
-                if rep:
-                    ms_j.append(t.last_kernel_ms())
-        t.set_option("cost_order", 0)
-        ms_j0 = []
-        for f in frames:
+        for f in frames:   # (frames 1-16: the shape's first launches of these batches, eight of them inside the mechanism)
             t.trace_device(f.data_ptr(), dh_off.data_ptr(), n, stream=stream.cuda_stream)
-            ms_j0.append(t.last_kernel_ms())
+        b2b_j = back_to_back(frames, dh_off, rounds=2)
+        t.set_option("cost_order", 0)
+        back_to_back(frames, dh_off)
+        b2b_j0 = back_to_back(frames, dh_off, rounds=2)
         t.set_option("cost_order", 1)
-        extras["c3_moving_camera"] = {"mrays_s": round(n / float(np.mean(ms_j)) / 1e3, 1), "frames": len(ms_j), "mrays_s_cost_order_off": round(n / float(np.mean(ms_j0)) / 1e3, 1),
+        extras["c3_moving_camera"] = {"mrays_s": round(n / b2b_j / 1e3, 1), "frames": 32, "mrays_s_cost_order_off": round(n / b2b_j0 / 1e3, 1),
                                       "note": "every launch traces DIFFERENT rays (the eye moves 0.022 per frame, 16 ray buffers of 134 MB in rotation: unlike the headline's one buffer they "
-                                              "do not stay in the Infinity Cache); mean over frames 17-48 with cost_order 1, over 16 frames with cost_order 0.  A moving camera's frames are recognised as "
+                                              "do not stay in the Infinity Cache); frames 17-48 back to back between two events with cost_order 1, then 32 frames with cost_order 0.  A moving camera's frames are recognised as "
                                               "the batch of the frame before but are not REPEATS of it: after eight such launches the shape's next 64 launches go out outside the mechanism "
-                                              "(round 5; an order learned from similar rays gained less than the mechanism cost: -1.5 % in BENCH_r04), so the two figures agree "
-                                              "within noise; the first eight frames -- not in the mean -- pay those ~2 %"}
+                                              "(round 5; an order learned from similar rays gains less than its recording launches cost: docs/EXPERIMENTS.md), so the two figures agree "
+                                              "within noise; the first eight frames -- not in the figure -- pay ~2 %"}
         del dh_off, frames
         shadow = sc.c3_shadow_rays(cfg, rays, hits)
         extras["c3_any_hit_shadow_mrays_s"] = timed(t, shadow, "any", reps=12, key="shadow")
@@ -965,8 +974,8 @@ def main():
                                    f"{n} pinhole primary rays per GPU per step, closest_hit",
                        "scheduling": "every step traces every ray from scratch; the ORDER in which the 128-ray chunks are claimed is the one learned from earlier steps of the same batch "
                                      "(option cost_order: the batch is recognised on the device by sample rays; it records chunk costs in its launches 2-4 and then in one launch of 8, "
-                                     "which runs ~7 % slower, and one launch in 16 ... 128 goes out in natural order to check that the learned order still pays -- the K timed steps "
-                                     "contain their share of all of those; first_touch_value = natural order, moving_camera_value = different rays every launch)",
+                                     "which runs ~7 % slower and is followed by a pair of small rebuild kernels -- the K timed steps contain their share of those; "
+                                     "first_touch_value = the same batch in natural order, moving_camera_value = different rays every launch, both timed back to back like the steps)",
                        "entry_cull": "on (default): an instance whose conservative sphere the ray's segment misses is not entered -- the reference's traversal of it "
                                      "would test no triangle (DESIGN 4.1); every hit record identical with the option off (gpu_matches_bit_exact below is against the CPU oracle); "
                                      "the roofline's VALU counters are those of this kernel, the algorithmic bytes are the reference algorithm's",
