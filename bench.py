@@ -427,14 +427,16 @@ def main():
         frames = [torch.from_numpy(sc.pinhole_rays(args.res, args.res, cfg["eye"] + np.array([0.02 * k, 0.01 * k, 0.0]), cfg["lattice_centre"], 45.0).view(np.uint8).reshape(-1)).cuda() for k in range(16)]
         for f in frames:   # (frames 1-16: the shape's first launches of these batches, eight of them inside the mechanism)
             t.trace_device(f.data_ptr(), dh_off.data_ptr(), n, stream=stream.cuda_stream)
-        b2b_j = back_to_back(frames, dh_off, rounds=2)
-        t.set_option("cost_order", 0)
-        back_to_back(frames, dh_off)
-        b2b_j0 = back_to_back(frames, dh_off, rounds=2)
-        t.set_option("cost_order", 1)
-        extras["c3_moving_camera"] = {"mrays_s": round(n / b2b_j / 1e3, 1), "frames": 32, "mrays_s_cost_order_off": round(n / b2b_j0 / 1e3, 1),
+        on_ms, off_ms = [], []
+        for _ in range(3):   # interleaved: this box's launch times drift by a per cent or two within a process
+            on_ms.append(back_to_back(frames, dh_off, rounds=1))
+            t.set_option("cost_order", 0)
+            off_ms.append(back_to_back(frames, dh_off, rounds=1))
+            t.set_option("cost_order", 1)
+        b2b_j, b2b_j0 = float(np.mean(on_ms)), float(np.mean(off_ms))
+        extras["c3_moving_camera"] = {"mrays_s": round(n / b2b_j / 1e3, 1), "frames": 48, "mrays_s_cost_order_off": round(n / b2b_j0 / 1e3, 1),
                                       "note": "every launch traces DIFFERENT rays (the eye moves 0.022 per frame, 16 ray buffers of 134 MB in rotation: unlike the headline's one buffer they "
-                                              "do not stay in the Infinity Cache); frames 17-48 back to back between two events with cost_order 1, then 32 frames with cost_order 0.  A moving camera's frames are recognised as "
+                                              "do not stay in the Infinity Cache); frames 17-112 in six runs of 16 back to back between two events, alternately with cost_order 1 and 0 (48 frames each).  A moving camera's frames are recognised as "
                                               "the batch of the frame before but are not REPEATS of it: after eight such launches the shape's next 64 launches go out outside the mechanism "
                                               "(round 5; an order learned from similar rays gains less than its recording launches cost: docs/EXPERIMENTS.md), so the two figures agree "
                                               "within noise; the first eight frames -- not in the figure -- pay ~2 %"}

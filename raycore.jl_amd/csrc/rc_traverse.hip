@@ -729,6 +729,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
     typedef hipcub::BlockScan<unsigned long long, kOrderThreads> Scan;
     __shared__ typename Scan::TempStorage scan_tmp;
     __shared__ uint32_t total[kOrderCountWords], before[kOrderClasses];  // chunks of class k in all blocks (last: the largest cost) / in the blocks before this one
+    __shared__ uint32_t unreported_of[kHistSlots], longest_of[kHistSlots];  // per rebuilt slot, for the header update at the end (a serial walk over the blocks' counts there cost 20 us)
     const uint32_t first = blockIdx.x * kOrderTile + threadIdx.x * kOrderPerThread;
     for (int slot = 0; slot < kHistSlots; ++slot) {
         if (hist[kHistPending + slot] == 0u) continue;
@@ -745,6 +746,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
             atomicMax(&total[kOrderClasses], counts[b * kOrderCountWords + kOrderClasses]);
         }
         __syncthreads();
+        if (threadIdx.x == 0) { unreported_of[slot] = total[kOrderClasses - 1]; longest_of[slot] = total[kOrderClasses]; }
         const uint32_t thr = hist[kHistScale + 4 * slot], top = hist[kHistScale + 4 * slot + 1];
         int cls[kOrderPerThread];
         unsigned long long packed[2] = {0ull, 0ull};  // this thread's chunks per class, 12 bits each, five classes per word
@@ -771,9 +773,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
     hist[kHistTicket] = 0u;
     for (int slot = 0; slot < kHistSlots; ++slot) {
         if (hist[kHistPending + slot] == 0u) continue;
-        const uint32_t* counts = order_counts(hist, slot);
-        uint32_t unreported = 0u, mx = 0u;
-        for (uint32_t b = 0; b < gridDim.x; ++b) { unreported += counts[b * kOrderCountWords + kOrderClasses - 1]; const uint32_t m = counts[b * kOrderCountWords + kOrderClasses]; mx = m > mx ? m : mx; }
+        const uint32_t unreported = unreported_of[slot], mx = longest_of[slot];
         uint32_t* scale = hist + kHistScale + 4 * slot;  // the scale of the slot's NEXT recording launch
         const uint32_t thr = scale[0], reported = n_chunks - unreported;
         uint32_t next = thr;

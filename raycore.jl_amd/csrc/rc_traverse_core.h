@@ -134,7 +134,8 @@ __device__ inline bool rc_claim_chunk(const RcClaim& c, const uint32_t* order, u
 
 // Which batch is this launch, and what does it do with the batch's slot?  A pure function of the history's header, the remembered sample
 // rays and the launch's own: every wave evaluates it (64 lanes, one sample ray each) and gets the same answer.  The closest slot below the
-// threshold is the batch's; none: the least recently used slot is given to it ("fresh": natural order, nothing recorded).  A slot records in
+// threshold is the batch's -- to continue if the launch repeats the slot's batch, to start over in otherwise; none: the least recently used
+// slot is given to it.  A launch that starts a slot is "fresh": natural order, nothing recorded.  A slot records in
 // its launches 2-4 (never the first: a batch that does not come back pays nothing; the reporting threshold needs two rounds to settle) and
 // then when the host's cadence says so (one launch in eight).
 struct OrderDecision {
@@ -166,8 +167,12 @@ __device__ inline OrderDecision order_select(const RcClaim& c, int lane, float r
         if (d < best_d) { best_d = d; best = k; }
     }
     OrderDecision o;
-    o.fresh = best < 0 ? 1u : 0u;
-    o.exact = (best >= 0 && best_d == 0.0f) ? 1u : 0u;  // the same sample rays bit for bit: a REPEAT of the remembered batch
+    // Only a REPEAT -- the same sample rays bit for bit -- continues a slot's history.  A batch that merely resembles a remembered one (a
+    // camera that moves every frame) starts over IN that slot (it replaces what it resembles instead of evicting somebody else): natural
+    // order, nothing recorded, exactly like a batch never seen.  An order learned from similar rays was measured slower than natural order
+    // (docs/EXPERIMENTS.md), and deciding this here rather than on the host makes it hold for a caller that enqueues far ahead of the device.
+    o.exact = (best >= 0 && best_d == 0.0f) ? 1u : 0u;
+    o.fresh = o.exact ? 0u : 1u;
     int sel = best;
     if (best < 0) {  // an empty slot, else the least recently used one
         uint32_t oldest = 0xFFFFFFFFu;

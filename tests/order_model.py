@@ -28,7 +28,8 @@ class Mutations:
     """knobs for the mutants the comparison has to catch"""
     record_first, record_last = 2, 4   # a slot records its launches 2-4 ...
     first_cadence_record = 8           # ... and then when the host's cadence asks (launches 8, 15, 23, 32, 39, ... of the shape)
-    repeats_only = True                # the streak counts launches that are not exact repeats (False: round 4's rule, unmatched launches only)
+    repeats_only = True                # the streak counts launches that are not exact repeats (False: only launches that matched no slot at all)
+    only_repeats_continue = True       # a launch that matches a slot without repeating its batch starts over in it (False: it continues the slot's history, the rule before)
     rebuild_on_pending_word = True     # the host runs the rebuild kernels when the device reported a waiting recording
 
 
@@ -91,8 +92,9 @@ class History:
                 break
             if best is None and self.batch[k] in near:
                 best = k
-        fresh = best is None
-        sel = min(range(K_SLOTS), key=lambda k: (self.stamp[k], k)) if fresh else best   # an empty slot, else the least recently used
+        # only a REPEAT continues a slot's history; a launch that merely resembles a remembered batch starts over in that batch's slot
+        fresh = (not exact) if self.m.only_repeats_continue else best is None
+        sel = best if best is not None else min(range(K_SLOTS), key=lambda k: (self.stamp[k], k))   # the matched slot, else an empty one, else the least recently used
         gen = 1 if fresh else self.gen[sel] + 1
         record = (self.m.record_first <= gen <= self.m.record_last) or (want_record and gen >= 5)
         valid = (not fresh) and self.has_order[sel] != 0
@@ -106,7 +108,7 @@ class History:
             self.has_order[sel] = 0
         if record:
             self.pending[sel] = 1
-        not_counted = exact if self.m.repeats_only else not fresh
+        not_counted = exact if self.m.repeats_only else best is not None
         self.streak = 0 if not_counted else self.streak + 1
         self.host_streak = self.streak     # (the test waits for every launch: the pinned words are current at the next one)
         self.host_pending = int(any(self.pending))

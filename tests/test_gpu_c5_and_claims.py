@@ -643,7 +643,7 @@ def test_changing_batch_sizes_never_block_and_change_no_result(rc, oracle):
 
 def test_alternating_batches_keep_their_own_claim_order(rc, oracle):
     """VERDICT r3 #5a: consecutive launches of ONE shape (size, mode, stream) that trace DIFFERENT rays -- two cameras, N light samples.  The
-    batch is recognised on the device by 64 sample rays (k_order_select): A and B get a slot each and keep alternating between them, a
+    batch is recognised on the device by 64 sample rays (order_select, inside the launch): A and B get a slot each and keep alternating between them, a
     camera that moves a little stays in its slot, a fifth distinct batch evicts the least recently used of the four slots -- and whatever
     order the chunks are claimed in, every launch returns the oracle's hits."""
     import ctypes
@@ -685,7 +685,8 @@ def test_alternating_batches_keep_their_own_claim_order(rc, oracle):
             seen.setdefault(k, sel)
             assert sel == seen[k] and fresh == (1 if rep == 0 else 0) and valid == (0 if rep < 2 else 1) and gens[sel] == rep + 1, (rep, k, sel, valid, fresh, gens)
     assert seen[0] != seen[1]
-    # the same camera, moved a little every frame: one slot (its samples follow the camera), never fresh again
+    # the same camera, moved a little every frame: one slot (its samples follow the camera: nobody else's is taken), but never a REPEAT: every
+    # frame starts over in that slot -- natural order, nothing recorded (round 5: decided on the device, so it holds however far ahead the host enqueues)
     moving = [view(eyes[0] + np.array([0.02 * f, 0.01 * f, 0.0])) for f in range(1, 7)]
     for f, b in enumerate(moving):
         d = torch.from_numpy(b.view(np.uint8).reshape(-1)).cuda()
@@ -694,7 +695,7 @@ def test_alternating_batches_keep_their_own_claim_order(rc, oracle):
         torch.cuda.synchronize()
         assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), o.trace(b, nthreads=16), f"moving camera frame {f}")
         h = header()
-        assert int(h[0]) == seen[0] and int(h[4]) == 0 and int(h[36]) == f + 1, (f, h[:8])   # (the streak of launches that are not REPEATS grows: eight of them and the host would pause the order kernels)
+        assert int(h[0]) == seen[0] and int(h[4]) == 1 and int(h[1]) == 0 and int(h[5]) == 0 and int(h[36]) == f + 1, (f, h[:8])   # (the streak of launches that are not REPEATS grows: eight of them and the host would pause the mechanism)
     sel, valid, fresh, gens = launch(0, "batch 0, close to where the camera stopped")
     sel, valid, fresh, gens = launch(0, "batch 0 again: a repeat, the streak starts over")
     assert int(header()[36]) == 0
@@ -714,8 +715,8 @@ def test_alternating_batches_keep_their_own_claim_order(rc, oracle):
 
 def test_batches_that_never_repeat_stop_paying_for_the_claim_order(rc, oracle):
     """A path tracer's bounce rays are new every launch: six different batches in rotation on the history's four slots match nothing, ever.
-    k_order_select reports the run of unmatched launches to the host through a pinned word; after eight of them the host leaves the order
-    kernels out (the header's launch clock stops advancing) for the next 64 launches of the shape.  Results are the oracle's throughout."""
+    The launches report the run of non-repeats to the host through a pinned word (order_commit); after eight of them the host keeps the
+    shape out of the mechanism (the header's launch clock stops advancing) for its next 64 launches.  Results are the oracle's throughout."""
     import ctypes
     import torch
     sc = rc.scenes
@@ -781,10 +782,11 @@ def test_batches_that_never_repeat_stop_paying_for_the_claim_order(rc, oracle):
 
 
 def test_a_camera_that_moves_every_frame_stops_paying_for_the_claim_order(rc, oracle):
-    """a camera that moves a little every frame is recognised as the batch of the frame before (its slot's order is reused)
-    -- and ran 1.5-2 % SLOWER than with the order switched off, because an order learned from similar rays gains less than the three small
-    dispatches in front of the launch cost.  k_order_select therefore counts the launches that are not REPEATS (identical sample rays) of a
-    remembered batch; after eight of them the shape's launches go out without the order kernels for a while.  A still camera keeps its order."""
+    """a camera that moves a little every frame is recognised as the batch of the frame before -- and ran 1.5-2 % SLOWER with
+    that batch's claim order than with the order switched off (an order learned from similar rays gains less than its recording launches
+    cost).  Only a REPEAT (identical sample rays) continues a slot's history: the moving camera's frames start over in their slot -- natural
+    order, nothing recorded -- and are counted; after eight of them the shape's launches leave the mechanism for a while.  A still camera
+    keeps its order."""
     import ctypes
     import torch
     sc = rc.scenes
@@ -812,8 +814,8 @@ def test_a_camera_that_moves_every_frame_stops_paying_for_the_claim_order(rc, or
     seen = [frame(eye0, f"still camera, launch {k + 1}") for k in range(4)]
     assert [c[0] for c in seen] == [1, 2, 3, 4] and [c[3] for c in seen] == [1, 0, 0, 0] and seen[3][1] == 1, seen   # repeats: the order is in use, the streak stays at 0
     seen = [frame(eye0 + np.array([0.02 * f, 0.01 * f, 0.0]), f"moving camera, frame {f}") for f in range(1, 13)]
-    assert [c[0] for c in seen[:8]] == list(range(5, 13)) and all(c[2] == 0 for c in seen[:8]), seen                 # matched (never fresh), through the order kernels
+    assert [c[0] for c in seen[:8]] == list(range(5, 13)) and all(c[2] == 1 and c[1] == 0 for c in seen[:8]), seen   # seen by the mechanism: fresh in their slot, natural order
     assert [c[3] for c in seen[:8]] == list(range(1, 9)), seen                                                        # ... but not repeats
-    assert all(c[0] == 12 for c in seen[8:]), seen                                                                    # frames 9-12: natural order, no order kernels
+    assert all(c[0] == 12 for c in seen[8:]), seen                                                                    # frames 9-12: outside the mechanism
     assert t.get_option("claim_drift") == 0
     t.free()

@@ -39,10 +39,12 @@ def test_five_batches_on_four_slots_never_match_and_the_host_pauses_after_eight(
     assert [t["streak"] for t in tr[:8]] == list(range(1, 9)) and tr[8:] == [None] * 7
 
 
-def test_a_moving_camera_is_matched_but_not_a_repeat_and_the_pause_ends():
+def test_a_moving_camera_starts_over_in_its_slot_every_frame_and_the_pause_ends():
     tr, _ = run(om.scripts()["still, then a moving camera, then still again"])
     moving = tr[4:16]
-    assert all(t["fresh"] == 0 for t in moving[:8]) and [t["streak"] for t in moving[:8]] == list(range(1, 9)) and moving[8:] == [None] * 4
+    # matched (the still batch's slot follows the camera: nobody else is evicted) but never a repeat: natural order, nothing recorded, from the first frame on
+    assert all(t["fresh"] == 1 and t["order_valid"] == 0 and t["records"] == 0 and t["sel"] == tr[3]["sel"] for t in moving[:8])
+    assert [t["streak"] for t in moving[:8]] == list(range(1, 9)) and moving[8:] == [None] * 4
     assert tr[16:] == [None] * 4                                                           # still inside the pause
     long, _ = run(om.scripts()["never repeating, the pause, then a repeating batch"])
     assert [t is not None for t in long[:8]] == [True] * 8 and long[8:72] == [None] * 64
@@ -54,7 +56,7 @@ def test_mutants_of_the_transitions_change_the_trace():
     """what the device comparison relies on: each of these one-token changes of the state machine shows up in the modelled words of at least
     one script (so the same change made in order_select / order_commit / rc_cost_order_setup fails tests/test_gpu_order_model.py)"""
     ref = {name: run(sc)[0] for name, sc in om.scripts().items()}
-    for field, value in (("record_first", 1), ("record_last", 3), ("first_cadence_record", 9), ("repeats_only", False), ("rebuild_on_pending_word", False)):
+    for field, value in (("record_first", 1), ("record_last", 3), ("first_cadence_record", 9), ("repeats_only", False), ("only_repeats_continue", False), ("rebuild_on_pending_word", False)):
         m = copy.copy(om.Mutations())
         setattr(m, field, value)
         assert any(run(sc, m)[0] != ref[name] for name, sc in om.scripts().items()), field
