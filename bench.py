@@ -458,17 +458,26 @@ def main():
         t.set_option("cost_order", 0)
         for f in fresh * 2:  # untimed: first touches of six new 134 MB buffers run 5-10 % slower than later passes, whatever the option
             t.trace_device(f.data_ptr(), dh_f.data_ptr(), n, stream=stream.cuda_stream)
-        for co in (1, 0):
-            t.set_option("cost_order", co)
-            ms = []
-            for rep in range(3):
+        t.set_option("cost_order", 1)
+        for f in fresh * 2:  # untimed too: the shape's first launches under the mechanism (the eighth starts the pause)
+            t.trace_device(f.data_ptr(), dh_f.data_ptr(), n, stream=stream.cuda_stream)
+        ms = {1: [], 0: []}
+        for rep in range(4):  # interleaved (launch times drift by a per cent or two within a process): 6 launches back to back per option and round
+            for co in (1, 0):
+                t.set_option("cost_order", co)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
                 for f in fresh:
                     t.trace_device(f.data_ptr(), dh_f.data_ptr(), n, stream=stream.cuda_stream)
-                    if rep:
-                        ms.append(t.last_kernel_ms())
-            nr[f"cost_order_{co}_mrays_s"] = round(n / float(np.mean(ms)) / 1e3, 1)
+                e1.record(stream)
+                e1.synchronize()
+                ms[co].append(e0.elapsed_time(e1) / len(fresh))
+        for co in (1, 0):
+            nr[f"cost_order_{co}_mrays_s"] = round(n / float(np.mean(ms[co])) / 1e3, 1)
         t.set_option("cost_order", 1)
-        nr["note"] = "4.19 M incoherent bounce rays, a different batch every launch (6 in rotation > the 4 batch slots): mean of 12 launches; after eight launches that matched no remembered batch the shape's launches go out in natural order, outside the mechanism (nothing is recorded for a batch's first launch either): the two figures should agree within noise"
+        nr["note"] = ("4.19 M incoherent bounce rays, a different batch every launch (6 in rotation > the 4 batch slots): 24 launches per option, back to back in runs of 6, the options alternating; "
+                      "a batch's first launch records nothing, and after eight launches that repeated no remembered batch the shape's next 64 launches go out in natural order without looking at their "
+                      "rays (counted and decided inside the launches): the two figures should agree within noise")
         extras["c4_never_repeating_batches"] = nr
         del fresh, dh_f
         mid = sc.c3_primary_rays(cfg, 1024, 1024)

@@ -1204,7 +1204,7 @@ int rc_get_option(rc_scene* s, const char* name, int64_t* value) {
     else if (k == "debug_order_ptr" || k == "debug_order_n" || k == "debug_ctl_ptr" || k == "debug_cost_ptr") {  // dev: the claim order of the most recently used launch shape
         const rc_scene::ChunkHistory* h = nullptr;
         for (const auto& e : s->histories) if (!h || e.last_use > h->last_use) h = &e;
-        *value = !h ? 0 : (k == "debug_order_n" ? (int64_t)h->n_chunks : (k == "debug_ctl_ptr" ? (int64_t)(uintptr_t)h->ctl.p : (k == "debug_cost_ptr" ? (int64_t)(uintptr_t)h->cost.p : (int64_t)(uintptr_t)h->order.p)));
+        *value = !h ? 0 : (k == "debug_order_n" ? (int64_t)h->n_chunks : (k == "debug_ctl_ptr" ? (int64_t)(uintptr_t)(h->ctl.p + h->parity * rc_scene::ChunkHistory::kHeaderWords) : (k == "debug_cost_ptr" ? (int64_t)(uintptr_t)h->cost.p : (int64_t)(uintptr_t)h->order.p)));
     }
     else if (k == "debug_inst_cull_ptr") *value = (int64_t)(uintptr_t)s->inst_cull.p;  // dev: the entry-cull spheres, 2 x float4 per instance
     else if (k == "cost_thr") *value = s->opt.cost_thr;

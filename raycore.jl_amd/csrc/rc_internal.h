@@ -274,10 +274,11 @@ struct rc_scene {
         DevBuf<uint32_t> cost, order, ctl;  // cost: kHistSlots arrays (one per remembered batch); ctl: the header words kHist* (rc_traverse_core.h) + per-block class counts of the order kernels
         DevBuf<float> samples;              // kHistSlots x kHistSamples sample rays (8 floats each): how a launch's batch is recognised
         uint64_t gen = 0;                   // launches of this shape so far
+        static constexpr uint32_t kHeaderWords = 48;  // = rc::kHistHeaderWords (rc_traverse_core.h; asserted in rc_traverse.hip)
+        uint32_t parity = 0;                // which copy of the header / the samples the shape's next launch reads (order_commit writes the other)
         uint64_t last_use = 0;
         RcEvent last;                       // behind the latest launch that used the entry's buffers
         PinnedU32 fresh_streak;             // written by the launches (order_commit): [0] consecutive launches of this shape that were not repeats of a remembered batch, [1] a recording waits for the rebuild kernels
-        uint32_t skip_left = 0;             // launches still to run without the mechanism (the shape's batches do not repeat)
         uint32_t rebuild_credit = 0;        // launches that still get the rebuild kernel pair in front (a slot may hold a recording: rc_cost_order_setup)
         uint64_t next_record = 8;           // the launch of the shape that next asks its batch to record (cadence 7, 8, 9, ...)
         uint32_t records_asked = 0;

@@ -695,6 +695,7 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
 // hist[kHistScale + 4 slot]: [0], [1] = the threshold / the top of the scale the slot's latest recording launch worked with; [2], [3] = the pair its next one will.
 namespace {
 constexpr int kOrderThreads = 256, kOrderPerThread = 4, kOrderTile = kOrderThreads * kOrderPerThread, kOrderClasses = 10, kOrderMaxBlocks = 256;
+static_assert(rc_scene::ChunkHistory::kHeaderWords == (uint32_t)kHistHeaderWords, "rc_internal.h repeats the size of a header copy");
 static_assert((uint32_t)(kOrderTile * kOrderMaxBlocks) == kHistSlotStride, "a slot's cost array holds the most chunks the rebuild kernels handle");
 constexpr int kOrderCountWords = kOrderClasses + 1;  // per block: the classes' chunk counts, the largest cost
 constexpr size_t kHistWords = kHistCounts + (size_t)kHistSlots * kOrderMaxBlocks * kOrderCountWords;
@@ -707,8 +708,9 @@ __device__ inline int order_class(uint32_t c, uint32_t thr, uint32_t top) {
 }
 __device__ inline uint32_t* order_counts(uint32_t* hist, int slot) { return hist + kHistCounts + (size_t)slot * kOrderMaxBlocks * kOrderCountWords; }
 
-__global__ __launch_bounds__(kOrderThreads) void k_order_count(const uint32_t* cost_base, uint32_t* hist, uint32_t n_chunks) {
+__global__ __launch_bounds__(kOrderThreads) void k_order_count(const uint32_t* cost_base, uint32_t* ctl, uint32_t parity, uint32_t n_chunks) {
     __shared__ uint32_t cnt[kOrderCountWords];
+    const uint32_t* hist = ctl + parity * kHistHeaderWords;  // the header copy the shape's next launch reads
     for (int slot = 0; slot < kHistSlots; ++slot) {
         if (hist[kHistPending + slot] == 0u) continue;  // (wave-uniform: a header word)
         if (threadIdx.x < kOrderCountWords) cnt[threadIdx.x] = 0u;
@@ -721,11 +723,12 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_count(const uint32_t* c
             if (first + j < n_chunks) { const uint32_t c = cost[first + j]; atomicAdd(&cnt[order_class(c, thr, top)], 1u); mx = c > mx ? c : mx; }
         if (mx) atomicMax(&cnt[kOrderClasses], mx);
         __syncthreads();
-        if (threadIdx.x < kOrderCountWords) order_counts(hist, slot)[blockIdx.x * kOrderCountWords + threadIdx.x] = cnt[threadIdx.x];  // [classes ..., block maximum]
+        if (threadIdx.x < kOrderCountWords) order_counts(ctl, slot)[blockIdx.x * kOrderCountWords + threadIdx.x] = cnt[threadIdx.x];  // [classes ..., block maximum]
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_base, uint32_t* order_base, uint32_t* hist, uint32_t n_chunks, uint32_t* host_words) {
+__global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_base, uint32_t* order_base, uint32_t* ctl, uint32_t parity, uint32_t n_chunks, uint32_t* host_words) {
+    uint32_t* hist = ctl + parity * kHistHeaderWords;
     typedef hipcub::BlockScan<unsigned long long, kOrderThreads> Scan;
     __shared__ typename Scan::TempStorage scan_tmp;
     __shared__ uint32_t total[kOrderCountWords], before[kOrderClasses];  // chunks of class k in all blocks (last: the largest cost) / in the blocks before this one
@@ -737,13 +740,20 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
         uint32_t* order = order_base + (size_t)slot * kHistSlotStride;
         if (threadIdx.x < kOrderCountWords) { total[threadIdx.x] = 0u; if (threadIdx.x < kOrderClasses) before[threadIdx.x] = 0u; }
         __syncthreads();
-        const uint32_t* counts = order_counts(hist, slot);
-        for (uint32_t b = threadIdx.x; b < gridDim.x; b += kOrderThreads) {
-            for (int k = 0; k < kOrderClasses; ++k) {
-                const uint32_t c = counts[b * kOrderCountWords + k];
-                if (c) { atomicAdd(&total[k], c); if (b < blockIdx.x) atomicAdd(&before[k], c); }
+        const uint32_t* counts = order_counts(ctl, slot);
+        {   // thread (word w, group g) sums word w of the blocks g, g + 16, ... in registers, then one LDS atomic per thread.  (One thread per
+            // BLOCK with an LDS atomic per word put 32 lanes on the same LDS address twenty times over: 17 of this kernel's 22 us.)
+            const uint32_t w = threadIdx.x & 15u, g = threadIdx.x >> 4;
+            if (w < (uint32_t)kOrderCountWords) {
+                uint32_t all = 0u, mine = 0u;
+                for (uint32_t b = g; b < gridDim.x; b += kOrderThreads / 16) {
+                    const uint32_t c = counts[b * kOrderCountWords + w];
+                    if (w == (uint32_t)kOrderClasses) all = c > all ? c : all;
+                    else { all += c; mine += b < blockIdx.x ? c : 0u; }
+                }
+                if (w == (uint32_t)kOrderClasses) atomicMax(&total[w], all);
+                else { if (all) atomicAdd(&total[w], all); if (mine) atomicAdd(&before[w], mine); }
             }
-            atomicMax(&total[kOrderClasses], counts[b * kOrderCountWords + kOrderClasses]);
         }
         __syncthreads();
         if (threadIdx.x == 0) { unreported_of[slot] = total[kOrderClasses - 1]; longest_of[slot] = total[kOrderClasses]; }
@@ -760,17 +770,26 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
         Scan(scan_tmp).ExclusiveSum(packed[1], prefix[1]);
         uint32_t pos[kOrderClasses], acc = 0;
         for (int k = 0; k < kOrderClasses; ++k) { pos[k] = acc + before[k] + (uint32_t)((prefix[k / 5] >> (12 * (k % 5))) & 0xFFFull); acc += total[k]; }
-        for (int j = 0; j < kOrderPerThread; ++j)
-            if (cls[j] >= 0) { order[pos[cls[j]]++] = first + j; cost[first + j] = 0u; }
+#pragma unroll
+        for (int j = 0; j < kOrderPerThread; ++j) {
+            if (cls[j] < 0) continue;
+            uint32_t at = 0;  // pos[cls[j]]++ by selection: an array indexed by a run-time class would live in scratch memory
+#pragma unroll
+            for (int k = 0; k < kOrderClasses; ++k) { const bool mine = cls[j] == k; at = mine ? pos[k] : at; pos[k] += mine ? 1u : 0u; }
+            order[at] = first + j;
+            cost[first + j] = 0u;
+        }
         __syncthreads();
     }
     // the header: every block has read what it needs of it above; the LAST block to get here turns the recordings into orders in use
+    // (No fence: what the blocks wrote above -- orders, cleared costs -- is read by the NEXT kernel; the last block reads only header words
+    // nobody writes in this kernel and its own LDS.  An agent-scope release here wrote back the whole L2 -- full of the previous launch's hit
+    // records -- and made this kernel 25 us long.)
     __shared__ uint32_t last_block;
-    __threadfence();
-    if (threadIdx.x == 0) last_block = atomicAdd(hist + kHistTicket, 1u) + 1u == gridDim.x ? 1u : 0u;
+    if (threadIdx.x == 0) last_block = atomicAdd(ctl + kHistTicket, 1u) + 1u == gridDim.x ? 1u : 0u;
     __syncthreads();
     if (!last_block || threadIdx.x != 0) return;
-    hist[kHistTicket] = 0u;
+    ctl[kHistTicket] = 0u;
     for (int slot = 0; slot < kHistSlots; ++slot) {
         if (hist[kHistPending + slot] == 0u) continue;
         const uint32_t unreported = unreported_of[slot], mx = longest_of[slot];
@@ -793,6 +812,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
 bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t stream, rc::RcClaim& c, const RcRay* d_rays, const float* host_sample) {
     const uint64_t n_base64 = (n + c.pool - 1) / c.pool;  // chunks (the claim order permutes whole chunks; parts follow their chunk)
     // only where the order can matter: at least a claim per wave; the cost path maps rays to chunks with a shift (pool a power of two)
+    if (s->n_tlas_nodes == 0) return false;  // (an empty scene's launches return before they look at the history: the header's two copies must flip with the host's parity)
     if (!s->opt.cost_order || c.n_chunks < c.total_waves || n_base64 < 64u || n_base64 > (uint64_t)(kOrderTile * kOrderMaxBlocks) || (c.pool & (c.pool - 1u)) != 0u || c.pool < 16u) return false;
     if (!d_rays && !host_sample) return false;
     const uint32_t n_base = (uint32_t)n_base64;
@@ -820,7 +840,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
             s->histories.emplace_back();
             h = &s->histories.back();
             h->cost.reserve((size_t)kHistSlots * kHistSlotStride); h->order.reserve((size_t)kHistSlots * kHistSlotStride); h->ctl.reserve(kHistWords);
-            h->samples.reserve((size_t)kHistSlots * kHistSamples * 8);
+            h->samples.reserve(2 * kHistSampleFloats);
         } else {
             if (!seen_before) return false;
             size_t victim = s->histories.size();
@@ -835,46 +855,35 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
             h = &s->histories[victim];
         }
         h->n_items = n; h->any = any_hit; h->stream = stream; h->n_chunks = n_base; h->pool = c.pool;
-        h->skip_left = 0;
         h->rebuild_credit = 0; h->next_record = 8; h->records_asked = 0;
-        if (h->fresh_streak.p) { reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p)[0] = 0u; reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p)[1] = 0u; }
+        if (h->fresh_streak.p) { reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p)[0] = 0u; reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p)[1] = 0u; reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p)[2] = 0u; }
         RC_HIP(hipMemsetAsync(h->ctl.p, 0, sizeof(uint32_t) * kHistCounts, stream));  // every batch slot empty (the cost arrays are cleared when a slot is given out)
         h->gen = 0;
+        h->parity = 0;
     }
     h->last_use = ++s->history_clock;
     s->cur_history = (int)(h - s->histories.data());
-    // A shape whose batches never repeat learns nothing and should pay nothing: the launch itself (order_commit) reports the run of launches
-    // that were not a repeat of a remembered batch (sample rays identical) into a pinned word; once it reads kGiveUpAfter (whenever the
-    // launches that wrote it have run -- nothing here waits) the next kGiveUpFor launches of the shape go out in natural order, outside the
-    // mechanism altogether, then the shape is tried again.
-    constexpr uint32_t kGiveUpAfter = 8, kGiveUpFor = 64;
+    // (A shape whose batches never repeat leaves the mechanism for a while: counted and decided on the device, order_select / order_commit.)
     h->fresh_streak.ensure();
-    if (h->skip_left > 0) { h->skip_left -= 1; return false; }
-    if (*reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p) >= kGiveUpAfter) {
-        *reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p) = 0u;
-        // the DEVICE's copy of the streak starts over too (it stayed at 8, so the first launch after the pause that was not a repeat
-        // reported 9 and the shape gave up again after a single probe launch -- a batch that starts repeating later never got its order back)
-        RC_HIP(hipMemsetAsync(h->ctl.p + kHistFreshStreak, 0, sizeof(uint32_t), stream));
-        h->skip_left = kGiveUpFor - 1;
-        return false;
-    }
     h->gen += 1;
     // Turning recordings into orders: the pair of rebuild kernels goes in front of this launch only when a slot MAY hold a recording --
     // the shape's first launches (a batch records its launches 2-4), the launches after the device reported a launch that was not a
     // repeat (a new batch starts its own launches 2-4), and the launch after one this host asked to record.  Everything else about the
     // launch's claim order is decided inside the launch itself (order_select).
-    volatile uint32_t* pinned = reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p);  // [0] the run of non-repeats, [1] a recording waits (both as of the latest launch that has FINISHED)
+    volatile uint32_t* pinned = reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p);  // [0] the run of non-repeats, [1] a recording waits, [2] the pause (all as of the latest launch that has FINISHED)
+    const bool paused = pinned[2] > 1u;  // (this launch and the next are still inside the pause: nothing records, nothing to rebuild)
     if (pinned[0] > 0u) h->rebuild_credit = 6;
+    if (paused) h->rebuild_credit = 0;
     const uint32_t blocks = (n_base + kOrderTile - 1) / kOrderTile;
-    if (h->gen >= 2 && (h->gen <= 6 || h->rebuild_credit > 0 || pinned[1] != 0u)) {
-        hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->ctl.p, n_base);
-        hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->order.p, h->ctl.p, n_base, h->fresh_streak.p);
+    if (h->gen >= 2 && !paused && (h->gen <= 6 || h->rebuild_credit > 0 || pinned[1] != 0u)) {
+        hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->ctl.p, h->parity, n_base);
+        hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(kOrderThreads), 0, stream, h->cost.p, h->order.p, h->ctl.p, h->parity, n_base, h->fresh_streak.p);
     }
     if (h->rebuild_credit > 0) h->rebuild_credit -= 1;
     // the recording cadence of a batch past its fourth launch: one launch in 7, 8, 9, 7, ... of the shape (not a fixed period: two or three
     // batches alternating on the shape must all get their turn)
     c.want_record = 0;
-    if (h->gen >= h->next_record) {
+    if (h->gen >= h->next_record && !paused) {
         c.want_record = 1;
         h->next_record = h->gen + 7 + (h->records_asked % 3);
         h->records_asked += 1;
@@ -892,6 +901,8 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
     c.order = h->order.p;
     c.cost = h->cost.p;
     c.hist = h->ctl.p;
+    c.parity = h->parity;  // the launch reads this copy of the header and writes the other: the shape's next launch reads that one
+    h->parity ^= 1u;
     return true;
 }
 

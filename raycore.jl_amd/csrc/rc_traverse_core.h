@@ -63,17 +63,18 @@ struct RcClaim {
     uint32_t c1, c2, c3;           // position in the claim order of the first chunk dealt in halves / quarters / eighths
     const uint32_t* order;         // position in the claim order -> chunk, a permutation of 0 .. ceil(n_items / pool) - 1; nullptr = natural order
     uint32_t* cost;                // per chunk: the longest time in flight (interior iterations of its wave) of a ray of the chunk this launch; nullptr = not recorded
-    uint32_t* hist;                // the history's header words (kHist*, below).  Every wave of the launch works out by itself which of the history's batch slots
-                                   // the launch belongs to (order_select: a pure function of the header and the launch's sample rays) -- `cost` / `order` are slot
-                                   // 0's arrays, slot k's lie k * kHistSlotStride words on --; the LAST workgroup to finish writes the header's next state.  nullptr = no history
+    uint32_t* hist;                // the history's header words (kHist*, below), two copies.  Every wave of the launch works out by itself which of the history's batch slots
+                                   // the launch belongs to (order_select: a pure function of the header copy `parity` and the launch's sample rays) -- `cost` / `order` are slot
+                                   // 0's arrays, slot k's lie k * kHistSlotStride words on --; wave 0 of workgroup 0 writes the next state into the other copy.  nullptr = no history
+    uint32_t parity;               // which copy of the header and of the remembered samples this launch READS (the host flips it per launch of the shape)
     uint32_t pool_shift;           // log2(pool) when pool is a power of two (the cost path maps a ray to its chunk with a shift)
     // what order_select needs to recognise the batch
     const RcRay* sample_rays;      // the launch's ray array, or nullptr: generated rays, described by sample_host
     uint64_t n_sample;             // rays in it
     float sample_host[8];
     float inv_l2;                  // 1 / (scene diagonal)^2: origins are compared relative to the scene
-    float* samples;                // kHistSlots x kHistSamples remembered sample rays (8 floats each)
-    uint32_t* host_streak;         // pinned word: the run of launches that were not repeats, for the host's pause logic
+    float* samples;                // 2 copies x kHistSlots x kHistSamples remembered sample rays (8 floats each)
+    uint32_t* host_streak;         // pinned words for the host's decision about the rebuild kernels: [0] the run of launches that were not repeats, [1] a recording waits, [2] launches of a pause still to go
     uint32_t init_thr;             // reporting threshold a batch starts with
     uint32_t want_record;          // the host's cadence: a slot past its fourth launch records in this launch
 };
@@ -82,15 +83,21 @@ struct RcClaim {
 // batch never seen before runs in natural order instead of in somebody else's).  Header words:
 constexpr int kHistSlots = 4, kHistSamples = 64;
 constexpr uint32_t kHistSlotStride = 1u << 18;  // words between the slots' cost arrays = the most chunks the rebuild kernels handle
-constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 3, kHistFresh = 4, kHistRecorded = 5,  // of the latest launch (written at its end: tests, tools)
+// The header exists TWICE (kHistHeaderWords apart): a launch reads copy `parity` and writes the next state into the other one, so the one wave
+// that writes (order_commit) can do it at the START of the launch, while every other wave is still reading, and nothing is left to do at the
+// end.  The host flips `parity` with every launch of the shape; the rebuild kernels work in place on the copy the next launch reads.
+constexpr int kHistSel = 0, kHistOrderValid = 1, kHistLifeThr = 2, kHistClock = 3, kHistFresh = 4, kHistRecorded = 5,  // of the latest launch (tests, tools)
               kHistFreshStreak = 36 /* consecutive launches that were not a repeat (identical sample rays) of a remembered batch */,
-              kHistTicket = 37 /* workgroups of the running launch that have finished (the last one updates the header and puts this back to 0) */,
+              kHistSkipLeft = 38 /* launches of the shape still to go out OUTSIDE the mechanism (its batches do not repeat: order_commit) */,
               kHistStamp = 8 /* [kHistSlots] */, kHistGen = 12 /* [kHistSlots] */,
               kHistScale = 16 /* [kHistSlots][4]: (threshold, top of the scale) the slot's latest recording launch worked with; the pair its next one will */,
               kHistPending = 32 /* [kHistSlots]: the slot's cost array holds a recording that no order has been built from yet */,
-              kHistHasOrder = 40 /* [kHistSlots]: the slot's order array holds an order built from a recording of the slot's batch */, kHistCounts = 48;
-// Round 5: nothing runs in front of a launch to prepare its claim order.  order_select (below) is evaluated by every wave of the launch itself;
-// the header's next state is written by the last workgroup to finish (all others have started, hence read the old state, before it can);
+              kHistHasOrder = 40 /* [kHistSlots]: the slot's order array holds an order built from a recording of the slot's batch */,
+              kHistHeaderWords = 48 /* one copy */,
+              kHistTicket = 2 * kHistHeaderWords /* k_order_scatter: blocks that have finished (behind both copies) */, kHistCounts = 2 * kHistHeaderWords + 8;
+constexpr size_t kHistSampleFloats = (size_t)kHistSlots * kHistSamples * 8;  // one copy of the remembered sample rays (they are doubled like the header)
+// Round 5: nothing runs in front of a launch to prepare its claim order and nothing behind it.  order_select (below) is evaluated by every
+// wave of the launch itself; wave 0 of workgroup 0 also writes the next state (order_commit) into the header's other copy;
 // the one thing left to separate dispatches is turning a finished RECORDING into an order (k_order_count / k_order_scatter, rc_traverse.hip),
 // which the host enqueues only in front of launches that may follow a recording -- one launch in eight of a repeating batch.
 // RECORDING costs: every reporting ray is an atomic whose acknowledgement the wave's next s_waitcnt vmcnt waits for along with its node
@@ -139,9 +146,21 @@ __device__ inline bool rc_claim_chunk(const RcClaim& c, const uint32_t* order, u
 // its launches 2-4 (never the first: a batch that does not come back pays nothing; the reporting threshold needs two rounds to settle) and
 // then when the host's cadence says so (one launch in eight).
 struct OrderDecision {
-    uint32_t sel, fresh, exact, gen, record, valid, life_thr;
+    uint32_t sel, fresh, exact, gen, record, valid, life_thr, paused;
 };
+// A shape whose batches never repeat learns nothing and should pay nothing: after kGiveUpAfter consecutive launches that were not repeats
+// the shape's next kGiveUpFor launches go out in natural order without looking at their rays, then the shape is tried again.  Counted and
+// decided here, on the device (rounds 4-5 had the host do it from a pinned word, which a caller that enqueues ahead of the device sees late).
+constexpr uint32_t kGiveUpAfter = 8, kGiveUpFor = 64;
 __device__ inline OrderDecision order_select(const RcClaim& c, int lane, float r[8]) {
+    const uint32_t* hist = c.hist + c.parity * kHistHeaderWords;
+    const float* samples = c.samples + c.parity * kHistSampleFloats;
+    if (hist[kHistSkipLeft] != 0u) {  // (a header word: the same answer in every wave)
+        OrderDecision o;
+        o.sel = 0u; o.fresh = 1u; o.exact = 0u; o.gen = 0u; o.record = 0u; o.valid = 0u; o.life_thr = 0xFFFFFFFFu; o.paused = 1u;
+        for (int k = 0; k < 8; ++k) r[k] = 0.f;
+        return o;
+    }
     if (c.sample_rays) {
         uint64_t idx = (uint64_t)lane * c.n_sample / (uint64_t)kHistSamples + c.n_sample / (2u * kHistSamples);
         if (idx >= c.n_sample) idx = c.n_sample - 1;
@@ -153,12 +172,11 @@ __device__ inline OrderDecision order_select(const RcClaim& c, int lane, float r
     }
     // (Loading all four slots' samples and header words up front -- one memory round trip instead of two or three -- was measured 0.7 %
     // SLOWER on C3: the launch's first claims wait behind 8 more vector loads per lane of every wave.)
-    const uint32_t* hist = c.hist;
     int best = -1;
     float best_d = 0.02f;  // mean over the samples of |dd|^2 / |d|^2 + |do|^2 / diagonal^2: ~0.1 rad of rotation, or a tenth of the scene of travel
     for (int k = 0; k < kHistSlots; ++k) {
         if (hist[kHistStamp + k] == 0u) continue;
-        const float* sp = c.samples + ((size_t)k * kHistSamples + lane) * 8;
+        const float* sp = samples + ((size_t)k * kHistSamples + lane) * 8;
         const float ox = r[0] - sp[0], oy = r[1] - sp[1], oz = r[2] - sp[2], dx = r[4] - sp[4], dy = r[5] - sp[5], dz = r[6] - sp[6];
         const float na = r[4] * r[4] + r[5] * r[5] + r[6] * r[6], nb = sp[4] * sp[4] + sp[5] * sp[5] + sp[6] * sp[6];
         float d = (dx * dx + dy * dy + dz * dz) / fmaxf(fmaxf(na, nb), 1e-30f) + (ox * ox + oy * oy + oz * oz) * c.inv_l2;
@@ -183,32 +201,57 @@ __device__ inline OrderDecision order_select(const RcClaim& c, int lane, float r
     o.record = ((o.gen >= 2u && o.gen <= 4u) || (c.want_record && o.gen >= 5u)) ? 1u : 0u;
     o.valid = (!o.fresh && hist[kHistHasOrder + o.sel] != 0u) ? 1u : 0u;
     o.life_thr = o.record ? hist[kHistScale + 4u * o.sel + 2u] : 0xFFFFFFFFu;
+    o.paused = 0u;
     return o;
 }
-// The header after the launch (one wave of the last workgroup to finish; `r` = this lane's sample ray of the launch).
+// The header after the launch, written into the OTHER copy by one wave (wave 0 of workgroup 0, at the start of the launch: it has just made
+// the decision, `r` = this lane's sample ray of the launch; nobody reads that copy before the shape's next launch).
 __device__ inline void order_commit(const RcClaim& c, const OrderDecision& o, int lane, const float r[8]) {
-    float* out = c.samples + ((size_t)o.sel * kHistSamples + lane) * 8;  // the slot's samples follow its batch
-    for (int k = 0; k < 8; ++k) out[k] = r[k];
-    if (lane != 0) return;
-    uint32_t* hist = c.hist;
-    const uint32_t clock = hist[kHistClock] + 1u;
-    hist[kHistClock] = clock;
-    hist[kHistStamp + o.sel] = clock;
-    hist[kHistGen + o.sel] = o.gen;
-    uint32_t* scale = hist + kHistScale + 4u * o.sel;  // [0], [1]: (threshold, top) of the slot's latest recording; [2], [3]: of its next one (k_order_scatter)
-    if (o.fresh) { scale[0] = scale[2] = c.init_thr; scale[1] = scale[3] = c.init_thr + 8u; hist[kHistPending + o.sel] = 0u; hist[kHistHasOrder + o.sel] = 0u; }
-    if (o.record) { scale[0] = scale[2]; scale[1] = scale[3]; hist[kHistPending + o.sel] = 1u; }  // the rebuild classes the costs with the scale they were recorded under
-    hist[kHistSel] = o.sel; hist[kHistFresh] = o.fresh; hist[kHistOrderValid] = o.valid; hist[kHistLifeThr] = o.life_thr; hist[kHistRecorded] = o.record;
-    // Tell the host when this shape's batches are not REPEATS of remembered ones -- a path tracer's bounce rays (never matched), but also a
-    // camera that moves every frame: matched, its slot's order reused, and still slower than natural order in round 4, because an order
-    // learned from SIMILAR rays gained less than the mechanism cost (BENCH_r04 c3_moving_camera).  The host then pauses the mechanism.
-    const uint32_t streak = o.exact ? 0u : hist[kHistFreshStreak] + 1u;
-    hist[kHistFreshStreak] = streak;
-    if (c.host_streak) {
+    const uint32_t* old_h = c.hist + c.parity * kHistHeaderWords;
+    uint32_t* new_h = c.hist + (c.parity ^ 1u) * kHistHeaderWords;
+    const float* old_s = c.samples + c.parity * kHistSampleFloats;
+    float* new_s = c.samples + (c.parity ^ 1u) * kHistSampleFloats;
+    // lane i carries header word i from the old copy to the new one, changed on the way where this launch changes it
+    uint32_t w = lane < kHistHeaderWords ? old_h[lane] : 0u;
+    auto put = [&](int idx, uint32_t v) { if (lane == idx) w = v; };
+    for (int k = 0; k < kHistSlots; ++k) {  // the remembered samples: the launch's own in its slot, the others as they were
+        const float4* from = reinterpret_cast<const float4*>(old_s + ((size_t)k * kHistSamples + lane) * 8);
+        float4* to = reinterpret_cast<float4*>(new_s + ((size_t)k * kHistSamples + lane) * 8);
+        const bool mine = !o.paused && (uint32_t)k == o.sel;
+        to[0] = mine ? make_float4(r[0], r[1], r[2], r[3]) : from[0];
+        to[1] = mine ? make_float4(r[4], r[5], r[6], r[7]) : from[1];
+    }
+    if (o.paused) {  // one launch of the pause gone; nothing else moves (the launch clock stands still)
+        const uint32_t left = old_h[kHistSkipLeft] - 1u;
+        put(kHistSkipLeft, left);
+        if (lane < kHistHeaderWords) new_h[lane] = w;
+        if (lane == 0 && c.host_streak) __hip_atomic_store(c.host_streak + 2, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const uint32_t clock = old_h[kHistClock] + 1u;
+    put(kHistClock, clock);
+    put(kHistStamp + (int)o.sel, clock);
+    put(kHistGen + (int)o.sel, o.gen);
+    const int sc = kHistScale + 4 * (int)o.sel;  // [0], [1]: (threshold, top) of the slot's latest recording; [2], [3]: of its next one (k_order_scatter)
+    if (o.fresh) { put(sc, c.init_thr); put(sc + 2, c.init_thr); put(sc + 1, c.init_thr + 8u); put(sc + 3, c.init_thr + 8u); put(kHistPending + (int)o.sel, 0u); put(kHistHasOrder + (int)o.sel, 0u); }
+    else if (o.record) { put(sc, old_h[sc + 2]); put(sc + 1, old_h[sc + 3]); }  // the rebuild classes the costs with the scale they were recorded under
+    if (o.record) put(kHistPending + (int)o.sel, 1u);
+    put(kHistSel, o.sel); put(kHistFresh, o.fresh); put(kHistOrderValid, o.valid); put(kHistLifeThr, o.life_thr); put(kHistRecorded, o.record);
+    // The run of launches that were not REPEATS of a remembered batch -- a path tracer's bounce rays (never matched), a camera that moves
+    // every frame (matched, never identical) -- and the pause it leads to.  The host reads the pinned copies to decide about the rebuild
+    // kernels: [0] the run (a new batch is starting: its launches 2-4 will record), [1] a recording waits, [2] the pause.
+    uint32_t streak = o.exact ? 0u : old_h[kHistFreshStreak] + 1u;
+    uint32_t skip = 0u;
+    if (streak >= kGiveUpAfter) { streak = 0u; skip = kGiveUpFor; }
+    put(kHistFreshStreak, streak);
+    put(kHistSkipLeft, skip);
+    if (lane < kHistHeaderWords) new_h[lane] = w;
+    const bool is_pending = lane >= kHistPending && lane < kHistPending + kHistSlots && w != 0u;
+    const uint32_t any_pending = __ballot(is_pending) ? 1u : 0u;  // ... whether a recording waits for the rebuild kernels
+    if (lane == 0 && c.host_streak) {
         __hip_atomic_store(c.host_streak, streak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        uint32_t any_pending = 0u;  // ... and whether a recording waits for the rebuild kernels
-        for (int k = 0; k < kHistSlots; ++k) any_pending |= hist[kHistPending + k];
         __hip_atomic_store(c.host_streak + 1, any_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(c.host_streak + 2, skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -671,11 +714,12 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, t
         claim_order = __builtin_amdgcn_readfirstlane(od.valid) ? claim_order + (size_t)sel * kHistSlotStride : nullptr;
         life_thr = __builtin_amdgcn_readfirstlane(od.life_thr);  // 0xFFFFFFFF: this launch does not record
         claim_cost = life_thr == 0xFFFFFFFFu ? nullptr : claim_cost + (size_t)sel * kHistSlotStride;
-        if (__builtin_amdgcn_readfirstlane(od.fresh)) {  // the slot's cost array still holds what the evicted batch recorded: nobody reads or records it during a batch's first launch
+        if (__builtin_amdgcn_readfirstlane(od.fresh) && !__builtin_amdgcn_readfirstlane(od.paused)) {  // the slot's cost array still holds what the evicted batch recorded: nobody reads or records it during a batch's first launch
             uint32_t* stale = a.claim.cost + (size_t)sel * kHistSlotStride;
             const uint64_t n_base = (a.n_items + a.claim.pool - 1u) / a.claim.pool;
             for (uint64_t i = gtid; i < n_base; i += av.total_threads) stale[i] = 0u;
         }
+        if (blockIdx.x == 0 && threadIdx.x < 64) order_commit(a.claim, od, lane, smp);  // the header's other copy: read by the shape's next launch
     }
     typename LaneStackP<LDS_N, BLOCK, stack_entry_t>::pos_t sp = st.empty();
     bool live = false;
@@ -966,22 +1010,6 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, t
             atomicAdd(&a.stats[14], st_outer);  // outer iterations (one pass over the phases each)
             for (int k = 0; k < 4; ++k) atomicAdd(&a.stats[15 + k], st_sub[k]);
             atomicAdd(&a.stats[19], st_cull);  // instance entries skipped by the entry cull (counted once per wave-pass: lane 0's copy of the wave total)
-        }
-    }
-    // The history's next state: written once, by the last workgroup of the launch to get here (every other workgroup has read the old one).
-    // (Writing it at the START of the launch instead -- by the last workgroup to have made its decision, which still holds it in registers --
-    // was measured slower: 512 ticket atomics on one address while every wave claims its first chunk, +10 us on a 1 M-ray launch.)
-    if (a.claim.hist) {
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            uint32_t ticket = 0;
-            if (lane == 0) ticket = atomicAdd(a.claim.hist + kHistTicket, 1u);
-            if ((uint32_t)__builtin_amdgcn_readfirstlane(ticket) + 1u == gridDim.x) {
-                float smp[8];
-                const OrderDecision od = order_select(a.claim, lane, smp);
-                order_commit(a.claim, od, lane, smp);
-                if (lane == 0) a.claim.hist[kHistTicket] = 0u;
-            }
         }
     }
 }

@@ -737,7 +737,7 @@ def test_batches_that_never_repeat_stop_paying_for_the_claim_order(rc, oracle):
         hip.hipMemcpy(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(t.get_option("debug_ctl_ptr")), ctypes.c_size_t(160), 3)
         torch.cuda.synchronize()
         h = h.cpu().numpy().view(np.uint32)
-        return int(h[3]), int(h[4]), int(h[36])   # launches seen by k_order_select, fresh, run of unmatched launches
+        return int(h[3]), int(h[4]), int(h[36])   # launches seen by the mechanism, fresh, run of non-repeats
 
     clocks = []
     for k in range(14):
@@ -746,11 +746,11 @@ def test_batches_that_never_repeat_stop_paying_for_the_claim_order(rc, oracle):
         torch.cuda.synchronize()
         assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), want[k % 6], f"launch {k + 1}")
         clocks.append(clock())
-    assert [c[0] for c in clocks[:8]] == list(range(1, 9)) and all(c[1] == 1 for c in clocks[:8]) and clocks[7][2] == 8
-    assert all(c[0] == 8 for c in clocks[8:]), clocks                      # launches 9-14: natural order, no order kernels
+    assert [c[0] for c in clocks[:8]] == list(range(1, 9)) and all(c[1] == 1 for c in clocks[:8]) and clocks[6][2] == 7 and clocks[7][2] == 0   # (the eighth non-repeat starts the pause and the count over)
+    assert all(c[0] == 8 for c in clocks[8:]), clocks                      # launches 9-14: natural order, outside the mechanism
     # after the pause the shape is really tried again.  The 64 skipped launches pass (6 done above), then a batch that REPEATS must
-    # get its order back: matched from its second launch on, an order in use from its third -- the device's own streak counter was zeroed
-    # with the host's, so one unmatched probe launch does not send the shape straight back into the pause.
+    # get its order back: matched from its second launch on, an order in use from its third -- the streak counter starts over with the pause,
+    # so one unmatched probe launch does not send the shape straight back into the pause.
     for k in range(58):
         t.trace_device(dev[k % 6].data_ptr(), out.data_ptr(), n)
     torch.cuda.synchronize()
@@ -766,7 +766,7 @@ def test_batches_that_never_repeat_stop_paying_for_the_claim_order(rc, oracle):
         torch.cuda.synchronize()
         w = h.cpu().numpy().view(np.uint32)
         seen.append((int(w[3]), int(w[1]), int(w[4]), int(w[36])))          # clock, order valid, fresh, streak
-    assert [c[0] for c in seen] == [9, 10, 11, 12, 13], seen               # every one of them went through the order kernels again
+    assert [c[0] for c in seen] == [9, 10, 11, 12, 13], seen               # every one of them was seen by the mechanism again
     assert seen[0][3] == 1 and all(c[2] == 0 and c[3] == 0 for c in seen[1:]), seen   # the first is unmatched (streak restarted at 1, not 9), the rest match
     assert [c[1] for c in seen[2:]] == [1, 1, 1], seen                       # an order from the batch's third launch on
     # a batch that DOES repeat on another shape is unaffected (histories are per shape)
@@ -815,7 +815,27 @@ def test_a_camera_that_moves_every_frame_stops_paying_for_the_claim_order(rc, or
     assert [c[0] for c in seen] == [1, 2, 3, 4] and [c[3] for c in seen] == [1, 0, 0, 0] and seen[3][1] == 1, seen   # repeats: the order is in use, the streak stays at 0
     seen = [frame(eye0 + np.array([0.02 * f, 0.01 * f, 0.0]), f"moving camera, frame {f}") for f in range(1, 13)]
     assert [c[0] for c in seen[:8]] == list(range(5, 13)) and all(c[2] == 1 and c[1] == 0 for c in seen[:8]), seen   # seen by the mechanism: fresh in their slot, natural order
-    assert [c[3] for c in seen[:8]] == list(range(1, 9)), seen                                                        # ... but not repeats
+    assert [c[3] for c in seen[:8]] == list(range(1, 8)) + [0], seen                                                  # ... but not repeats (the eighth starts the pause and the count over)
     assert all(c[0] == 12 for c in seen[8:]), seen                                                                    # frames 9-12: outside the mechanism
     assert t.get_option("claim_drift") == 0
+    t.free()
+    # the same for a caller that never waits: 4 still launches and 20 moving frames enqueued back to back.  The pause is counted and started
+    # on the device (order_commit), so it begins after the eighth moving frame however late the host hears of it
+    t = build_product(rc, cfg)
+    still = sc.pinhole_rays(1280, 800, eye0, centre, 45.0)
+    bufs = [torch.from_numpy(sc.pinhole_rays(1280, 800, eye0 + np.array([0.02 * f, 0.01 * f, 0.0]), centre, 45.0).view(np.uint8).reshape(-1)).cuda() for f in range(1, 21)]
+    d_still = torch.from_numpy(still.view(np.uint8).reshape(-1)).cuda()
+    out = torch.zeros(len(still) * 32, dtype=torch.uint8, device="cuda")
+    for _ in range(4):
+        t.trace_device(d_still.data_ptr(), out.data_ptr(), len(still))
+    for b in bufs:
+        t.trace_device(b.data_ptr(), out.data_ptr(), len(still))
+    torch.cuda.synchronize()
+    h = torch.empty(40, dtype=torch.int32, device="cuda")
+    hip.hipMemcpy(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(t.get_option("debug_ctl_ptr")), ctypes.c_size_t(160), 3)
+    torch.cuda.synchronize()
+    w = h.cpu().numpy().view(np.uint32)
+    assert int(w[3]) == 12 and int(w[38]) == 64 - 12 and int(w[36]) == 0, w[:40]   # launch clock stopped at 4 + 8, 12 launches of the pause gone
+    last = sc.pinhole_rays(1280, 800, eye0 + np.array([0.02 * 20, 0.01 * 20, 0.0]), centre, 45.0)
+    assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), o.trace(last, nthreads=16), "the last of 20 frames enqueued without waiting")
     t.free()

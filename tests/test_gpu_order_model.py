@@ -62,7 +62,6 @@ def test_device_follows_the_model(rc, oracle, name):
     rig = Rig(rc, oracle)
     t = build_product(rc, rig.cfg)
     model = om.History()
-    prev = None
     script = om.scripts()[name]
     for k, (batch, near) in enumerate(script):
         check = k < 24 or k >= len(script) - 8           # (the oracle pass of a long script's middle is skipped: those launches run in natural order anyway)
@@ -74,11 +73,7 @@ def test_device_follows_the_model(rc, oracle, name):
             assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), want, f"{name}: launch {k + 1}")
         expect = model.launch(batch, near)
         got = rig.header(t)
-        if expect is None:   # the header as the launch before left it (the launch that starts a pause zeroes the device's streak word)
-            assert got == dict(prev, streak=model.streak), f"{name}: launch {k + 1} should have gone out without the order kernels\n device {got}\n before {prev}"
-        else:
-            assert got == expect, f"{name}: launch {k + 1}\n device {got}\n model  {expect}"
-        prev = got
+        assert got == expect, f"{name}: launch {k + 1}\n device {got}\n model  {expect}"   # (a launch inside a pause moves nothing but skip_left)
     assert t.get_option("claim_drift") == 0
     t.free()
 
