@@ -104,7 +104,7 @@ class History:
         gen = 1 if fresh else self.gen[sel] + 1
         record = (self.m.record_first <= gen <= self.m.record_last) or (want_record and gen >= 5)
         valid = (not fresh) and self.has_order[sel] != 0
-        # ---- device: order_commit, by the last workgroup of the launch ----
+        # ---- device: order_commit, by one wave of the launch (into the header's other copy) ----
         self.batch[sel] = batch            # the slot's samples follow the batch
         self.clock += 1
         self.stamp[sel] = self.clock
