@@ -258,6 +258,8 @@ struct rc_scene {
     DevBuf<uint32_t> counters;        // kCounterSlots slots of claim counters (self-resetting, rc_claim_chunk), the sticky status word, dev statistics; zeroed at rc_scene_create
     uint64_t launch_seq = 0;          // eager launches so far; slot = launch_seq % kEagerSlots
     int cur_slot = 0;                 // slot of the launch being prepared
+    hipEvent_t bound_t0 = nullptr, bound_t1 = nullptr;  // RcLaunchGuard::bind: the events the launch's kernel is to carry
+    bool bound_used = false;
     struct LaunchSlot {               // per counter slot: the events of its latest launch
         hipEvent_t t0 = nullptr, t1 = nullptr;  // timing pair; t1 also orders the slot's next user when that one runs on another stream
         hipStream_t stream = nullptr;
@@ -392,6 +394,7 @@ struct RcLaunchGuard {
     bool capturing = false;
     RcLaunchGuard(rc_scene* scene, hipStream_t stream);
     void start();
+    void bind();   // the launch's ONE kernel carries the slot's events (hipExtLaunchKernelGGL) instead of event records around it
     void finish();
 };
 void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcClaim& out);  // the RcClaim of the launch being prepared

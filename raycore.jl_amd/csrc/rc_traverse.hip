@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
 #include <hipcub/hipcub.hpp>
 
 #include "rc_traverse_core.h"
@@ -451,11 +452,24 @@ void RcLaunchGuard::start() {
     if (rc_event_mode() < 2) RC_HIP(hipEventRecord(slot.t0, stream));
 }
 
+void RcLaunchGuard::bind() {  // instead of start(): the launch's kernel carries the events itself (launch_variant)
+    if (capturing) return;
+    if (rc_event_mode() >= 2) { start(); return; }  // (dev modes measure the event packets)
+    rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
+    if (!slot.t0) {
+        RC_HIP(hipEventCreateWithFlags(&slot.t0, hipEventDisableSystemFence));
+        RC_HIP(hipEventCreateWithFlags(&slot.t1, hipEventDefault));
+    }
+    s->bound_t0 = slot.t0; s->bound_t1 = slot.t1; s->bound_used = false;
+}
+
 void RcLaunchGuard::finish() {
     RC_HIP(hipGetLastError());
+    const bool bound = s->bound_used;
+    s->bound_t0 = s->bound_t1 = nullptr; s->bound_used = false;
     if (capturing) return;  // a captured launch has no events of its own: the graph orders it, and its duration is the replay's business
     rc_scene::LaunchSlot& slot = s->slots[s->cur_slot];
-    if (rc_event_mode() < 3) RC_HIP(hipEventRecord(slot.t1, stream));
+    if (rc_event_mode() < 3 && !bound) RC_HIP(hipEventRecord(slot.t1, stream));
     // the per-stream resources this launch used are busy until here (asked by the next stream that wants to take one over)
     const bool closed = rc_event_mode() < 3;  // (they follow the launch's closing event instead of recording their own)
     auto mark = [&](RcEvent& last) { if (closed) last.follow(slot.t1); else last.record(stream); };
@@ -599,15 +613,19 @@ template <bool ANY>
 static void launch_variant(rc_scene* s, int64_t kernel, const TraceArgs& a, uint32_t blocks, hipStream_t stream) {
     const int64_t lds = s->opt.lds_stack;
     const bool stats = s->opt.stats != 0;
-#define RC_LAUNCH_P(L, W) hipLaunchKernelGGL((k_trace_persistent<ANY, L, W, false>), dim3(blocks), dim3(kBlock), 0, stream, a)
-#define RC_LAUNCH_S(L, W) hipLaunchKernelGGL((k_trace_simple<ANY, L, W>), dim3(blocks), dim3(kBlock), 0, stream, a)
+    // The launch's timing / ordering events ride on the kernel's own dispatch (hipExtLaunchKernelGGL binds them to its start and end): no
+    // event packets of their own around the kernel -- they cost ~3 us each between two back-to-back launches.  (Null outside RcLaunchGuard::bind.)
+    hipEvent_t e0 = s->bound_t0, e1 = s->bound_t1;
+    s->bound_used = e0 != nullptr;
+#define RC_LAUNCH_P(L, W) hipExtLaunchKernelGGL((k_trace_persistent<ANY, L, W, false>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a)
+#define RC_LAUNCH_S(L, W) hipExtLaunchKernelGGL((k_trace_simple<ANY, L, W>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a)
     if (kernel == 4) {
         bool& attr_set = s->lds_attr_set[ANY ? 1 : 0];  // per scene = per device: the attribute belongs to the function on one device
         if (!attr_set) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kBigBlock, kLdsStack, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_trace_phased_lds<ANY, kBigBlock, kLdsStack, 4>), dim3(blocks), dim3(kBigBlock), kBigLdsBytes, stream, a);
+        hipExtLaunchKernelGGL((k_trace_phased_lds<ANY, kBigBlock, kLdsStack, 4>), dim3(blocks), dim3(kBigBlock), kBigLdsBytes, stream, e0, e1, 0u, a);
     } else if (kernel == 5) {
         bool& attr_set = s->lds_attr_set[2 + (ANY ? 1 : 0)];
         if (!attr_set) {
@@ -616,51 +634,51 @@ static void launch_variant(rc_scene* s, int64_t kernel, const TraceArgs& a, uint
         }
         if (stats && rc_stack16(s)) {  // dev: the same kernel with per-phase pass / lane counters (option "stats"; tools/isa_mix.py weights the phases' static opcode histograms with them)
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes16));
-            hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes16, stream, a);
+            hipExtLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes16, stream, e0, e1, 0u, a);
         } else if (stats) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
-            hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
+            hipExtLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, e0, e1, 0u, a);
         } else if (a.timeline) {  // dev: the same kernel with per-wave event times written to the caller's buffer (option "timeline_ptr")
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes));
-            hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
+            hipExtLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, e0, e1, 0u, a);
         } else if (rc_stack16(s)) {
             bool& set16 = s->lds_attr_set[12 + (ANY ? 1 : 0)];
             if (!set16) {
                 RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMidLdsBytes16));
                 set16 = true;
             }
-            hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, false, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes16, stream, a);
+            hipExtLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6, false, false, true>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes16, stream, e0, e1, 0u, a);
         } else
-        hipLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, a);
+        hipExtLaunchKernelGGL((k_trace_phased_lds<ANY, kMidBlock, kMidStack, 6>), dim3(blocks), dim3(kMidBlock), kMidLdsBytes, stream, e0, e1, 0u, a);
     } else if (kernel == 6 && rc_stack16(s)) {
         bool& attr_set = s->lds_attr_set[14 + (ANY ? 1 : 0)];
         if (!attr_set) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_partial<ANY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartialLdsBytes16));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_trace_phased_partial<ANY, true>), dim3(blocks), dim3(kMidBlock), kPartialLdsBytes16, stream, a);
+        hipExtLaunchKernelGGL((k_trace_phased_partial<ANY, true>), dim3(blocks), dim3(kMidBlock), kPartialLdsBytes16, stream, e0, e1, 0u, a);
     } else if (kernel == 6) {
         bool& attr_set = s->lds_attr_set[6 + (ANY ? 1 : 0)];
         if (!attr_set) {
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_phased_partial<ANY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartialLdsBytes));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_trace_phased_partial<ANY>), dim3(blocks), dim3(kMidBlock), kPartialLdsBytes, stream, a);
+        hipExtLaunchKernelGGL((k_trace_phased_partial<ANY>), dim3(blocks), dim3(kMidBlock), kPartialLdsBytes, stream, e0, e1, 0u, a);
     } else if (kernel == 3) {
-        if (stats) hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        else if (lds == 16) hipLaunchKernelGGL((k_trace_phased<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        else if (lds == 20) hipLaunchKernelGGL((k_trace_phased<ANY, 20, 7, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        else if (lds == 17) hipLaunchKernelGGL((k_trace_phased<ANY, 16, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        else if (lds == 13) hipLaunchKernelGGL((k_trace_phased<ANY, 12, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        else hipLaunchKernelGGL((k_trace_phased<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        if (stats) hipExtLaunchKernelGGL((k_trace_phased<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
+        else if (lds == 16) hipExtLaunchKernelGGL((k_trace_phased<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
+        else if (lds == 20) hipExtLaunchKernelGGL((k_trace_phased<ANY, 20, 7, false>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
+        else if (lds == 17) hipExtLaunchKernelGGL((k_trace_phased<ANY, 16, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
+        else if (lds == 13) hipExtLaunchKernelGGL((k_trace_phased<ANY, 12, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
+        else hipExtLaunchKernelGGL((k_trace_phased<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
     } else if (kernel == 2) {
-        if (stats) hipLaunchKernelGGL((k_trace_sched<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        else if (lds == 16) hipLaunchKernelGGL((k_trace_sched<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
-        else hipLaunchKernelGGL((k_trace_sched<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        if (stats) hipExtLaunchKernelGGL((k_trace_sched<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
+        else if (lds == 16) hipExtLaunchKernelGGL((k_trace_sched<ANY, 16, 8, false>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
+        else hipExtLaunchKernelGGL((k_trace_sched<ANY, 24, 6, false>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
     } else if (kernel == 0) {
         if (lds == 12) RC_LAUNCH_S(12, 8); else if (lds == 16) RC_LAUNCH_S(16, 8); else if (lds == 32) RC_LAUNCH_S(32, 4); else RC_LAUNCH_S(24, 6);
     } else if (stats) {
-        hipLaunchKernelGGL((k_trace_persistent<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+        hipExtLaunchKernelGGL((k_trace_persistent<ANY, 24, 6, true>), dim3(blocks), dim3(kBlock), 0, stream, e0, e1, 0u, a);
     } else {
         if (lds == 12) RC_LAUNCH_P(12, 8); else if (lds == 16) RC_LAUNCH_P(16, 8); else if (lds == 32) RC_LAUNCH_P(32, 4); else RC_LAUNCH_P(24, 6);
     }
@@ -941,8 +959,8 @@ void rc_launch_trace(rc_scene* s, const RcRay* d_rays, RcHit* d_hits, uint64_t n
     if (kernel == 6) {  // a plan made for the full-LDS kernels (<= 256 instances) has no TLAS renumbering: tlas_k = 0, its blas_k still fits
         a.tlas_k = wide ? s->tlas_top_k : s->tlas_top_k32; a.blas_k = s->opt.blas_top ? (wide ? s->blas_top_k : s->blas_top_k32) : 0; a.lds_blas_base = a.tlas_k;
     }
-    launch.start();
-    if (learn_order && (kernel == 3 || kernel == 5 || kernel == 6) && !launch.capturing) rc_cost_order_setup(s, n, any_hit, stream, a.claim, d_rays);  // (inside the timed region: the order kernel is part of the launch's cost)
+    launch.bind();
+    if (learn_order && (kernel == 3 || kernel == 5 || kernel == 6) && !launch.capturing) rc_cost_order_setup(s, n, any_hit, stream, a.claim, d_rays);  // (the rebuild pair, when there is one, runs in front of the timed kernel)
     if (any_hit) launch_variant<true>(s, kernel, a, blocks, stream); else launch_variant<false>(s, kernel, a, blocks, stream);
     launch.finish();
 }
