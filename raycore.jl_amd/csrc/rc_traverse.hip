@@ -701,7 +701,7 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
 //     the RECORDING launch worked with, longest first; then the chunks nobody reported; chunk ids ascending inside a class (a stable
 //     counting sort: k_order_count tallies the classes per 1024-chunk block, k_order_scatter places every chunk into the slot's order array,
 //     clears its cost for the slot's next recording and -- block 0 -- leaves the threshold and the scale of that next recording: the
-//     threshold moves so that roughly 10-40 % of the chunks report).
+//     threshold moves so that roughly 30-70 % of the chunks report).
 //   The host enqueues the pair only in front of launches that MAY follow a recording (rc_cost_order_setup): the shape's first launches, the
 //   launches after a batch that was not a repeat was reported, and the launch after one the host's cadence asked to record -- one launch in
 //   eight of a repeating batch.  A recording the host misses (it learns of new batches through a pinned word, late when the caller enqueues
@@ -711,8 +711,21 @@ uint32_t rc_blocks_per_cu(rc_scene* s) {
 //   (A first-launch PREDICTOR -- claim order from the number of top-of-tree boxes each chunk's middle ray passes -- was built and measured in
 //   round 4: worth 5-12 % of a 1 M-ray launch, and the small kernels it needs cost as much: profiles/r04_first_launch_predictor.txt.  Not kept.)
 // hist[kHistScale + 4 slot]: [0], [1] = the threshold / the top of the scale the slot's latest recording launch worked with; [2], [3] = the pair its next one will.
+// dev knobs (tools/probes/build_variants.sh): the number of cost classes of the rebuilt order and the share of the chunks the reporting
+// threshold aims at.  Round 5 (tools/probes/order_quality_probe.py, docs/EXPERIMENTS.md): 10 / 16 / 26 / 31 classes order equally well; the
+// share matters -- with 30-70 % of the chunks reporting (rounds 3-4: 10-40 %) the same batches run 3-8 % faster, because the chunks below
+// the threshold are claimed in natural order BEHIND the reported ones and most of a batch's medium-long chunks were among them.
+#ifndef RC_ORDER_CLASSES
+#define RC_ORDER_CLASSES 10
+#endif
+#ifndef RC_ORDER_RAISE_PCT
+#define RC_ORDER_RAISE_PCT 70
+#define RC_ORDER_LOWER_PCT 30
+#endif
 namespace {
-constexpr int kOrderThreads = 256, kOrderPerThread = 4, kOrderTile = kOrderThreads * kOrderPerThread, kOrderClasses = 10, kOrderMaxBlocks = 256;
+constexpr int kOrderThreads = 256, kOrderPerThread = 4, kOrderTile = kOrderThreads * kOrderPerThread, kOrderClasses = RC_ORDER_CLASSES, kOrderMaxBlocks = 256;
+constexpr int kOrderPacked = (kOrderClasses + 4) / 5;  // u64 words of 12-bit per-class counters (k_order_scatter)
+static_assert(kOrderClasses + 1 <= 32, "k_order_scatter sums the blocks' counts with 32 threads per block group");
 static_assert(rc_scene::ChunkHistory::kHeaderWords == (uint32_t)kHistHeaderWords, "rc_internal.h repeats the size of a header copy");
 static_assert((uint32_t)(kOrderTile * kOrderMaxBlocks) == kHistSlotStride, "a slot's cost array holds the most chunks the rebuild kernels handle");
 constexpr int kOrderCountWords = kOrderClasses + 1;  // per block: the classes' chunk counts, the largest cost
@@ -721,7 +734,7 @@ constexpr size_t kHistWords = kHistCounts + (size_t)kHistSlots * kOrderMaxBlocks
 __device__ inline int order_class(uint32_t c, uint32_t thr, uint32_t top) {
     if (c == 0u) return kOrderClasses - 1;
     const uint32_t span = top > thr ? top - thr + 1u : 1u, above = c > thr ? c - thr : 0u;
-    const uint32_t q = above * (uint32_t)(kOrderClasses - 1) / span;  // 0 .. 8 (and beyond when this launch's rays outlived the scale)
+    const uint32_t q = above * (uint32_t)(kOrderClasses - 1) / span;  // 0 .. kOrderClasses - 2 (and beyond when this launch's rays outlived the scale)
     return q >= (uint32_t)(kOrderClasses - 1) ? 0 : (int)(kOrderClasses - 2) - (int)q;
 }
 __device__ inline uint32_t* order_counts(uint32_t* hist, int slot) { return hist + kHistCounts + (size_t)slot * kOrderMaxBlocks * kOrderCountWords; }
@@ -759,12 +772,12 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
         if (threadIdx.x < kOrderCountWords) { total[threadIdx.x] = 0u; if (threadIdx.x < kOrderClasses) before[threadIdx.x] = 0u; }
         __syncthreads();
         const uint32_t* counts = order_counts(ctl, slot);
-        {   // thread (word w, group g) sums word w of the blocks g, g + 16, ... in registers, then one LDS atomic per thread.  (One thread per
+        {   // thread (word w, group g) sums word w of the blocks g, g + 8, ... in registers, then one LDS atomic per thread.  (One thread per
             // BLOCK with an LDS atomic per word put 32 lanes on the same LDS address twenty times over: 17 of this kernel's 22 us.)
-            const uint32_t w = threadIdx.x & 15u, g = threadIdx.x >> 4;
+            const uint32_t w = threadIdx.x & 31u, g = threadIdx.x >> 5;
             if (w < (uint32_t)kOrderCountWords) {
                 uint32_t all = 0u, mine = 0u;
-                for (uint32_t b = g; b < gridDim.x; b += kOrderThreads / 16) {
+                for (uint32_t b = g; b < gridDim.x; b += kOrderThreads / 32) {
                     const uint32_t c = counts[b * kOrderCountWords + w];
                     if (w == (uint32_t)kOrderClasses) all = c > all ? c : all;
                     else { all += c; mine += b < blockIdx.x ? c : 0u; }
@@ -777,15 +790,20 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
         if (threadIdx.x == 0) { unreported_of[slot] = total[kOrderClasses - 1]; longest_of[slot] = total[kOrderClasses]; }
         const uint32_t thr = hist[kHistScale + 4 * slot], top = hist[kHistScale + 4 * slot + 1];
         int cls[kOrderPerThread];
-        unsigned long long packed[2] = {0ull, 0ull};  // this thread's chunks per class, 12 bits each, five classes per word
+        unsigned long long packed[kOrderPacked];  // this thread's chunks per class, 12 bits each, five classes per word
+#pragma unroll
+        for (int q = 0; q < kOrderPacked; ++q) packed[q] = 0ull;
         for (int j = 0; j < kOrderPerThread; ++j) {
             cls[j] = first + j < n_chunks ? order_class(cost[first + j], thr, top) : -1;
-            if (cls[j] >= 0) packed[cls[j] / 5] += 1ull << (12 * (cls[j] % 5));
+#pragma unroll
+            for (int q = 0; q < kOrderPacked; ++q) packed[q] += (cls[j] >= 0 && cls[j] / 5 == q) ? 1ull << (12 * (cls[j] % 5)) : 0ull;
         }
-        unsigned long long prefix[2];
-        Scan(scan_tmp).ExclusiveSum(packed[0], prefix[0]);
-        __syncthreads();
-        Scan(scan_tmp).ExclusiveSum(packed[1], prefix[1]);
+        unsigned long long prefix[kOrderPacked];
+#pragma unroll
+        for (int q = 0; q < kOrderPacked; ++q) {
+            if (q) __syncthreads();
+            Scan(scan_tmp).ExclusiveSum(packed[q], prefix[q]);
+        }
         uint32_t pos[kOrderClasses], acc = 0;
         for (int k = 0; k < kOrderClasses; ++k) { pos[k] = acc + before[k] + (uint32_t)((prefix[k / 5] >> (12 * (k % 5))) & 0xFFFull); acc += total[k]; }
 #pragma unroll
@@ -814,8 +832,8 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_scatter(uint32_t* cost_
         uint32_t* scale = hist + kHistScale + 4 * slot;  // the scale of the slot's NEXT recording launch
         const uint32_t thr = scale[0], reported = n_chunks - unreported;
         uint32_t next = thr;
-        if (reported * 5u > n_chunks * 2u) next += (next >> 2) + 1u;        // more than 40 % of the chunks reported: raise the bar
-        else if (reported * 10u < n_chunks && next > 2u) next -= next >> 2;  // fewer than 10 %: lower it
+        if (reported * 100ull > (unsigned long long)n_chunks * RC_ORDER_RAISE_PCT) next += (next >> 2) + 1u;        // more than this share of the chunks reported: raise the bar
+        else if (reported * 100ull < (unsigned long long)n_chunks * RC_ORDER_LOWER_PCT && next > 2u) next -= next >> 2;  // fewer than this: lower it
         scale[2] = next;
         scale[3] = mx > next ? mx : next + 8u;  // the longest lifetime just seen scales the next recording's classes
         hist[kHistPending + slot] = 0u;
