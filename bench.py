@@ -99,7 +99,7 @@ def make_roofline(launch_ms, n_rays, node_f, inst_f, counts_source, pmc, kernel_
                                       "SQ_INSTS_VALU -8.7 %, launch time unchanged).  Right behind it: the texture-data path, busy `td_busy_frac` of the launch with the four fetch instructions of every node visit (~22 cycles each "
                                       "whatever the exec mask) -- a shorter chain could buy at most 1 / td_busy_frac.  `frac` stays the VALU-issue figure of earlier rounds for continuity; it is not the binding roof.",
                     "sources": {"valu_wave_instructions_per_launch, lane_utilisation, traffic": COUNTER_FILE + " (rocprofv3 --pmc passes over this bench command, tools/capture_profiles.sh; its fingerprint matches the kernel sources of this run; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md: the traffic is the coalesced ray / hit stream)",
-                                "avg_launch_ms": "HIP events around every timed launch, this run",
+                                "avg_launch_ms": "the HIP events every timed launch carries on its own kernel dispatch (start / end of the kernel on the launch stream), read back after the timed region: rc_recent_kernel_ms, this run",
                                 "peak": "MI355X_MICROARCH.md execution model: a wave64 VALU instruction issues over 2 cycles on the SIMD-32: 256 CUs x 4 SIMDs x 2.4 GHz / 2",
                                 "node / instance counts": counts_source}}
         m = (mix or {}).get("mix")
@@ -285,18 +285,31 @@ def main():
         torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # Every launch carries its own two HIP events on its kernel's dispatch (hipExtLaunchKernelGGL binds them to the kernel's start and end on
+    # the launch stream): the K durations are read back after the timed region (rc_recent_kernel_ms keeps the last 47 launches').  More steps
+    # than that: torch events around every step, as in rounds 1-4 -- two event packets per step, ~6 us, inside the timed region.
+    own_events = args.steps <= 47
+    ev = [] if own_events else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     rc.lib().rc_range_push(b"headline:timed_steps")
-    for a, b in ev:
-        a.record(stream)
-        step()
-        b.record(stream)
+    if own_events:
+        for _ in range(args.steps):
+            step()
+    else:
+        for a, b in ev:
+            a.record(stream)
+            step()
+            b.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
     rc.lib().rc_range_pop()
-    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if own_events:
+        per_step = t.recent_kernel_ms(args.steps)
+        assert len(per_step) == args.steps and all(x > 0 for x in per_step), per_step
+        launch_ms = float(np.mean(per_step))
+    else:
+        launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -326,6 +339,9 @@ def main():
         rooflines = {}
         last_ms = {}
 
+        # launches of a batch before its steady state is measured: the reporting threshold of the learned claim order moves by a quarter per recording
+        # (launches 2-4, then one in eight) and has settled after ~30 launches (profiles/r05_order_quality.txt); a render loop runs for hundreds
+        STEADY, STEADY_HBM = 36, 12
         def timed(scene, rs, mode, reps=3, key=None, label=None):
             """Rate of the batch repeated on one stream.  reps <= 5: best launch by its own events (cost_order off, or one-off measurements).
             More: the batch's steady state, measured like the headline's steps -- 16 launches back to back between two events on the stream,
@@ -442,12 +458,12 @@ def main():
                                               "within noise; the first eight frames -- not in the figure -- pay ~2 %"}
         del dh_off, frames
         shadow = sc.c3_shadow_rays(cfg, rays, hits)
-        extras["c3_any_hit_shadow_mrays_s"] = timed(t, shadow, "any", reps=12, key="shadow")
+        extras["c3_any_hit_shadow_mrays_s"] = timed(t, shadow, "any", reps=STEADY, key="shadow")
         t.set_option("cost_order", 0)
         extras["c3_any_hit_shadow_first_launch_mrays_s"] = timed(t, shadow, "any", reps=5, label="shadow_first_launch")
         t.set_option("cost_order", 1)
         bounce = sc.c4_bounce_rays(cfg, rays, hits, 4 * n)
-        extras["c4_incoherent_16M_closest_mrays_s"] = timed(t, bounce, "closest", reps=12, key="c4")
+        extras["c4_incoherent_16M_closest_mrays_s"] = timed(t, bounce, "closest", reps=STEADY, key="c4")
         del bounce, shadow
         # A path tracer's bounce rays are NEW every launch: six different 4.19 M-ray incoherent batches in rotation, three rounds.  No batch
         # comes back before its slot has been given away, so nothing is ever learned -- and nothing must be paid for trying: a batch seen for
@@ -481,7 +497,7 @@ def main():
         extras["c4_never_repeating_batches"] = nr
         del fresh, dh_f
         mid = sc.c3_primary_rays(cfg, 1024, 1024)
-        extras["c3_1Mi_primary_closest_mrays_s"] = timed(t, mid, "closest", reps=12, key="c3")
+        extras["c3_1Mi_primary_closest_mrays_s"] = timed(t, mid, "closest", reps=STEADY, key="c3")
         cfg2 = sc.config_c2()
         t2 = rc.TLAS(local_rank)
         t2.add_geometry(*cfg2["blas"][0])
@@ -494,7 +510,7 @@ def main():
         t2.set_option("cost_order", 0)
         extras["c2_100k_blas_1M_coherent_closest_first_launch_mrays_s"] = timed(t2, rays2, "closest", reps=5, label="c2_first_launch")
         t2.set_option("cost_order", 1)
-        extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(t2, rays2, "closest", reps=12, key="c2")
+        extras["c2_100k_blas_1M_coherent_closest_mrays_s"] = timed(t2, rays2, "closest", reps=STEADY, key="c2")
         extras["c2_100k_blas_1M_coherent_closest_4_in_flight_mrays_s"] = in_flight(t2, rays2)
         # VERDICT r3 #5a: consecutive same-size batches that DIFFER -- two view directions alternating on one stream.  The device tells the
         # batches apart by their sample rays and keeps an order for each; with the option off both run in natural order.
@@ -527,7 +543,7 @@ def main():
                 tb.push_instances(b, xf, ids)
             tb.sync()
             big[str(int(np.prod(lattice)))] = {"triangles": tb.n_primitives() * tb.n_instances(),
-                                               "mrays_s": timed(tb, sc.c3_primary_rays(cfgb, args.res, args.res), "closest", reps=12, label=f"c3_{int(np.prod(lattice))}_instances"),
+                                               "mrays_s": timed(tb, sc.c3_primary_rays(cfgb, args.res, args.res), "closest", reps=STEADY, label=f"c3_{int(np.prod(lattice))}_instances"),
                                                "tlas_top_k": tb.get_option("tlas_top_k"), "blas_top_k": tb.get_option("blas_top_k")}
             tb.free()
         extras["c3_blas_more_instances_closest"] = big
@@ -546,7 +562,7 @@ def main():
             tb.set_option("cost_order", 0)
             first = timed(tb, rg, "closest", reps=3, label=f"random_{nt}_first_launch")
             tb.set_option("cost_order", 1)
-            rate = timed(tb, rg, "closest", reps=12, key="r1m" if nt == 1_000_000 else None, label=f"random_{nt}")
+            rate = timed(tb, rg, "closest", reps=STEADY, key="r1m" if nt == 1_000_000 else None, label=f"random_{nt}")
             ref[str(nt)] = {"mrays_s": rate, "first_launch_mrays_s": first, "ms_per_1M_rays": round(1e3 / rate, 3), "mrays_s_4_in_flight": in_flight(tb, rg), "reference_rx7900xtx_ms": ref_ms}
             tb.free()
         extras["random_geometry_1M_rays_closest"] = ref
@@ -565,7 +581,7 @@ def main():
         tb.push_instances(1)
         tb.sync()
         del dv
-        rate = timed(tb, inc, "closest", reps=12, label="hbm_regime_4M_tris", key="hbm")
+        rate = timed(tb, inc, "closest", reps=STEADY_HBM, label="hbm_regime_4M_tris", key="hbm")
         hbm_launch_ms = last_ms["hbm"]["mean_of_last_8_ms"]
         tb.set_option("kernel", 3); tb.set_option("stats", 1)
         timed(tb, inc, "closest", reps=1, label="hbm_regime_4M_tris_stats_kernel3")

@@ -438,6 +438,11 @@ int rc_host_unregister(rc_scene* scene, void* ptr);
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
  * stream (kernel only, no copies), in milliseconds. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);
+/* The same for the scene's most recent eager launches on any stream, oldest first: up to max_launches (at most 47: a launch's events live until
+ * the scene's 48th launch after it) durations into ms[], their number into *n.  Waits for the launches asked about.  For a caller that
+ * enqueues a run of launches back to back and wants every one's duration afterwards without putting events of its own between them (the
+ * reference times its kernels the same way, one by one: docs/src/hw_acceleration.md:198-218).  Captured launches have no events: 0. */
+int rc_recent_kernel_ms(rc_scene* scene, uint32_t max_launches, float* ms, uint32_t* n);
 
 #ifdef __cplusplus
 }

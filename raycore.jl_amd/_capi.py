@@ -112,6 +112,7 @@ SYMBOLS = [
     ("rc_host_register", _int, [_vp, _vp, _u64]),
     ("rc_host_unregister", _int, [_vp, _vp]),
     ("rc_last_kernel_ms", _int, [_vp, _pf]),
+    ("rc_recent_kernel_ms", _int, [_vp, _u32, _pf, _pu32]),
 ]
 
 _lib = None

@@ -414,6 +414,14 @@ class TLAS:
         check(lib().rc_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def recent_kernel_ms(self, max_launches=47):
+        """Durations (ms, oldest first) of the scene's most recent eager launches, from the events the launches carried themselves
+        (rc_recent_kernel_ms): for timing a run of back-to-back launches without events between them."""
+        out = (C.c_float * int(max_launches))()
+        n = C.c_uint32(0)
+        check(lib().rc_recent_kernel_ms(self._h, int(max_launches), out, C.byref(n)))
+        return [float(out[i]) for i in range(n.value)]
+
     def host_register(self, array):
         """Page-lock a numpy array (rays, a reused `out=` hit array, triangle soup, a view-factor matrix) so the host-buffer calls move
         it by DMA at the full PCIe rate; undo with host_unregister.  The accel keeps a reference to the array while it is registered (an

@@ -1446,4 +1446,27 @@ int rc_last_kernel_ms(rc_scene* s, float* ms) {
     });
 }
 
+int rc_recent_kernel_ms(rc_scene* s, uint32_t max_launches, float* ms, uint32_t* n_out) {
+    if (!s || !ms || !n_out) return fail(RC_ERR_INVALID_ARGUMENT, "NULL argument");
+    return guarded([&] {
+        use_device(s);
+        *n_out = 0;
+        std::lock_guard<std::mutex> g(s->launch_mu);
+        // the events of a launch stay in its counter slot until the slot's next launch (kEagerSlots launches later): waits for each launch asked about
+        const uint64_t have = s->launch_seq < (uint64_t)(kEagerSlots - 1) ? s->launch_seq : (uint64_t)(kEagerSlots - 1);
+        const uint64_t n = (uint64_t)max_launches < have ? (uint64_t)max_launches : have;
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t launch = s->launch_seq - n + 1 + i;  // (launch numbers start at 1)
+            const rc_scene::LaunchSlot& slot = s->slots[launch % (uint64_t)kEagerSlots];
+            float t = 0.f;
+            if (slot.recorded && slot.t0 && slot.t1) {
+                RC_HIP(hipEventSynchronize(slot.t1));
+                if (hipEventElapsedTime(&t, slot.t0, slot.t1) != hipSuccess) { (void)hipGetLastError(); t = 0.f; }
+            }
+            ms[i] = t;
+        }
+        *n_out = (uint32_t)n;
+    });
+}
+
 }  // extern "C"

@@ -542,6 +542,11 @@ end
 function last_kernel_ms(t::MI355XTLAS)
     ms = Ref{Cfloat}(0); check(ccall((:rc_last_kernel_ms, LIB), Cint, (Ptr{Cvoid}, Ref{Cfloat}), t.ptr, ms)); ms[]
 end
+"Durations (ms, oldest first) of the scene's most recent launches, from the events the launches carried themselves."
+function recent_kernel_ms(t::MI355XTLAS, max_launches::Integer=47)
+    ms = Vector{Cfloat}(undef, max_launches); n = Ref{UInt32}(0)
+    check(ccall((:rc_recent_kernel_ms, LIB), Cint, (Ptr{Cvoid}, UInt32, Ptr{Cfloat}, Ref{UInt32}), t.ptr, UInt32(max_launches), ms, n)); ms[1:n[]]
+end
 device_count() = Int(ccall((:rc_device_count, LIB), Cint, ()))
 "Page-lock a host array that is traced again and again (`Vector{RTRay}`, a reused `Vector{RTHitResult}`): DMA at the full PCIe rate."
 host_register!(t::MI355XTLAS, a::Array) = (check(ccall((:rc_host_register, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64), t.ptr, a, sizeof(a))); a)

@@ -126,3 +126,32 @@ def test_each_thread_reads_its_own_launch_time(rc, scene):
     th.join()
     assert result["big"] > 1.5 * ms_small   # ~0.9 ms against ~0.1 ms; the margin only has to tell the two launches apart
     assert abs(t.last_kernel_ms() - ms_small) < 1e-6  # this thread's own launch, still
+
+
+@pytest.mark.gpu
+def test_recent_kernel_ms_reports_every_launch_of_a_back_to_back_run(rc, oracle):
+    """rc_recent_kernel_ms: the durations of a run of launches enqueued without waiting, from the events each launch carried on its own kernel
+    dispatch; they agree with a bracket of HIP events around the whole run (kernels back to back: sum of durations <= bracket)."""
+    import torch
+    sc = rc.scenes
+    cfg = sc.config_c3(lattice=(4, 4, 2))
+    t = build_product(rc, cfg)
+    rays = sc.pinhole_rays(1280, 800, cfg["eye"], cfg["lattice_centre"], 45.0)
+    d = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+    out = torch.zeros(len(rays) * 32, dtype=torch.uint8, device="cuda")
+    for _ in range(6):
+        t.trace_device(d.data_ptr(), out.data_ptr(), len(rays))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        t.trace_device(d.data_ptr(), out.data_ptr(), len(rays), stream=torch.cuda.current_stream().cuda_stream)
+    e1.record()
+    e1.synchronize()
+    ms = t.recent_kernel_ms(20)
+    assert len(ms) == 20 and all(0.01 < x < 50.0 for x in ms), ms
+    assert abs(ms[-1] - t.last_kernel_ms()) < 1e-6
+    bracket = e0.elapsed_time(e1)
+    assert 0.7 * bracket < sum(ms) <= bracket * 1.001, (sum(ms), bracket)
+    assert len(t.recent_kernel_ms(47)) == 26 and t.recent_kernel_ms(0) == []
+    t.free()
