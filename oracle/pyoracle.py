@@ -11,7 +11,12 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librc_oracle.so")
+# RC_ORACLE_VARIANT=asan|tsan: the sanitized builds (oracle/Makefile `san` / `tsan`), for tests/test_oracle_sanitized.py only -- the
+# interpreter must have been started with the matching sanitizer runtime in LD_PRELOAD.
+_VARIANT = os.environ.get("RC_ORACLE_VARIANT", "")
+assert _VARIANT in ("", "asan", "tsan"), _VARIANT
+_SO = os.path.join(_HERE, "librc_oracle%s.so" % ("_" + _VARIANT if _VARIANT else ""))
+_TARGET = {"": "all", "asan": "san", "tsan": "tsan"}[_VARIANT]
 
 NODE_DT = np.dtype([("aabb0_min", "<f4", 3), ("aabb0_max", "<f4", 3), ("aabb1_min", "<f4", 3),
                     ("aabb1_max", "<f4", 3), ("child0", "<u4"), ("child1", "<u4"), ("parent", "<u4")])
@@ -39,7 +44,7 @@ def build(force=False):
     """Compile the oracle with its committed recipe (oracle/Makefile)."""
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(
             os.path.getmtime(os.path.join(_HERE, f)) for f in ("rc_oracle.c", "rc_oracle.h")):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", _TARGET])
     return _SO
 
 

@@ -587,7 +587,11 @@ static inline void intersect_internal_node(const rco_node* node, v3 inv_d, v3 ra
 static uint32_t* g_hist_tlas = NULL;
 static uint32_t* g_hist_blas = NULL;
 void rco_set_histograms(uint32_t* tlas, uint32_t* blas) { g_hist_tlas = tlas; g_hist_blas = blas; }
-static int32_t g_max_sp = 0;  /* dev: deepest stack seen (single-threaded use) */
+static int32_t g_max_sp = 0;  /* dev: deepest stack seen (a maximum kept with relaxed atomics: the pool's threads all report into it) */
+static inline void note_sp(int32_t sp) {
+    int32_t cur = __atomic_load_n(&g_max_sp, __ATOMIC_RELAXED);
+    while (sp > cur && !__atomic_compare_exchange_n(&g_max_sp, &cur, sp, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
 /* dev: per-step event trace of one ray (tools/sched_sim.py replays these through wave-scheduling policies).  One byte per loop
  * iteration: low 3 bits = kind (0 TLAS interior, 1 BLAS interior, 2 instance entry, 3 leaf miss, 4 leaf hit), 0x20 = pushed the far
  * child, 0x40 = popped (no near child / after a leaf), 0x80 = that pop returned to the top level (sentinel); a second byte array
@@ -608,7 +612,7 @@ static __thread rco_entry_rec* tl_ent = NULL;
 static __thread uint32_t tl_ent_cap = 0, tl_ent_n = 0;
 #define ENT_BEGIN(i, t) do { if (tl_ent) { if (tl_ent_n < tl_ent_cap) { tl_ent[tl_ent_n].inst = (uint32_t)(i); tl_ent[tl_ent_n].closest_at_entry = (t); tl_ent[tl_ent_n].leaf_tests = 0; } ++tl_ent_n; } } while (0)
 #define ENT_LEAF() do { if (tl_ent && tl_ent_n > 0 && tl_ent_n <= tl_ent_cap) tl_ent[tl_ent_n - 1].leaf_tests += 1; } while (0)
-int32_t rco_max_stack(int reset) { int32_t v = g_max_sp; if (reset) g_max_sp = 0; return v; }
+int32_t rco_max_stack(int reset) { int32_t v = __atomic_load_n(&g_max_sp, __ATOMIC_RELAXED); if (reset) __atomic_store_n(&g_max_sp, 0, __ATOMIC_RELAXED); return v; }
 
 static void set_miss(rco_hit* h) {
     h->hit = 0; h->t = 0.0f; h->primitive_id = 0xFFFFFFFFu; h->instance_custom_index = 0;
@@ -650,7 +654,7 @@ static void traverse(const rco_scene* s, const rco_ray* r, rco_hit* out, uint32_
             uint32_t near_c, far_c;
             intersect_internal_node(node, ray_inv_d, ray_o, ray_mint, ray_maxt, &near_c, &far_c);
             ev = current_instance < 0 ? 0u : 1u;
-            if (far_c != RCO_INVALID_NODE) { if (sp < RCO_STACK) stack[sp++] = far_c; if (sp > g_max_sp) g_max_sp = sp; ev |= 0x20u; }
+            if (far_c != RCO_INVALID_NODE) { if (sp < RCO_STACK) stack[sp++] = far_c; note_sp(sp); ev |= 0x20u; }
             if (near_c != RCO_INVALID_NODE) { node_index = near_c; EV_PUT(ev, sp); continue; }
         } else if (current_instance < 0) {
             current_instance = (int32_t)node->child1;
@@ -1364,6 +1368,7 @@ static void traverse4(const blas_t* b, const rco_ray* r, rco_hit* out, uint32_t*
             }
             for (int i = hit_count - 1; i >= 1; --i) /* :637-642 */
                 if (h_idx[i] != RCO_INVALID_NODE && sp < RCO_STACK) stack[sp++] = h_idx[i];
+            note_sp(sp); /* dev: rco_max_stack */
             if (hit_count > 0 && h_idx[0] != RCO_INVALID_NODE) { node_idx = h_idx[0]; continue; }
         } else {
             uint32_t prim_idx = node->child[0];

@@ -465,7 +465,7 @@ void rc_launch_trace4(rc_scene* s, const Blas& b, const RcRay* d_rays, RcHit* d_
     rc_claim_fill(s, n, total_threads / 64u, a.claim);
     a.refill = (int)s->opt.refill;
     a.int_thr = (int)s->opt.sched_thr;
-    a.overflow = s->cur_overflow; a.total_threads = total_threads;
+    a.overflow = rc_launch_overflow(s, total_threads); a.total_threads = total_threads;  // (a captured launch: its own region, allocated here -- ADVICE r5)
     a.status = rc_status_word(s);
     launch.start();
     if (any_hit) hipLaunchKernelGGL((k_trace4<true, 24>), dim3(blocks), dim3(kBlock), 0, stream, a);

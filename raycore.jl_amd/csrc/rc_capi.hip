@@ -1451,17 +1451,27 @@ int rc_recent_kernel_ms(rc_scene* s, uint32_t max_launches, float* ms, uint32_t*
     return guarded([&] {
         use_device(s);
         *n_out = 0;
-        std::lock_guard<std::mutex> g(s->launch_mu);
-        // the events of a launch stay in its counter slot until the slot's next launch (kEagerSlots launches later): waits for each launch asked about
-        const uint64_t have = s->launch_seq < (uint64_t)(kEagerSlots - 1) ? s->launch_seq : (uint64_t)(kEagerSlots - 1);
-        const uint64_t n = (uint64_t)max_launches < have ? (uint64_t)max_launches : have;
+        // the events of a launch stay in its counter slot until the slot's next launch (kEagerSlots launches later).  Only the handles are
+        // copied under launch_mu; the waits happen without it, so other threads keep launching on the scene meanwhile -- a slot
+        // that such a launch reuses before it is read here reports the newer launch's duration.
+        struct Pair { hipEvent_t t0, t1; };
+        std::vector<Pair> ev;
+        uint64_t n = 0;
+        {
+            std::lock_guard<std::mutex> g(s->launch_mu);
+            const uint64_t have = s->launch_seq < (uint64_t)(kEagerSlots - 1) ? s->launch_seq : (uint64_t)(kEagerSlots - 1);
+            n = (uint64_t)max_launches < have ? (uint64_t)max_launches : have;
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint64_t launch = s->launch_seq - n + 1 + i;  // (launch numbers start at 1)
+                const rc_scene::LaunchSlot& slot = s->slots[launch % (uint64_t)kEagerSlots];
+                ev.push_back((slot.recorded && slot.t0 && slot.t1) ? Pair{slot.t0, slot.t1} : Pair{nullptr, nullptr});
+            }
+        }
         for (uint64_t i = 0; i < n; ++i) {
-            const uint64_t launch = s->launch_seq - n + 1 + i;  // (launch numbers start at 1)
-            const rc_scene::LaunchSlot& slot = s->slots[launch % (uint64_t)kEagerSlots];
             float t = 0.f;
-            if (slot.recorded && slot.t0 && slot.t1) {
-                RC_HIP(hipEventSynchronize(slot.t1));
-                if (hipEventElapsedTime(&t, slot.t0, slot.t1) != hipSuccess) { (void)hipGetLastError(); t = 0.f; }
+            if (ev[i].t1) {
+                RC_HIP(hipEventSynchronize(ev[i].t1));
+                if (hipEventElapsedTime(&t, ev[i].t0, ev[i].t1) != hipSuccess) { (void)hipGetLastError(); t = 0.f; }
             }
             ms[i] = t;
         }

@@ -750,7 +750,7 @@ void rc_note_stage_launch(rc_scene* s, hipStream_t stream) {
 
 void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32_t ray_begin, uint32_t n_ray, RcRay* d_out, hipStream_t stream) {
     if (n_ray == 0) return;
-    SceneView v = rc_scene_view(s, 0);
+    SceneView v = rc_scene_view_static(s);
     hipLaunchKernelGGL(k_view_factor_rays, dim3((n_ray + 255) / 256), dim3(256), 0, stream, v, (uint32_t)seed, (uint32_t)(seed >> 32), src, ray_begin, n_ray, d_out);
     RC_HIP(hipGetLastError());
     rc_note_stage_launch(s, stream);
@@ -759,7 +759,7 @@ void rc_launch_view_factor_rays(rc_scene* s, uint64_t seed, uint32_t src, uint32
 void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, float* d_points, float* d_normals, hipStream_t stream) {
     if (n == 0) return;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cus * 8);
-    hipLaunchKernelGGL(k_hit_points, dim3(blocks), dim3(256), 0, stream, rc_scene_view(s, 0), d_rays, d_hits, n, d_points, d_normals);
+    hipLaunchKernelGGL(k_hit_points, dim3(blocks), dim3(256), 0, stream, rc_scene_view_static(s), d_rays, d_hits, n, d_points, d_normals);
     RC_HIP(hipGetLastError());
     rc_note_stage_launch(s, stream);
 }
@@ -767,7 +767,7 @@ void rc_launch_hit_points(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits,
 void rc_launch_shadow_rays(rc_scene* s, const RcRay* d_rays, const RcHit* d_hits, uint64_t n, const float light[3], float bias, RcRay* d_out, hipStream_t stream) {
     if (n == 0) return;
     uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cus * 8);
-    hipLaunchKernelGGL(k_shadow_rays, dim3(blocks), dim3(256), 0, stream, rc_scene_view(s, 0), d_rays, d_hits, n, light[0], light[1], light[2], bias, d_out);
+    hipLaunchKernelGGL(k_shadow_rays, dim3(blocks), dim3(256), 0, stream, rc_scene_view_static(s), d_rays, d_hits, n, light[0], light[1], light[2], bias, d_out);
     RC_HIP(hipGetLastError());
     rc_note_stage_launch(s, stream);
 }

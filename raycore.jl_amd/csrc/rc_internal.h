@@ -254,7 +254,8 @@ struct rc_scene {
     int cur_capture = -1;              // the capture slot of the launch being prepared (-1: an eager launch)
     int last_capture = -1;
     int cur_region = -1, cur_history = -1, cur_scratch = -1;  // what the launch being prepared uses: RcLaunchGuard::finish records their events
-    uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared (a captured launch's is allocated by rc_scene_view, which knows the grid)
+    uint32_t* cur_overflow = nullptr;  // the region of the launch being prepared (a captured launch's is allocated by rc_launch_overflow, which knows the grid)
+    bool guard_live = false;           // an RcLaunchGuard exists (set / cleared by it under launch_mu): the cur_* fields are meaningful
     DevBuf<uint32_t> counters;        // kCounterSlots slots of claim counters (self-resetting, rc_claim_chunk), the sticky status word, dev statistics; zeroed at rc_scene_create
     uint64_t launch_seq = 0;          // eager launches so far; slot = launch_seq % kEagerSlots
     int cur_slot = 0;                 // slot of the launch being prepared
@@ -393,6 +394,9 @@ struct RcLaunchGuard {
     std::unique_lock<std::mutex> lock;
     bool capturing = false;
     RcLaunchGuard(rc_scene* scene, hipStream_t stream);
+    ~RcLaunchGuard();
+    RcLaunchGuard(const RcLaunchGuard&) = delete;
+    RcLaunchGuard& operator=(const RcLaunchGuard&) = delete;
     void start();
     void bind();   // the launch's ONE kernel carries the slot's events (hipExtLaunchKernelGGL) instead of event records around it
     void finish();

@@ -28,6 +28,7 @@
 
 #include "../../include/raycore_mi355x.h"
 #include "rc_internal.h"
+#include "rc_rccl_abi.h"
 
 namespace {
 
@@ -205,55 +206,98 @@ float rc_view_factors_rows_to_host(rc_scene* s, uint32_t rays_per_triangle, uint
 }
 
 // ---- RCCL, called directly (no torch): loaded at first use so that the library itself has no link-time dependency on it ----------------
+// The six entry points and the enum values are declared by hand in rc_rccl_abi.h and pinned to <rccl/rccl.h> by tests/test_rccl_abi.py.
 namespace {
-typedef struct ncclComm* ncclComm_t;
+using rc_rccl::comm_t;
 struct Rccl {
     void* handle = nullptr;
-    int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*Reduce)(const void*, void*, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    rc_rccl::CommInitAllFn CommInitAll = nullptr;
+    rc_rccl::CommDestroyFn CommDestroy = nullptr;
+    rc_rccl::ReduceFn Reduce = nullptr;
+    rc_rccl::GroupStartFn GroupStart = nullptr;
+    rc_rccl::GroupEndFn GroupEnd = nullptr;
+    rc_rccl::GetErrorStringFn GetErrorString = nullptr;
 };
-constexpr int kNcclUint32 = 3, kNcclUint64 = 5, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
+constexpr int kNcclUint32 = rc_rccl::kUint32, kNcclUint64 = rc_rccl::kUint64, kNcclSum = rc_rccl::kSum;
 std::mutex g_rccl_mu;
 Rccl g_rccl;
-std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;  // one communicator set per device list, kept for the life of the process
+std::map<std::vector<int>, std::vector<comm_t>> g_comms;  // one communicator set per device list, kept for the life of the process
 
+// Environment RC_RCCL_LIBRARY names the RCCL build to use (a path or a soname; once a process has mapped some other librccl.so -- torch
+// brings its own -- LD_LIBRARY_PATH no longer decides which one dlopen("librccl.so") returns).  When it is set nothing else is tried: a
+// caller who asks for a particular library must not silently get another.
 Rccl& rccl() {
     if (g_rccl.handle) return g_rccl;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.handle) break;
+    const char* chosen = getenv("RC_RCCL_LIBRARY");
+    if (chosen && chosen[0]) {
+        g_rccl.handle = dlopen(chosen, RTLD_NOW | RTLD_GLOBAL);
+        if (!g_rccl.handle) throw RcError(RC_ERR_HIP, std::string("RC_RCCL_LIBRARY=") + chosen + " could not be loaded: " + dlerror());
+    } else {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.handle) break;
+        }
+        if (!g_rccl.handle) throw RcError(RC_ERR_HIP, std::string("RC_VF_MODE_RAYS needs RCCL and librccl.so could not be loaded: ") + dlerror());
     }
-    if (!g_rccl.handle) throw RcError(RC_ERR_HIP, std::string("RC_VF_MODE_RAYS needs RCCL and librccl.so could not be loaded: ") + dlerror());
-    auto sym = [&](const char* n) { void* p = dlsym(g_rccl.handle, n); if (!p) throw RcError(RC_ERR_HIP, std::string("librccl.so lacks ") + n); return p; };
-    g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(sym("ncclCommInitAll"));
-    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
-    g_rccl.Reduce = reinterpret_cast<decltype(g_rccl.Reduce)>(sym("ncclReduce"));
-    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(sym("ncclGroupStart"));
-    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
-    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+    void* h = g_rccl.handle;
+    auto sym = [&](const char* n) {
+        void* p = dlsym(h, n);
+        if (!p) { g_rccl.handle = nullptr; throw RcError(RC_ERR_HIP, std::string("the RCCL library lacks ") + n); }
+        return p;
+    };
+    g_rccl.CommInitAll = reinterpret_cast<rc_rccl::CommInitAllFn>(sym("ncclCommInitAll"));
+    g_rccl.CommDestroy = reinterpret_cast<rc_rccl::CommDestroyFn>(sym("ncclCommDestroy"));
+    g_rccl.Reduce = reinterpret_cast<rc_rccl::ReduceFn>(sym("ncclReduce"));
+    g_rccl.GroupStart = reinterpret_cast<rc_rccl::GroupStartFn>(sym("ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<rc_rccl::GroupEndFn>(sym("ncclGroupEnd"));
+    g_rccl.GetErrorString = reinterpret_cast<rc_rccl::GetErrorStringFn>(sym("ncclGetErrorString"));
     return g_rccl;
 }
 void nccl_ok(int rc, const char* what) {
-    if (rc != 0) throw RcError(RC_ERR_HIP, std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+    if (rc != rc_rccl::kSuccess) throw RcError(RC_ERR_HIP, std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
 }
 
 // The communicator set of a device list (rank g = devs[g]), created on first use and kept for the life of the process.
-std::vector<ncclComm_t> comms_for(const std::vector<int>& devs) {
+std::vector<comm_t> comms_for(const std::vector<int>& devs) {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     Rccl& r = rccl();
     auto it = g_comms.find(devs);
     if (it == g_comms.end()) {
-        std::vector<ncclComm_t> fresh(devs.size());
+        std::vector<comm_t> fresh(devs.size());
         nccl_ok(r.CommInitAll(fresh.data(), (int)devs.size(), devs.data()), "ncclCommInitAll");
         it = g_comms.emplace(devs, fresh).first;
     }
     return it->second;
 }
+// A communicator set whose collective failed is not used again (RCCL leaves it in an undefined state): forget and destroy it, the next
+// call builds a fresh one.
+void drop_comms(const std::vector<int>& devs) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    auto it = g_comms.find(devs);
+    if (it == g_comms.end()) return;
+    if (g_rccl.CommDestroy) for (comm_t c : it->second) (void)g_rccl.CommDestroy(c);
+    g_comms.erase(it);
+}
+// ncclGroupStart ... ncclGroupEnd around the per-rank calls of one collective; an exception between the two still closes the group
+// (this thread's later RCCL calls would otherwise be queued for ever).
+struct RcclGroup {
+    Rccl& r;
+    bool open = false;
+    explicit RcclGroup(Rccl& lib) : r(lib) { nccl_ok(r.GroupStart(), "ncclGroupStart"); open = true; }
+    void end() { open = false; nccl_ok(r.GroupEnd(), "ncclGroupEnd"); }
+    ~RcclGroup() { if (open) (void)r.GroupEnd(); }
+};
+// Test hook (only under RC_ENABLE_DEBUG_HOOKS=1, like option debug_set_overflow): RC_DEBUG_RANKS_SHARE_DEVICE=1 lets scenes that live on
+// ONE device count as one RCCL rank each, so that a one-GPU box can execute the multi-rank branches below against a stub communicator
+// (tests/fake_rccl; real RCCL refuses a device list with duplicates).  Never set in production: replicas on one device are added on
+// the host (totals) or refused (RC_VF_MODE_RAYS).
+bool ranks_may_share_a_device() {
+    const char* hooks = getenv("RC_ENABLE_DEBUG_HOOKS");
+    const char* share = getenv("RC_DEBUG_RANKS_SHARE_DEVICE");
+    return hooks && hooks[0] == '1' && share && share[0] == '1';
+}
 bool distinct_devices(rc_scene* const* scenes, int n) {
+    if (ranks_may_share_a_device()) return true;  // (the C ABI has already refused the same SCENE twice)
     std::vector<int> d(n);
     for (int g = 0; g < n; ++g) d[g] = scenes[g]->device;
     std::sort(d.begin(), d.end());
@@ -314,13 +358,9 @@ static void multi_rays(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_
     const uint32_t n = scenes[0]->n_flat_prims;
     std::vector<int> devs(n_scenes);
     for (int g = 0; g < n_scenes; ++g) devs[g] = scenes[g]->device;
-    {
-        std::vector<int> sorted = devs;
-        std::sort(sorted.begin(), sorted.end());
-        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
-            throw RcError(RC_ERR_INVALID_ARGUMENT, "RC_VF_MODE_RAYS reduces over RCCL, which needs one DISTINCT device per scene (use RC_VF_MODE_ROWS for several scenes on one device)");
-    }
-    const std::vector<ncclComm_t> comms = comms_for(devs);
+    if (!distinct_devices(scenes, n_scenes))
+        throw RcError(RC_ERR_INVALID_ARGUMENT, "RC_VF_MODE_RAYS reduces over RCCL, which needs one DISTINCT device per scene (use RC_VF_MODE_ROWS for several scenes on one device)");
+    const std::vector<comm_t> comms = comms_for(devs);
     const uint32_t C = chunk_rows_for(scenes[0], n, n), n_chunks = (n + C - 1) / C;
     std::vector<DeviceJob> jobs(n_scenes);
     std::vector<DevBuf<uint32_t>> acc(n_scenes);
@@ -361,12 +401,12 @@ static void multi_rays(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_
             RC_HIP(hipSetDevice(scenes[g]->device));
             RC_HIP(hipStreamWaitEvent(jobs[g].comm, traced[g][k], 0));
         }
-        nccl_ok(r.GroupStart(), "ncclGroupStart");
+        RcclGroup group(r);
         for (int g = 0; g < n_scenes; ++g) {
             uint32_t* blk = acc[g].p + (size_t)r0 * n;
             nccl_ok(r.Reduce(blk, blk, (size_t)(r1 - r0) * n, kNcclUint32, kNcclSum, 0, comms[g], jobs[g].comm), "ncclReduce");
         }
-        nccl_ok(r.GroupEnd(), "ncclGroupEnd");
+        group.end();
         RC_HIP(hipSetDevice(scenes[0]->device));
         RC_HIP(hipEventRecord(reduced[k], jobs[0].comm));
     };
@@ -405,6 +445,7 @@ static void multi_rays(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_
     } catch (...) {
         abort_copies.store(true, std::memory_order_release);
         copier.join();
+        drop_comms(devs);
         throw;
     }
     copier.join();
@@ -452,7 +493,7 @@ void rc_view_factor_totals_multi_impl(rc_scene* const* scenes, int n_scenes, uin
     const bool use_rccl = n_scenes > 1 && distinct_devices(scenes, n_scenes);
     std::vector<int> devs(n_scenes);
     for (int g = 0; g < n_scenes; ++g) devs[g] = scenes[g]->device;
-    std::vector<ncclComm_t> comms;
+    std::vector<comm_t> comms;
     if (use_rccl) comms = comms_for(devs);
     std::vector<hipStream_t> stream(n_scenes, nullptr);
     hipEvent_t t_begin = nullptr, t_end = nullptr;
@@ -475,10 +516,16 @@ void rc_view_factor_totals_multi_impl(rc_scene* const* scenes, int n_scenes, uin
     std::vector<uint64_t> total((size_t)2 * n, 0);
     if (use_rccl) {  // stream-ordered behind each device's trace: RCCL itself waits for the slowest rank
         Rccl& r = rccl();
-        nccl_ok(r.GroupStart(), "ncclGroupStart");
-        for (int g = 0; g < n_scenes; ++g)
-            nccl_ok(r.Reduce(scenes[g]->u64_stage.p, scenes[g]->u64_stage.p, (size_t)2 * n, kNcclUint64, kNcclSum, 0, comms[g], stream[g]), "ncclReduce");
-        nccl_ok(r.GroupEnd(), "ncclGroupEnd");
+        try {
+            RcclGroup group(r);
+            for (int g = 0; g < n_scenes; ++g)
+                nccl_ok(r.Reduce(scenes[g]->u64_stage.p, scenes[g]->u64_stage.p, (size_t)2 * n, kNcclUint64, kNcclSum, 0, comms[g], stream[g]), "ncclReduce");
+            group.end();
+        } catch (...) {
+            for (int g = 0; g < n_scenes; ++g) { (void)hipSetDevice(scenes[g]->device); (void)hipStreamSynchronize(stream[g]); }  // the traces in flight write the scenes' staging vectors
+            drop_comms(devs);
+            throw;
+        }
     }
     RC_HIP(hipSetDevice(scenes[0]->device));
     if (use_rccl || n_scenes == 1) {
@@ -528,7 +575,7 @@ void rc_multi_prepare_impl(rc_scene* const* scenes, int n_scenes, float out_ms[4
     std::vector<int> devs(n_scenes);
     for (int g = 0; g < n_scenes; ++g) devs[g] = scenes[g]->device;
     auto t0 = now();
-    std::vector<ncclComm_t> comms;
+    std::vector<comm_t> comms;
     if (use_rccl) comms = comms_for(devs);
     const float ms_comm = ms_since(t0);
     t0 = now();
@@ -544,10 +591,12 @@ void rc_multi_prepare_impl(rc_scene* const* scenes, int n_scenes, float out_ms[4
     t0 = now();
     if (use_rccl && n > 0) {  // the first collective of a communicator sets up its xGMI connections: do it here, on zeros
         Rccl& r = rccl();
-        nccl_ok(r.GroupStart(), "ncclGroupStart");
-        for (int g = 0; g < n_scenes; ++g)
-            nccl_ok(r.Reduce(scenes[g]->u64_stage.p, scenes[g]->u64_stage.p, (size_t)2 * n, kNcclUint64, kNcclSum, 0, comms[g], scenes[g]->aux_streams[0]), "ncclReduce");
-        nccl_ok(r.GroupEnd(), "ncclGroupEnd");
+        try {
+            RcclGroup group(r);
+            for (int g = 0; g < n_scenes; ++g)
+                nccl_ok(r.Reduce(scenes[g]->u64_stage.p, scenes[g]->u64_stage.p, (size_t)2 * n, kNcclUint64, kNcclSum, 0, comms[g], scenes[g]->aux_streams[0]), "ncclReduce");
+            group.end();
+        } catch (...) { drop_comms(devs); throw; }
         for (int g = 0; g < n_scenes; ++g) { RC_HIP(hipSetDevice(scenes[g]->device)); RC_HIP(hipStreamSynchronize(scenes[g]->aux_streams[0])); }
     }
     const float ms_warm = use_rccl ? ms_since(t0) : 0.f;

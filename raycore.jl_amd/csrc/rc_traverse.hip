@@ -383,7 +383,8 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
     capturing = cap == hipStreamCaptureStatusActive;
     const size_t region_words = (size_t)kTotalStack * (size_t)s->n_cus * 8 * kBlock;  // the largest grid any option can ask for: rc_set_option clamps blocks_per_cu to 8 blocks of 256 threads per CU
-    s->cur_capture = -1; s->cur_region = -1; s->cur_history = -1; s->cur_scratch = -1;
+    s->cur_capture = -1; s->cur_region = -1; s->cur_history = -1; s->cur_scratch = -1; s->cur_overflow = nullptr;
+    s->guard_live = true;
     if (capturing) {
         // A captured launch bakes its addresses into the graph and may be replayed at any time, beside eager launches and beside other
         // graphs: it gets a lane-stack spill region AND a slot of claim counters that no other launch, eager or captured, will ever use
@@ -434,6 +435,13 @@ RcLaunchGuard::RcLaunchGuard(rc_scene* scene, hipStream_t st) : s(scene), stream
         if (slot.recorded && slot.stream != stream) RC_HIP(hipStreamWaitEvent(stream, slot.t1, 0));
     }
     if (s->opt.stats) RC_HIP(hipMemsetAsync(rc_stats_words(s), 0, kStatsWords * sizeof(unsigned long long), stream));
+}
+
+// The launch state is the guard's: once it is gone no capture slot, region or spill pointer is current (a stale cur_capture
+// used to let a later unguarded call allocate into -- or index past -- the capture slots).  Runs with launch_mu still held.
+RcLaunchGuard::~RcLaunchGuard() {
+    s->cur_capture = -1; s->cur_region = -1; s->cur_history = -1; s->cur_scratch = -1; s->cur_overflow = nullptr;
+    s->guard_live = false;
 }
 
 static int rc_event_mode() {  // dev (tools/archive/event_probe.py): RC_EVENT_MODE = 0 product, 1 hipEventDisableSystemFence on t1 too, 2 no t0 event, 3 no events at all (single-stream runs only), 4 system fence on t0 as well (rounds 3-4)
@@ -548,12 +556,26 @@ void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcCl
     while ((2u << out.pool_shift) <= out.pool) ++out.pool_shift;
 }
 
-rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
+// The scene's arrays as the kernels see them: no launch state, no side effects.  What kernels that never spill a traversal stack get (the
+// wavefront stages, which run OUTSIDE RcLaunchGuard and without launch_mu: ADVICE r5 -- they used to go through the allocating view
+// below and could publish a tiny capture region into another thread's captured launch).
+rc::SceneView rc_scene_view_static(rc_scene* s) {
     rc::SceneView v;
     v.tlas_nodes = s->tlas_nodes.p; v.blas_nodes = s->flat_nodes.p; v.inst = s->inst_recs.p; v.prims = s->flat_prims.p;
     v.n_tlas_nodes = s->n_tlas_nodes; v.n_prims = s->n_flat_prims; v.tlas_off = s->n_flat_nodes; v.n_nodes_total = s->n_flat_nodes + s->n_tlas_nodes; v.n_inst = s->n_static_instances;
     v.inst_cull = (s->opt.entry_cull && s->inst_cull.p && s->n_static_instances) ? s->inst_cull.p : nullptr;
-    if (s->cur_capture >= 0 && !s->cur_overflow) {  // a captured launch: its own spill region, sized for its own grid (every capture used to pin the largest grid's 268 MB)
+    v.overflow = nullptr; v.total_threads = 0;
+    v.status = rc_status_word(s);
+    return v;
+}
+
+// The stack spill region of the launch being prepared (inside an RcLaunchGuard, launch_mu held).  An eager launch has its stream's
+// region already; a captured launch gets its own here, sized for its own grid of `total_threads` threads (every capture used
+// to pin the largest grid's 268 MB) -- allocated inside the capture: the entry points run with the thread's capture-interaction mode
+// relaxed, in which hipMalloc is legal.  Never returns null.
+uint32_t* rc_launch_overflow(rc_scene* s, uint32_t total_threads) {
+    if (!s->guard_live) throw RcError(1, "internal: rc_launch_overflow outside RcLaunchGuard");
+    if (s->cur_capture >= 0 && !s->cur_overflow) {
         rc_scene::CaptureSlot& cs = s->capture_slots[s->cur_capture];
         try {
             cs.region.reserve((size_t)kTotalStack * std::max<uint32_t>(total_threads, 64u));
@@ -565,8 +587,14 @@ rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
         }
         s->cur_overflow = cs.region.p;
     }
-    v.overflow = s->cur_overflow; v.total_threads = total_threads;
-    v.status = rc_status_word(s);
+    if (!s->cur_overflow) throw RcError(1, "internal: the launch has no stack spill region");
+    return s->cur_overflow;
+}
+
+// The view of a traversal launch with `total_threads` threads (inside an RcLaunchGuard).
+rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads) {
+    rc::SceneView v = rc_scene_view_static(s);
+    v.overflow = rc_launch_overflow(s, total_threads); v.total_threads = total_threads;
     return v;
 }
 

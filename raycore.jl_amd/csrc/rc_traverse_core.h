@@ -1017,7 +1017,9 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, t
 
 }  // namespace rc
 
-rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads);  // rc_traverse.hip
+rc::SceneView rc_scene_view(rc_scene* s, uint32_t total_threads);  // rc_traverse.hip: a traversal launch's view, inside an RcLaunchGuard
+rc::SceneView rc_scene_view_static(rc_scene* s);                    // the arrays only: no spill region, no side effects (stage kernels)
+uint32_t* rc_launch_overflow(rc_scene* s, uint32_t total_threads);  // the spill region of the launch being prepared (never null)
 rc::PersistArgs rc_persist_args(rc_scene* s, uint64_t n_items, uint32_t total_threads);
 // cost-ordered claiming for a launch inside an RcLaunchGuard: `kind` separates the histories of launches that map items to rays differently
 // (0 closest_hit, 1 any_hit, 2 the get_illumination grid)

@@ -142,3 +142,56 @@ def test_trace4_device_buffers(rc, oracle):
     torch.cuda.synchronize()
     got = d_h.cpu().numpy().view(rc.HIT_DT)
     assert_hits_equal(got, s.trace4(b, r, nthreads=4), "device closest4")
+
+
+def test_captured_trace4_on_a_deep_tree_owns_a_spill_region(rc, oracle):
+    """a BVH4 launch captured into a hipGraph must get a stack spill region of its own.  Heavily overlapping triangles
+    make every ray descend with all four children pushed at every level, so the 24-entry LDS stack of k_trace4 spills into the region on
+    the first descent (depth >= 10 => >= 27 entries); with a null region the replay would fault or corrupt.  A stage launch (which runs
+    outside the launch guard) after the capture must neither allocate into nor index the capture slots."""
+    import torch
+    v = soup(100000, 71, 0.6)
+    s, b = oracle_scene(oracle, v)
+    blas = rc.build_blas4(v)
+    blas._scene.sync()  # (build_blas4 pushed an identity instance; the stage launch below wants the scene synced)
+    r = rays_for(1500, 72)
+    import ctypes as C
+    L = oracle.lib()
+    L.rco_max_stack.restype, L.rco_max_stack.argtypes = C.c_int32, [C.c_int]
+    L.rco_max_stack(1)
+    s.trace4(b, r[:300], nthreads=1)
+    assert L.rco_max_stack(1) > 24, "the scene no longer drives the stack past k_trace4's 24 LDS entries: the test would prove nothing"
+    want, want_any = s.trace4(b, r, nthreads=8), s.trace4(b, r, mode="any", nthreads=8)
+    assert_hits_equal(blas.trace(r), want, "eager closest4 (deep)")
+    n = len(r)
+    d_r = torch.from_numpy(r.view(np.uint8).reshape(-1)).cuda()
+    d_h, d_a, d_sh = (torch.zeros(n * 32, dtype=torch.uint8, device="cuda") for _ in range(3))
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        cs = torch.cuda.current_stream().cuda_stream
+        blas.trace_device(d_r.data_ptr(), d_h.data_ptr(), n, stream=cs)
+        blas.trace_device(d_r.data_ptr(), d_a.data_ptr(), n, mode="any", stream=cs)
+    scene = blas._scene
+    assert scene.get_option("release_captures") == 2          # two captured launches, each with its own slot and region
+    # an unguarded stage launch right after the capture (it used to find a stale capture slot current)
+    scene.shadow_rays_device(d_r.data_ptr(), d_h.data_ptr(), n, np.array([3, 3, 3], np.float32), d_sh.data_ptr(), bias=1e-3, stream=st.cuda_stream)
+    st.synchronize()
+    for rep in range(3):
+        d_h.zero_(); d_a.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert_hits_equal(d_h.cpu().numpy().view(rc.HIT_DT), want, f"captured closest4 replay {rep}")
+        assert_hits_equal(d_a.cpu().numpy().view(rc.HIT_DT), want_any, f"captured any4 replay {rep}")
+    # eager launches beside the graph still work and do not disturb it
+    assert_hits_equal(blas.trace(r), want, "eager after capture")
+    g.replay()
+    torch.cuda.synchronize()
+    assert_hits_equal(d_h.cpu().numpy().view(rc.HIT_DT), want, "replay after eager")
+    del g
+    scene.set_option("release_captures", 1)
+    assert scene.get_option("release_captures") == 0
+    scene.shadow_rays_device(d_r.data_ptr(), d_h.data_ptr(), n, np.array([3, 3, 3], np.float32), d_sh.data_ptr(), bias=1e-3, stream=st.cuda_stream)  # after release: nothing to index
+    st.synchronize()
+    scene.wait_for_gpu()
