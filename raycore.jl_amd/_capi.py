@@ -68,6 +68,8 @@ SYMBOLS = [
     ("rc_trace_any", _int, [_vp, _vp, _vp, _u64]),
     ("rc_trace_closest_device", _int, [_vp, _vp, _vp, _u64, _vp]),
     ("rc_trace_any_device", _int, [_vp, _vp, _vp, _u64, _vp]),
+    ("rc_trace_closest_device_batches", _int, [_vp, _vp, _vp, _vp, _int, _vp]),
+    ("rc_trace_any_device_batches", _int, [_vp, _vp, _vp, _vp, _int, _vp]),
     ("rc_set_option", _int, [_vp, C.c_char_p, _i64]),
     ("rc_get_option", _int, [_vp, C.c_char_p, C.POINTER(_i64)]),
     ("rc_generate_ray_grid_device", _int, [_vp, _vp, _u32, _vp, _vp]),

@@ -399,6 +399,18 @@ class TLAS:
         fn = lib().rc_trace_closest_device if mode == "closest" else lib().rc_trace_any_device
         check(fn(self._h, ptr(d_rays), ptr(d_hits), int(n), ptr(stream) if stream else None))
 
+    def trace_device_batches(self, d_rays, d_hits, n, mode="closest", stream=None):
+        """Several INDEPENDENT device batches in one call (rc_trace_*_device_batches): sequences of device pointers and ray counts.  The
+        batches overlap on the scene's auxiliary streams, forked from and joined back into `stream`; asynchronous like trace_device."""
+        k = len(n)
+        if len(d_rays) != k or len(d_hits) != k:
+            raise ValueError("d_rays, d_hits and n must have one entry per batch")
+        rp = (C.c_void_p * k)(*[int(x) for x in d_rays])
+        hp = (C.c_void_p * k)(*[int(x) for x in d_hits])
+        nn = (C.c_uint64 * k)(*[int(x) for x in n])
+        fn = lib().rc_trace_closest_device_batches if mode == "closest" else lib().rc_trace_any_device_batches
+        check(fn(self._h, rp, hp, nn, k, ptr(stream) if stream else None))
+
     def hit_points_device(self, d_rays, d_hits, n, d_points, d_normals=None, stream=None):
         check(lib().rc_hit_points_device(self._h, ptr(d_rays), ptr(d_hits), int(n), ptr(d_points), ptr(d_normals) if d_normals else None,
                                          ptr(stream) if stream else None))

@@ -309,6 +309,8 @@ int rc_scene_destroy(rc_scene* s) {
     }
     for (auto& c : s->call_ctx) if (c && c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     for (auto a : s->aux_streams) if (a) (void)hipStreamDestroy(a);
+    if (s->batch_fork) (void)hipEventDestroy(s->batch_fork);
+    for (auto e : s->batch_join) if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return RC_OK;
@@ -801,6 +803,56 @@ static int trace_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint6
 }
 int rc_trace_closest_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace_device(s, d_rays, d_hits, n, stream, 0); }
 int rc_trace_any_device(rc_scene* s, const rc_ray* d_rays, rc_hit* d_hits, uint64_t n, void* stream) { return trace_device(s, d_rays, d_hits, n, stream, 1); }
+
+// Several INDEPENDENT device batches in one call.  A launch of about a million rays ends with most of the machine idle --
+// its waves wait for their longest rays -- and the next launch's workgroups can fill that tail only if they are not ordered behind it:
+// callers who kept four such launches in flight on four streams measured +28-44 %.  This entry point does that for them:
+// the batches go round-robin onto the scene's auxiliary streams, forked from `stream` with an event and joined back into it, so to the
+// caller the call is ONE asynchronous operation on `stream`.  Every batch is traced exactly as a single rc_trace_*_device call would.
+static int trace_device_batches(rc_scene* s, const rc_ray* const* d_rays, rc_hit* const* d_hits, const uint64_t* n, int n_batches, void* stream_, int any) {
+    if (!s) return fail(RC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    return guarded([&] {
+        use_device(s);
+        require_synced(s);
+        if (n_batches < 0) throw RcError(RC_ERR_INVALID_ARGUMENT, "n_batches is negative");
+        if (n_batches == 0) return;
+        if (!d_rays || !d_hits || !n) throw RcError(RC_ERR_INVALID_ARGUMENT, "the batch arrays are NULL");
+        for (int b = 0; b < n_batches; ++b)
+            if (n[b] && (!d_rays[b] || !d_hits[b])) throw RcError(RC_ERR_INVALID_ARGUMENT, "rays/hits of batch " + std::to_string(b) + " is NULL");
+        hipStream_t stream = (hipStream_t)stream_;
+        if (n_batches == 1) {  // nothing to overlap
+            rc_launch_trace(s, reinterpret_cast<const RcRay*>(d_rays[0]), reinterpret_cast<RcHit*>(d_hits[0]), n[0], any, stream);
+            return;
+        }
+        std::lock_guard<std::mutex> one(s->batches_mu);
+        constexpr int kLanes = 4;
+        for (auto& a : s->aux_streams) if (!a) RC_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        if (!s->batch_fork) RC_HIP(hipEventCreateWithFlags(&s->batch_fork, hipEventDisableTiming));
+        for (auto& e : s->batch_join) if (!e) RC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const int lanes = n_batches < kLanes ? n_batches : kLanes;
+        RC_HIP(hipEventRecord(s->batch_fork, stream));
+        for (int k = 0; k < lanes; ++k) RC_HIP(hipStreamWaitEvent(s->aux_streams[k], s->batch_fork, 0));
+        // Whatever happens below, every forked stream is joined back: a caller that is CAPTURING `stream` must get all of them back before it
+        // can end the capture, and an eager caller must never be left ordered behind nothing.
+        std::string err;
+        int code = 0;
+        try {
+            for (int b = 0; b < n_batches; ++b)
+                rc_launch_trace(s, reinterpret_cast<const RcRay*>(d_rays[b]), reinterpret_cast<RcHit*>(d_hits[b]), n[b], any, s->aux_streams[b % kLanes]);
+        } catch (const RcError& e) { err = e.what(); code = e.code; }
+        for (int k = 0; k < lanes; ++k) {
+            RC_HIP(hipEventRecord(s->batch_join[k], s->aux_streams[k]));
+            RC_HIP(hipStreamWaitEvent(stream, s->batch_join[k], 0));
+        }
+        if (code) throw RcError(code, err);
+    });
+}
+int rc_trace_closest_device_batches(rc_scene* s, const rc_ray* const* d_rays, rc_hit* const* d_hits, const uint64_t* n, int n_batches, void* stream) {
+    return trace_device_batches(s, d_rays, d_hits, n, n_batches, stream, 0);
+}
+int rc_trace_any_device_batches(rc_scene* s, const rc_ray* const* d_rays, rc_hit* const* d_hits, const uint64_t* n, int n_batches, void* stream) {
+    return trace_device_batches(s, d_rays, d_hits, n, n_batches, stream, 1);
+}
 
 // ---- BVH4 (src/bvh4.jl) ------------------------------------------------------------------------------------------
 static_assert(sizeof(rc_bvh4_node) == 120, "BVHNode4 is 120 bytes");

@@ -61,6 +61,7 @@ struct GridSource {
     GridParams g;
     uint64_t first;
     __device__ inline RcRay operator()(uint64_t i) const { return grid_ray(g, first + i); }
+    static constexpr bool kPrefetch = false;  // rays are generated, nothing to read ahead (ArraySource::prefetch)
 };
 // Counting into an accumulator array from inside a wave.  An atomic on ONE address costs ~12.7 ns on this chip whether or not it
 // returns a value and however many lanes issue it (tools/archive/atomic_probe.hip), so a driver whose rays mostly land on a few large
@@ -267,6 +268,7 @@ struct ViewFactorSource {
         const uint32_t src = order ? order[pos] : pos;
         return view_factor_ray(prims[src], src, ray_idx, k0, k1);  // Philox is keyed by the PRIMITIVE index: the rays do not depend on the addressing
     }
+    static constexpr bool kPrefetch = false;
 };
 struct ViewFactorSink {
     const RcInstRec* inst;

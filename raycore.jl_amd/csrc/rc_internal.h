@@ -131,7 +131,10 @@ constexpr int kLdsPlaneNodes = 310;
 constexpr int kPartialPlaneNodes = 585;  // node planes of the PARTIAL_LDS kernel (no leaf table, no instance planes): 32 760 bytes
 // Scenes whose trees ALL have fewer than 65 534 nodes (every BLAS <= 32 767 triangles, <= 32 767 instances) run the STACK16 shape of the
 // same kernels (round 5): lane-stack entries of 16 bits, and the 24 KiB of LDS that frees per workgroup holds more of the tree.
-constexpr int kLdsPlaneNodes16 = 748;      // 7 x 748 x 8 = 41 888 bytes of node planes (+ 24 576 of stacks + 1 024 + 14 336 = 81 824)
+#ifndef RC_LDS_PLANES16        // dev: tools/lds_bound_probe.py builds a variant with 1 278 entries (every interior node of a 1 024-triangle BLAS; one workgroup per CU)
+#define RC_LDS_PLANES16 748
+#endif
+constexpr int kLdsPlaneNodes16 = RC_LDS_PLANES16;  // 7 x 748 x 8 = 41 888 bytes of node planes (+ 24 576 of stacks + 1 024 + 14 336 = 81 824)
 constexpr int kPartialPlaneNodes16 = 1023; // 7 x 1023 x 8 = 57 288 (+ 24 576 = 81 864)
 constexpr uint32_t kStack16MaxLeaves = 32767;
 }  // namespace rc
@@ -300,6 +303,8 @@ struct rc_scene {
     std::condition_variable ctx_cv;
     std::vector<std::unique_ptr<CallCtx>> call_ctx;
     hipStream_t aux_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // rc_multi.hip: two compute streams, a copy stream, a communication stream (created on first use)
+    std::mutex batches_mu;             // rc_trace_*_device_batches: one fork / join over the auxiliary streams is enqueued at a time
+    hipEvent_t batch_fork = nullptr, batch_join[4] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex stage_mu;               // stage kernels (hit points, shadow rays, ...) on the callers' streams: the last launch per stream, so that
     std::map<hipStream_t, hipEvent_t> stage_events;  // rc_scene_destroy can wait for exactly the work that still reads the scene
     std::mutex host_call_mu;          // the other host-buffer entry points (illumination, view factors, collisions, exports) run one at a time

@@ -934,7 +934,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
     // the shape's first launches (a batch records its launches 2-4), the launches after the device reported a launch that was not a
     // repeat (a new batch starts its own launches 2-4), and the launch after one this host asked to record.  Everything else about the
     // launch's claim order is decided inside the launch itself (order_select).
-    volatile uint32_t* pinned = reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p);  // [0] the run of non-repeats, [1] a recording waits, [2] the pause (all as of the latest launch that has FINISHED)
+    volatile uint32_t* pinned = reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p);  // [0] the run of non-repeats, [1] a recording waits, [2] the pause (written by order_commit at the START of a launch: as of the latest launch that has STARTED -- possibly one still in flight; benign, the rebuild kernels are stream-ordered behind it)
     const bool paused = pinned[2] > 1u;  // (this launch and the next are still inside the pause: nothing records, nothing to rebuild)
     if (pinned[0] > 0u) h->rebuild_credit = 6;
     if (paused) h->rebuild_credit = 0;

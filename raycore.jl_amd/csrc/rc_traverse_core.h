@@ -494,6 +494,19 @@ struct ArraySource {
         float4 a = q[0], b = q[1];
         return RcRay{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     }
+    // Round 6: a wave that has just claimed the range [first, end) touches one dword of every 64-byte line of it (lane L: rays first + 2 L and
+    // first + 2 L + 1; 64 lanes = 128 rays = a whole chunk), in the same memory round trip as its first ray loads.  A batch traced for the first
+    // time is read from HBM (through cold TLB entries), and a chunk is consumed in 3-4 refills of 20-64 rays -- each of which used to pay that
+    // round trip; now the later ones find their lines in L2.  The value is never used (the caller only keeps it alive up to the ray loads' wait).
+#ifdef RC_NO_RAY_PREFETCH   // dev: A/B builds (tools/ab_fresh.py)
+    static constexpr bool kPrefetch = false;
+#else
+    static constexpr bool kPrefetch = true;
+#endif
+    __device__ inline uint32_t prefetch(unsigned long long first, unsigned long long end, int lane) const {
+        const unsigned long long i = first + 2ull * (unsigned long long)lane;
+        return i < end ? *reinterpret_cast<const uint32_t*>(rays + i) : 0u;
+    }
 };
 struct HitWriter {
     const RcInstRec* inst;
@@ -572,7 +585,11 @@ constexpr size_t kMidLdsBytes = (size_t)kMidStack * kMidBlock * 4 + kLdsTopBytes
 // STACK16 shape (scenes whose trees all have fewer than 65 534 nodes: 16-bit lane stacks, 24 KiB instead of 48): kLdsPlaneNodes16 node-plane entries
 constexpr size_t kNodePlaneBytes16 = (size_t)7 * kLdsPlaneNodes16 * sizeof(float2);
 constexpr size_t kMidLdsBytes16 = (size_t)kMidStack * kMidBlock * 2 + kNodePlaneBytes16 + kLeafTableBytes + kInstPlaneBytes;
+#if RC_LDS_PLANES16 == 748
 static_assert(kMidLdsBytes <= 81920 && kMidLdsBytes16 <= 81920, "two workgroups per CU share 160 KiB of LDS");
+#else   // dev variant (tools/lds_bound_probe.py): one workgroup per CU
+static_assert(kMidLdsBytes <= 81920 && kMidLdsBytes16 <= 163840, "one workgroup per CU has 160 KiB of LDS");
+#endif
 struct LdsTop {
     float2* tl;    // node planes: plane p of entry e at tl[p * (plane entries) + e]
     uint32_t* lt;  // lt[j] = instance index of TLAS leaf n - 1 + j + 1 (node index n + j)
@@ -941,9 +958,11 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, t
                     const unsigned long long free_mask = __ballot(!live);
                     const int nf = __popcll(free_mask);
                     if (nf == 0) break;
+                    uint32_t touched = 0u;
                     if (pool_next == pool_end) {
                         if (exhausted) break;
                         if (!rc_claim_chunk(a.claim, claim_order, (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane, a.n_items, pool_next, pool_end)) { exhausted = true; break; }
+                        if constexpr (Source::kPrefetch) touched = src.prefetch(pool_next, pool_end, lane);  // the claimed range's lines, requested together with the first ray loads below
                     }
                     const unsigned long long left = pool_end - pool_next;
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_mask >> 32),
@@ -980,6 +999,7 @@ __device__ inline void phased_trace(const SceneView& av, const PersistArgs& a, t
                         live = true;
                         start_it = it_total;
                     }
+                    if constexpr (Source::kPrefetch) asm volatile("" ::"v"(touched));  // (keeps the touch alive; loads return in order, so the ray loads' wait has covered it)
                     RC_MARK("refill_end");
                     RC_MARK("finish_begin");
                     pool_next += ((unsigned long long)nf < left) ? (unsigned long long)nf : left;

@@ -21,11 +21,11 @@ end
 MI355XBackend() = MI355XBackend(0)
 
 last_error() = unsafe_string(ccall((:rc_last_error, LIB), Cstring, ()))
-# roctx ranges around a caller's own phases (every entry point of the library is a range of its own): `range("shade") do ... end`
+# roctx ranges around a caller's own phases (every entry point of the library is a range of its own): `profile_range("shade") do ... end` (not `range`: that would shadow Base.range inside the module)
 range_push(name::AbstractString) = ccall((:rc_range_push, LIB), Cint, (Cstring,), name)
 range_pop() = ccall((:rc_range_pop, LIB), Cint, ())
 ranges_enabled() = ccall((:rc_ranges_enabled, LIB), Cint, ()) != 0
-function range(f, name::AbstractString)
+function profile_range(f, name::AbstractString)
     range_push(name)
     try
         return f()
@@ -384,6 +384,13 @@ device_download!(dst::Vector, src::Ptr{Cvoid}) =
 trace_device!(a::MI355XStaticTLAS, d_rays::Ptr{RTRay}, d_hits::Ptr{RTHitResult}, n::Integer; any::Bool = false, stream::Ptr{Cvoid} = C_NULL) =
     check(any ? ccall((:rc_trace_any_device, LIB), Cint, (Ptr{Cvoid}, Ptr{RTRay}, Ptr{RTHitResult}, UInt64, Ptr{Cvoid}), a.owner.ptr, d_rays, d_hits, n, stream) :
                 ccall((:rc_trace_closest_device, LIB), Cint, (Ptr{Cvoid}, Ptr{RTRay}, Ptr{RTHitResult}, UInt64, Ptr{Cvoid}), a.owner.ptr, d_rays, d_hits, n, stream))
+
+"Several INDEPENDENT device batches in one call: they overlap on the scene's auxiliary streams, forked from and joined back into `stream`."
+function trace_device_batches!(a::MI355XStaticTLAS, d_rays::Vector{Ptr{RTRay}}, d_hits::Vector{Ptr{RTHitResult}}, n::Vector{UInt64}; any::Bool = false, stream::Ptr{Cvoid} = C_NULL)
+    length(d_rays) == length(d_hits) == length(n) || error("d_rays, d_hits and n must have one entry per batch")
+    check(any ? ccall((:rc_trace_any_device_batches, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{RTRay}}, Ptr{Ptr{RTHitResult}}, Ptr{UInt64}, Cint, Ptr{Cvoid}), a.owner.ptr, d_rays, d_hits, n, length(n), stream) :
+                ccall((:rc_trace_closest_device_batches, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{RTRay}}, Ptr{Ptr{RTHitResult}}, Ptr{UInt64}, Cint, Ptr{Cvoid}), a.owner.ptr, d_rays, d_hits, n, length(n), stream))
+end
 
 "One shard of get_illumination: rays [ray_begin, ray_end) of the grid, histogram ACCUMULATED into the device vector d_counts."
 illumination_device!(a::MI355XStaticTLAS, viewdir, grid_size::Integer, ray_begin::Integer, ray_end::Integer, d_counts::Ptr{Float32};

@@ -120,15 +120,21 @@ def normalize(v):
     return v / np.linalg.norm(v, axis=-1, keepdims=True)
 
 
-def pinhole_rays(width, height, eye, look_at, fov_deg=45.0, up=(0, 1, 0)):
+def pinhole_rays(width, height, eye, look_at, fov_deg=45.0, up=(0, 1, 0), jitter_seed=None):
+    """One primary ray per pixel through the pixel's centre; jitter_seed: through a uniformly random point of the pixel instead (a
+    progressive renderer's frames: the same image, different rays every launch)."""
     eye = np.asarray(eye, dtype=np.float64)
     f = normalize(np.asarray(look_at, dtype=np.float64) - eye)
     r = normalize(np.cross(f, np.asarray(up, dtype=np.float64)))
     u = np.cross(r, f)
     half = np.tan(np.radians(fov_deg) / 2)
-    xs = ((np.arange(width) + 0.5) / width * 2 - 1) * half * (width / height)
-    ys = ((np.arange(height) + 0.5) / height * 2 - 1) * half
-    X, Y = np.meshgrid(xs, ys)
+    px, py = np.meshgrid(np.arange(width) + 0.5, np.arange(height) + 0.5)
+    if jitter_seed is not None:
+        g = rng(jitter_seed)
+        px = px + g.uniform(-0.5, 0.5, size=px.shape)
+        py = py + g.uniform(-0.5, 0.5, size=py.shape)
+    X = (px / width * 2 - 1) * half * (width / height)
+    Y = (py / height * 2 - 1) * half
     d = normalize(f + X[..., None] * r + Y[..., None] * u).reshape(-1, 3)
     return make_rays(np.broadcast_to(eye, d.shape), d)
 
@@ -176,8 +182,8 @@ def config_c3(lon=64, bands=33, lattice=(8, 8, 4), pitch=1.5, seed=0xC3):
             "eye": centre + np.array([0.0, 0.0, -(ext[2] / 2 + 14.0)]), "light": np.array([10.0, 10.0, 10.0])}
 
 
-def c3_primary_rays(cfg, width=2048, height=2048):
-    return pinhole_rays(width, height, cfg["eye"], cfg["lattice_centre"], 45.0)
+def c3_primary_rays(cfg, width=2048, height=2048, jitter_seed=None):
+    return pinhole_rays(width, height, cfg["eye"], cfg["lattice_centre"], 45.0, jitter_seed=jitter_seed)
 
 
 def c3_hit_frames(cfg, rays, hits):

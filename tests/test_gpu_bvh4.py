@@ -192,6 +192,8 @@ def test_captured_trace4_on_a_deep_tree_owns_a_spill_region(rc, oracle):
     del g
     scene.set_option("release_captures", 1)
     assert scene.get_option("release_captures") == 0
+    d_h.zero_()   # (all misses: BVH4 hit records carry no instance, the TLAS-level stage must not be fed them)
+    torch.cuda.synchronize()
     scene.shadow_rays_device(d_r.data_ptr(), d_h.data_ptr(), n, np.array([3, 3, 3], np.float32), d_sh.data_ptr(), bias=1e-3, stream=st.cuda_stream)  # after release: nothing to index
     st.synchronize()
     scene.wait_for_gpu()

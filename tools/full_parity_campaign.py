@@ -28,7 +28,7 @@ for name, t, o, r, mode in work:
     # device-resident repeats: launches 1-17 of the same batch on one stream -- fresh slot (1), recording launches (2-4, then the host's cadence:
     # 8, 15), orders rebuilt behind them (the rebuild pair in front of launches 2-6, 9, 16), orders reused in between -- for the kernels
     # that claim in a learned order, entry cull on and off, 16-bit and 32-bit lane stacks (round 5: the batch's slot is worked out inside
-    # the launch, the header is written by its last workgroup)
+    # the launch, the header is written by wave 0 of workgroup 0 at the START of the launch: order_commit)
     d_r = torch.from_numpy(r.view(np.uint8).reshape(-1)).cuda()
     d_h = torch.empty(len(r) * 32, dtype=torch.uint8, device="cuda")
     shape = 0

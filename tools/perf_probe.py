@@ -78,18 +78,21 @@ def main():
             tb.push_instances(1)
             tb.sync()
             wl_extra[key] = (f"random {nt//1000}k tris", tb, rc.generate_ray_grid(tb, (0.3, 0.2, 1.0), 1000), "closest")
-    if "hbm" in args.workloads.split(","):  # the HBM-bound regime of bench.py's extra: a 4 M-triangle BLAS (512 MB of nodes) and 4 194 304 incoherent rays
-        g = np.random.default_rng(7)
-        ro = g.random((4194304, 3))
-        rd = g.standard_normal((4194304, 3))
-        rd /= np.linalg.norm(rd, axis=1, keepdims=True)
-        tb = rc.TLAS(0)
-        dv = torch.from_numpy(sc.random_triangles(4_000_000, 42, edge=0.01)).cuda()
-        tb.add_geometry_device(dv.data_ptr(), 4_000_000)
-        tb.push_instances(1)
-        tb.sync()
-        del dv
-        wl_extra["hbm"] = ("4 M tris incoherent", tb, sc.make_rays(ro, rd), "closest")
+    # the memory-bound regimes of bench.py's extras: 4 194 304 incoherent rays on a 4 M-triangle BLAS (512 MB of nodes: beyond L2, partly in the
+    # 256 MiB Infinity Cache) and on a 16 M-triangle BLAS (2 GB of nodes: DRAM must serve)
+    for key, nt in (("hbm", 4_000_000), ("hbm16", 16_000_000)):
+        if key in args.workloads.split(","):
+            g = np.random.default_rng(7)
+            ro = g.random((4194304, 3))
+            rd = g.standard_normal((4194304, 3))
+            rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+            tb = rc.TLAS(0)
+            dv = torch.from_numpy(sc.random_triangles(nt, 42, edge=0.01)).cuda()
+            tb.add_geometry_device(dv.data_ptr(), nt)
+            tb.push_instances(1)
+            tb.sync()
+            del dv
+            wl_extra[key] = (f"{nt // 1_000_000} M tris incoherent", tb, sc.make_rays(ro, rd), "closest")
     wl = {"c2": ("C2 closest", t2, rays2, "closest"), "c3": ("C3 primary", t3, rays3, "closest"),
           "shadow": ("C3 shadow-any", t3, shadow, "any"), "c4": ("C4 bounce", t3, bounce, "closest")}
     wl.update(wl_extra)

@@ -3,12 +3,12 @@
 # (1 M tris), the 1 Mi-ray C3 view and 4 M incoherent rays on a 4 M-triangle BLAS, each in its own process and one counter set per pass (--pmc with --kernel-trace only; FETCH_SIZE / WRITE_SIZE in
 # separate passes), plus one un-profiled --kernel-trace pass for the launch duration.  The last three dispatches of the workload's kernel
 # are averaged: steady state, claim order learned from the previous launch of the same batch.
-#   tools/pmc_workloads.sh r05      ->  gpurun_out/r05/profiles/r05_pmc_workloads_kernel5.json   (copy to profiles/)
+#   tools/pmc_workloads.sh r06      ->  gpurun_out/r06/profiles/r06_pmc_workloads_kernel5.json   (copy to profiles/)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/$R/wl; P=gpurun_out/$R/profiles
 mkdir -p $O $P
-for W in c2 shadow c4 r1m c3 hbm; do
+for W in c2 shadow c4 r1m c3 hbm hbm16; do
   EXTRA=""; [ "$W" = "c3" ] && EXTRA="--c3res 1024"
   export RC_PROBE_REPS=7   # launches 5-7 of the batch are averaged: the learned order in use, none of them a recording launch (those are launches 2-4 and every 8th)
   CMD="python3 tools/perf_probe.py --variants kernel=-1 --workloads $W $EXTRA"
@@ -34,7 +34,8 @@ names = {"c2": ("BASELINE C2: 100 000-triangle BLAS, 1 000 000 coherent grid ray
          "r1m": ("random geometry, 1 000 000 triangles in one BLAS, 1 000 000 coherent grid rays, closest_hit (the reference's published benchmark shape)", 1000000, "<false"),
          "c3": ("C3 scene, 1 048 576 primary rays (1024 x 1024 pinhole), closest_hit: the mid-size batch of the headline scene", 1048576, "<false"),
          "hbm": ("the HBM-bound regime: one 4 000 000-triangle BLAS of random triangles (512 MB of nodes: beyond L2 + Infinity Cache), 4 194 304 incoherent rays "
-                 "(uniform origins in the unit cube, uniform directions, seed 7: the batch of bench.py's extra), closest_hit", 4194304, "<false")}
+                 "(uniform origins in the unit cube, uniform directions, seed 7: the batch of bench.py's extra), closest_hit", 4194304, "<false"),
+         "hbm16": ("past the Infinity Cache: one 16 000 000-triangle BLAS of random triangles (2 GB of nodes, 8 x the 256 MiB MALL), the same 4 194 304 incoherent rays, closest_hit", 4194304, "<false")}
 out = {"command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 tools/perf_probe.py --variants kernel=-1 --workloads <w> (one process per workload and counter set; tools/pmc_workloads.sh)",
        "averaged": "the last 3 dispatches of the workload's trace kernel in each pass = launches 5-7 of the same batch: the learned claim order in use, no recording (a batch records its launches 2-4 and then one in 8, which run ~7 % longer)",
        "fingerprint": bench.kernel_fingerprint(), "workloads": {}}
