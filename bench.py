@@ -42,9 +42,9 @@ HBM_RANDOM64_GBS = 2500.0  # dependent random 64-byte gathers: profiles/r02_fetc
 # 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instructions / s.  (Round 2 divided by 4 cycles -- the measured cost of v_mul / v_add /
 # v_mov -- which the builder's own probe contradicts for v_fma_f32; the per-opcode measurements now enter through `mix_ceiling`.)
 VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
-COUNTER_FILE = os.path.join("profiles", "r05_pmc_c3.json")          # per-launch PMC counters of the bench kernel (tools/capture_profiles.sh)
-WORKLOADS_FILE = os.path.join("profiles", "r05_pmc_workloads_kernel5.json")  # the same counters for the extras' workloads: C2, shadow rays, C4, random geometry, C3 1 Mi rays, the HBM-bound regime (tools/pmc_workloads.sh)
-MIX_FILE = os.path.join("profiles", "r05_isa_mix_kernel5.json")     # dynamic opcode histogram of the bench kernel x measured cycles per opcode (tools/isa_mix.py)
+COUNTER_FILE = os.path.join("profiles", "r06_pmc_c3.json")          # per-launch PMC counters of the bench kernel (tools/capture_profiles.sh)
+WORKLOADS_FILE = os.path.join("profiles", "r06_pmc_workloads_kernel5.json")  # the same counters for the extras' workloads: C2, shadow rays, C4, random geometry, C3 1 Mi rays, the HBM-bound regime (tools/pmc_workloads.sh)
+MIX_FILE = os.path.join("profiles", "r06_isa_mix_kernel5.json")     # dynamic opcode histogram of the bench kernel x measured cycles per opcode (tools/isa_mix.py)
 COUNTS_FILE = os.path.join("profiles", "c3_reference_counts.json")  # reference-algorithm fetch counts per ray for this workload (written by the N=1 run)
 # Fallback when the counts file is missing (same numbers, measured by the oracle in round 1)
 C3_NODE_FETCHES_PER_RAY = 33.006
@@ -160,6 +160,8 @@ def make_hbm_regime(rate_mrays_s, node_fetches_per_ray, n_rays, launch_ms, entry
                              "hbm_fabric_note": "FETCH_SIZE x 64 B + WRITE_SIZE: requests L2 sends to the fabric.  Infinity-Cache hits are counted, so this is an upper bound on DRAM bytes "
                                                 "(tree_bytes against the 256 MiB MALL says how loose)",
                              "achievable_random_GBs": HBM_RANDOM64_GBS, "frac_of_achievable_random": round(gbs / HBM_RANDOM64_GBS, 4),
+                             "achievable_random_note": "the builder's round-2 probe of DEPENDENT random 64-byte gathers (one chain per lane, profiles/r02_fetch_calibration.txt); a fraction above 1 says "
+                                                       "that probe was not the machine's limit for this access pattern -- the traversal keeps more independent requests in flight -- not that a roof was broken",
                              "frac_of_achievable_stream": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_stream_GBs": HBM_ACHIEVABLE_GBS, "traffic": phys,
                              "avg_launch_ms": round(secs * 1e3, 4), "launch_ms_hip_events": launch_ms,
                              "kernel": ((entry.get("kernel") or {}).get("Kernel_Name")),
@@ -500,12 +502,20 @@ def main():
             e1.synchronize()
             return e0.elapsed_time(e1) / (rounds * len(buffers))
         # the figure rounds 1-5 headlined: ONE buffer replayed, claim order learned from its earlier launches (a render loop with a still
-        # camera, repeated queries).  40 launches to learn (the reporting threshold settles after ~30), then K back to back between two events
+        # camera, repeated queries).  64 launches for the pause the headline's fresh batches caused + 120 to learn (the reporting threshold needs ~80 launches to settle on this batch), then K back to back between two events
         # -- the order-rebuild kernel pairs that precede about one launch in eight are inside the interval.
-        for _ in range(40):
+        for _ in range(64 + 120):   # the headline's never-repeating batches have put the launch shape into its 64-launch pause (order_commit): sit that out first; then ~80 launches until the reporting threshold has settled (tools/probes/repeat_vs_natural_probe.py)
             t.trace_device(d_rays.data_ptr(), dh_off.data_ptr(), n, stream=stream.cuda_stream)
         b2b_rep = back_to_back([d_rays], dh_off, rounds=args.steps)
-        extras["c3_repeated_batch"] = {"mrays_s": round(n / b2b_rep / 1e3, 1), "launches": args.steps, "hits_identical_to_the_first_launch": bool(torch.equal(dh_off, d_hits)),
+        try:
+            import ctypes
+            hdr = torch.zeros(48, dtype=torch.int32, device="cuda")
+            ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(hdr.data_ptr()), ctypes.c_void_p(t.get_option("debug_ctl_ptr")), ctypes.c_size_t(192), 3)
+            hdr = hdr.cpu().numpy()
+            rep_state = {"last_launch_fresh": int(hdr[4]), "last_launch_used_a_learned_order": int(hdr[1]), "last_launch_recorded": int(hdr[5]), "pause_launches_left": int(hdr[38]), "slot_generation": int(hdr[12 + int(hdr[0])])}
+        except Exception as e:  # noqa: BLE001
+            rep_state = {"error": str(e)[:100]}
+        extras["c3_repeated_batch"] = {"mrays_s": round(n / b2b_rep / 1e3, 1), "launches": args.steps, "hits_identical_to_the_first_launch": bool(torch.equal(dh_off, d_hits)), "order_state": rep_state,
                                        "note": "the unjittered C3 batch replayed from one buffer with the claim order learned from its own earlier launches (option cost_order, default on): "
                                                "what rounds 1-5 reported as `value`; needs an identical previous launch"}
         t.set_option("cost_order", 0)

@@ -447,7 +447,10 @@ int rc_host_register(rc_scene* scene, void* ptr, uint64_t bytes);
 int rc_host_unregister(rc_scene* scene, void* ptr);
 
 /* Timing of the most recent trace / driver launch or BLAS build (device pipeline, without staging copies) on this scene, measured with HIP events on the launch
- * stream (kernel only, no copies), in milliseconds. */
+ * stream (kernel only, no copies), in milliseconds.  For a trace launch the two events ride on the trace kernel's own dispatch: the figure is that
+ * kernel's duration and does NOT include the pair of small claim-order rebuild kernels (5 + 8 us) the library enqueues in front of about one
+ * launch in eight of a REPEATED batch (first launches enqueue nothing else).  Time a run of launches between two events of your own on the stream
+ * to include them -- bench.py does so for every repeated-batch figure. */
 int rc_last_kernel_ms(rc_scene* scene, float* ms);
 /* The same for the scene's most recent eager launches on any stream, oldest first: up to max_launches (at most 47: a launch's events live until
  * the scene's 48th launch after it) durations into ms[], their number into *n.  Waits for the launches asked about.  For a caller that

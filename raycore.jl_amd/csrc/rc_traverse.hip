@@ -550,7 +550,7 @@ void rc_claim_fill(rc_scene* s, uint64_t n_items, uint32_t total_waves, rc::RcCl
     out.g1 = (uint32_t)chunks[0]; out.g2 = (uint32_t)(chunks[0] + 2 * chunks[1]); out.g3 = (uint32_t)(chunks[0] + 2 * chunks[1] + 4 * chunks[2]);
     out.c1 = (uint32_t)chunks[0]; out.c2 = (uint32_t)(chunks[0] + chunks[1]); out.c3 = (uint32_t)(chunks[0] + chunks[1] + chunks[2]);
     out.order = nullptr; out.cost = nullptr; out.hist = nullptr;
-    out.sample_rays = nullptr; out.n_sample = 0; out.inv_l2 = 0.f; out.samples = nullptr; out.host_streak = nullptr; out.init_thr = 0; out.want_record = 0;
+    out.sample_rays = nullptr; out.n_sample = 0; out.inv_l2 = 0.f; out.samples = nullptr; out.host_streak = nullptr; out.init_thr = 0; out.want_record = 0; out.host_gen = 0;
     for (int k = 0; k < 8; ++k) out.sample_host[k] = 0.f;
     out.pool_shift = 0;
     while ((2u << out.pool_shift) <= out.pool) ++out.pool_shift;
@@ -935,7 +935,13 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
     // repeat (a new batch starts its own launches 2-4), and the launch after one this host asked to record.  Everything else about the
     // launch's claim order is decided inside the launch itself (order_select).
     volatile uint32_t* pinned = reinterpret_cast<volatile uint32_t*>(h->fresh_streak.p);  // [0] the run of non-repeats, [1] a recording waits, [2] the pause (written by order_commit at the START of a launch: as of the latest launch that has STARTED -- possibly one still in flight; benign, the rebuild kernels are stream-ordered behind it)
-    const bool paused = pinned[2] > 1u;  // (this launch and the next are still inside the pause: nothing records, nothing to rebuild)
+    // [2] = launches of the pause still to go after the launch that wrote the word | that launch's number << 8.  A caller that enqueues far ahead of the
+    // device reads an OLD word: every launch of the shape enqueued since takes one launch off the pause.  (Round 6: without the age a burst of 200
+    // launches enqueued behind a pause -- bench.py's repeated-batch extra -- stayed "paused" on the host for its whole length: the recordings of the
+    // batch's launches 2-4 were never turned into an order.)
+    const uint32_t w2 = pinned[2], skip_seen = w2 & 0xFFu, gen_seen = w2 >> 8;
+    const uint32_t since = ((uint32_t)(h->gen - 1) - gen_seen) & 0xFFFFFFu;   // launches of the shape enqueued after the one that wrote the word
+    const bool paused = skip_seen > 1u + since;  // (this launch and the next are still inside the pause: nothing records, nothing to rebuild)
     if (pinned[0] > 0u) h->rebuild_credit = 6;
     if (paused) h->rebuild_credit = 0;
     const uint32_t blocks = (n_base + kOrderTile - 1) / kOrderTile;
@@ -961,6 +967,7 @@ bool rc_cost_order_setup(rc_scene* s, uint64_t n, int any_hit, hipStream_t strea
     for (int k = 0; k < 8; ++k) c.sample_host[k] = host_sample ? host_sample[k] : 0.f;
     c.samples = h->samples.p;
     c.host_streak = h->fresh_streak.p;
+    c.host_gen = (uint32_t)h->gen & 0xFFFFFFu;
     c.init_thr = (uint32_t)s->opt.cost_thr;
     c.order = h->order.p;
     c.cost = h->cost.p;

@@ -74,9 +74,11 @@ struct RcClaim {
     float sample_host[8];
     float inv_l2;                  // 1 / (scene diagonal)^2: origins are compared relative to the scene
     float* samples;                // 2 copies x kHistSlots x kHistSamples remembered sample rays (8 floats each)
-    uint32_t* host_streak;         // pinned words for the host's decision about the rebuild kernels: [0] the run of launches that were not repeats, [1] a recording waits, [2] launches of a pause still to go
+    uint32_t* host_streak;         // pinned words for the host's decision about the rebuild kernels: [0] the run of launches that were not repeats, [1] a recording waits, [2] launches of a pause still to go | host_gen << 8
     uint32_t init_thr;             // reporting threshold a batch starts with
     uint32_t want_record;          // the host's cadence: a slot past its fourth launch records in this launch
+    uint32_t host_gen;             // the host's count of launches of this shape (24 bits): written back next to the pause word, so that a host that has enqueued
+                                   // far ahead of the device knows HOW OLD the pause count it reads is (each launch since takes one off it)
 };
 // A history (rc_scene::ChunkHistory) remembers up to kHistSlots different BATCHES of one launch shape, told apart on the device by
 // kHistSamples sample rays (VERDICT r3 #5a: two cameras alternating on one stream each learn from their OWN previous launch, and a
@@ -225,7 +227,7 @@ __device__ inline void order_commit(const RcClaim& c, const OrderDecision& o, in
         const uint32_t left = old_h[kHistSkipLeft] - 1u;
         put(kHistSkipLeft, left);
         if (lane < kHistHeaderWords) new_h[lane] = w;
-        if (lane == 0 && c.host_streak) __hip_atomic_store(c.host_streak + 2, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0 && c.host_streak) __hip_atomic_store(c.host_streak + 2, left | (c.host_gen << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     const uint32_t clock = old_h[kHistClock] + 1u;
@@ -251,7 +253,7 @@ __device__ inline void order_commit(const RcClaim& c, const OrderDecision& o, in
     if (lane == 0 && c.host_streak) {
         __hip_atomic_store(c.host_streak, streak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(c.host_streak + 1, any_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(c.host_streak + 2, skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(c.host_streak + 2, skip | (c.host_gen << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (skip <= kGiveUpFor = 64: 8 bits)
     }
 }
 

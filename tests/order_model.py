@@ -13,7 +13,10 @@ A launch is described by what order_select can see of it: `batch` (any hashable:
 (a set of batch ids whose sample rays are within the matching threshold of this launch's without being identical: the frame before of a
 moving camera).  Data-dependent words (the reporting threshold and the scale of the cost classes) are outside the model: it says WHETHER a
 launch records, not with which threshold.  The model assumes the caller waits for every launch (the pinned words the host reads are then
-current); a caller that enqueues far ahead sees them late, which delays a rebuild and changes no result.
+current); a caller that enqueues far ahead sees them late, which delays a rebuild and changes no result -- except for the pause count, which
+used to keep such a caller "paused" on the host for as long as it did not wait: since round 6 the word carries the number of the launch that
+wrote it and the host takes one launch off for every launch enqueued since (tests/test_gpu_order_model.py::
+test_a_caller_that_enqueues_far_ahead_still_gets_its_order).
 """
 
 K_SLOTS = 4                    # kHistSlots

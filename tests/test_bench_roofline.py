@@ -128,14 +128,14 @@ def test_workload_rooflines_recompute_from_the_workloads_file():
     wl = json.load(open(os.path.join(ROOT, b.WORKLOADS_FILE)))
     pmc = json.load(open(os.path.join(ROOT, b.COUNTER_FILE)))
     assert wl["fingerprint"]["sha256"] == pmc["fingerprint"]["sha256"]          # both captured from the same kernel sources
-    assert set(wl["workloads"]) >= {"c2", "shadow", "c4", "r1m", "c3", "hbm"}
+    assert set(wl["workloads"]) >= {"c2", "shadow", "c4", "r1m", "c3", "hbm", "hbm16"}
     for key, e in wl["workloads"].items():
         c = e["counters_mean_per_launch"]
         ms = e["kernel_stats"]["average_ns"] * 1e-6
         r = b.make_workload_roofline(e, ms, e["n_rays"], True)
         achieved = c["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9
         assert r["bound"] == "valu-issue" and r["peak"] == 1228.8 and abs(r["achieved"] - achieved) < 0.1, key
-        assert abs(r["frac"] - achieved / 1228.8) < 1e-3 and (0.05 if key == "hbm" else 0.1) < r["frac"] < 0.6, (key, r["frac"])   # (the HBM-bound regime issues least: its waves wait for memory)
+        assert abs(r["frac"] - achieved / 1228.8) < 1e-3 and (0.02 if key.startswith("hbm") else 0.1) < r["frac"] < 0.6, (key, r["frac"])   # (the HBM-bound regime issues least: its waves wait for memory)
         lane = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)
         assert abs(r["lane_utilisation"] - lane) < 1e-3 and 0.2 < lane < 0.7, (key, lane)
         assert abs(r["lane_throughput_frac"] - r["frac"] * lane) < 1e-3
@@ -154,28 +154,38 @@ def test_workload_rooflines_recompute_from_the_workloads_file():
     assert fr["c4"] > fr["c2"] and fr["c4"] > fr["r1m"]
 
 
-def test_hbm_regime_roofline_recomputes_from_the_workloads_file():
-    """north_star's ">= 40 % HBM-roofline" is only meaningful where HBM binds -- a 4 M-triangle BLAS (512 MB of nodes) under
-    4 M incoherent rays.  The physical bytes per launch come from the FETCH_SIZE / WRITE_SIZE passes of THIS round's kernels (fingerprinted like
-    every counter file); bench.py turns them into a roofline object with bound "hbm" and refuses counters of other kernel sources."""
+def test_memory_bound_regimes_recompute_from_the_workloads_file():
+    """north_star's ">= 40 % HBM-roofline" is only testable where memory binds -- 4 M incoherent rays on a 4 M-triangle BLAS
+    (512 MB of nodes: beyond L2, half of it inside the 256 MiB Infinity Cache) and on a 16 M-triangle BLAS (2 GB: DRAM must serve).  What binds
+    those launches is the texture data path (TD ~0.98 busy), so the roofline object says bound "texture-path" with TD busy as its fraction, and
+    carries the memory side as `hbm_fabric_frac` -- FETCH_SIZE counts Infinity-Cache hits, so it is an upper bound on DRAM traffic -- next to the
+    builder's own 2.5 TB/s ceiling for dependent random 64-byte gathers.  Recomputed here from this round's fingerprinted counter file."""
     b = bench_module()
     wl = json.load(open(os.path.join(ROOT, b.WORKLOADS_FILE)))
-    e = wl["workloads"]["hbm"]
-    ms = e["kernel_stats"]["average_ns"] * 1e-6
-    rate = e["n_rays"] / ms / 1e3                                   # Mrays/s of the un-profiled trace pass
-    fetches = 97.5                                                  # node fetches per ray (bench.py measures them live with the STATS kernel)
-    out = b.make_hbm_regime(rate, fetches, e["n_rays"], ms, e, True)
-    r = out["roofline"]
-    c = e["counters_mean_per_launch"]
-    phys = c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024          # x1: random 64-byte gathers (profiles/r02_fetch_calibration.txt)
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["traffic"] - phys) < 1.0
-    gbs = phys / (ms * 1e-3) / 1e9
-    assert abs(r["achieved"] - gbs) < 0.1 and abs(r["frac"] - gbs / 8000.0) < 1e-3 and abs(r["frac_of_achievable"] - gbs / 6300.0) < 1e-3
-    assert 0.40 <= r["frac"] < 0.6                                  # the north star's figure, answered from current counters
-    assert abs(out["fetch_amplification"] - phys / ((64 + 60 * fetches + 140) * e["n_rays"])) < 1e-3 and 0.6 < out["fetch_amplification"] < 1.1   # no wasted re-reads
-    assert c["TCC_MISS_sum"] > 2 * c["TCC_HIT_sum"]                 # the regime really is beyond the caches
-    assert "<false" in r["kernel"] and b.WORKLOADS_FILE in json.dumps(r["sources"])
-    # counters of other kernel sources, or none: no physical figure, and the extra says why
-    for entry, ok in ((e, False), (None, True), ({}, True)):
-        o2 = b.make_hbm_regime(rate, fetches, e["n_rays"], ms, entry, ok)
-        assert o2["roofline"] is None and o2["hbm_physical_frac"] is None and "fingerprint" in o2["note"] and o2["mrays_s"] == rate
+    fr = {}
+    for key, fetches, tree in (("hbm", 97.5, 511999936), ("hbm16", 182.1, 2047999936)):   # node fetches per ray: bench.py measures them live with the STATS kernel
+        e = wl["workloads"][key]
+        ms = e["kernel_stats"]["average_ns"] * 1e-6
+        rate = e["n_rays"] / ms / 1e3                               # Mrays/s of the un-profiled trace pass
+        out = b.make_hbm_regime(rate, fetches, e["n_rays"], ms, e, True, key=key, tree_bytes=tree)
+        r = out["roofline"]
+        c = e["counters_mean_per_launch"]
+        td = c["TD_TD_BUSY_sum"] / c["GRBM_GUI_ACTIVE"] / 32.0
+        ta = c["TA_TA_BUSY_sum"] / c["GRBM_GUI_ACTIVE"] / 32.0
+        assert r["bound"] == "texture-path" and abs(r["frac"] - td) < 1e-3 and abs(r["td_busy_frac"] - td) < 1e-3 and abs(r["ta_busy_frac"] - ta) < 1e-3
+        assert 0.9 < td <= 1.0 and 0.85 < ta <= 1.0, (key, td, ta)      # the texture path is what is saturated
+        assert r["valu_issue_frac"] < 0.15                              # ... not the VALU
+        phys = c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024          # x1: random 64-byte gathers (profiles/r02_fetch_calibration.txt)
+        gbs = phys / (ms * 1e-3) / 1e9
+        assert abs(r["traffic"] - phys) < 1.0 and abs(r["hbm_fabric_GBs"] - gbs) < 0.1 and r["hbm_peak_GBs"] == 8000.0
+        assert abs(r["hbm_fabric_frac"] - gbs / 8000.0) < 1e-3 and abs(r["frac_of_achievable_random"] - gbs / 2500.0) < 1e-3 and abs(r["frac_of_achievable_stream"] - gbs / 6300.0) < 1e-3
+        assert r["achievable_random_GBs"] == 2500.0 and "Infinity-Cache" in r["hbm_fabric_note"] and out["tree_bytes"] == tree
+        assert abs(out["fetch_amplification"] - phys / ((64 + 60 * fetches + 140) * e["n_rays"])) < 1e-3 and 0.5 < out["fetch_amplification"] < 1.2   # no wasted re-reads
+        assert c["TCC_MISS_sum"] > 2 * c["TCC_HIT_sum"]                 # beyond L2
+        assert "<false" in r["kernel"] and b.WORKLOADS_FILE in json.dumps(r["sources"])
+        fr[key] = r["hbm_fabric_frac"]
+        for entry, ok in ((e, False), (None, True), ({}, True)):        # counters of other kernel sources, or none: no physical figure, and the extra says why
+            o2 = b.make_hbm_regime(rate, fetches, e["n_rays"], ms, entry, ok, key=key)
+            assert o2["roofline"] is None and o2["hbm_physical_frac"] is None and "fingerprint" in o2["note"] and o2["mrays_s"] == rate
+    # the north star's ">= 40 % of the HBM roofline", answered at both points from current counters: fabric-side where the MALL still helps, DRAM-side where it cannot
+    assert fr["hbm"] >= 0.40 and fr["hbm16"] >= 0.40, fr

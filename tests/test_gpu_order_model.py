@@ -98,3 +98,30 @@ def test_shapes_and_streams_keep_separate_histories(rc, oracle):
                                ("side", n, side.cuda_stream), ("full", n, 0), ("short", n - 8192, 0), ("side", n, side.cuda_stream), ("full", n, 0)):
         go(key, count, stream)
     t.free()
+
+
+def test_a_caller_that_enqueues_far_ahead_still_gets_its_order(rc, oracle):
+    """Round 6: the host half decides about the rebuild kernels from pinned words the device writes -- words a caller that never waits reads LATE.
+    The pause count is therefore written together with the number of the launch that wrote it, and the host takes one launch off it for every
+    launch enqueued since.  Ten never-repeating batches (the shape pauses for 64 launches), then 64 + 40 launches of ONE batch and not a single
+    synchronisation in between: the batch must end up traced in an order learned from its own recordings (before the fix the host saw "paused" for the
+    whole burst, nothing was ever rebuilt, and the repeated batch ran in natural order for as long as the caller did not wait -- bench.py's
+    repeated-batch extra did exactly that)."""
+    import torch
+    rig = Rig(rc, oracle)
+    t = build_product(rc, rig.cfg)
+    bufs = [rig.rays(100 + k, False) for k in range(10)]
+    d, want, n = rig.rays(3, True)
+    out = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for b, _, nb in bufs:
+        t.trace_device(b.data_ptr(), out.data_ptr(), nb)
+    for _ in range(64 + 40):
+        t.trace_device(d.data_ptr(), out.data_ptr(), n)
+    torch.cuda.synchronize()
+    h = rig.header(t)
+    assert h["skip_left"] == 0 and h["fresh"] == 0 and h["gen"][h["sel"]] >= 30, h
+    assert h["has_order"][h["sel"]] == 1 and h["order_valid"] == 1, f"the burst never got its recordings rebuilt into an order: {h}"
+    assert_hits_equal(out.cpu().numpy().view(rc.HIT_DT), want, "last launch of the burst")
+    assert t.get_option("claim_drift") == 0
+    t.free()

@@ -13,12 +13,12 @@ with the dynamic histogram built here from three committed inputs:
     switch / finish phases; the marker build must have the same VALU instruction count and register use as the product build -- checked),
     VALU opcodes counted per phase;
   * how often a wave runs each phase: the pass counters of the kernel's STATS instantiation (tools/phase_passes.py on the GPU box,
-    profiles/r05_phase_passes_kernel5.json);
+    profiles/r06_phase_passes_kernel5.json);
   * cycles per opcode: profiles/r02_valu_probe.txt (tools/archive/valu_probe.hip), ns per wave-instruction per SIMD x 2.4 GHz.
 The prediction sum(passes x static count) is compared with the measured SQ_INSTS_VALU of the counter file: that is the check that the
 histogram describes what ran.
 
-    python3 tools/isa_mix.py [--workload c3] > profiles/r05_isa_mix_kernel5.json
+    python3 tools/isa_mix.py [--workload c3] > profiles/r06_isa_mix_kernel5.json
 """
 import argparse
 import collections
@@ -164,8 +164,8 @@ def cycles3(op, table, which):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c3")
-    ap.add_argument("--passes", default=os.path.join(ROOT, "profiles", "r05_phase_passes_kernel5.json"))
-    ap.add_argument("--counters", default=os.path.join(ROOT, "profiles", "r05_pmc_c3.json"))
+    ap.add_argument("--passes", default=os.path.join(ROOT, "profiles", "r06_phase_passes_kernel5.json"))
+    ap.add_argument("--counters", default=os.path.join(ROOT, "profiles", "r06_pmc_c3.json"))
     args = ap.parse_args()
     marked, meta_m = assembly(True)
     plain, meta_p = assembly(False)

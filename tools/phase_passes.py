@@ -1,7 +1,7 @@
 """How often a wave of the dominant trace kernel runs each of its phases, per launch (GPU box): kernel 5's STATS instantiation
 (option "stats") counts, per wave and summed over the launch, the interior-loop iterations, the leaf / switch / refill passes that
 had at least one lane to serve, the lanes served, and the outer iterations.  tools/isa_mix.py weights the static opcode histogram of
-each phase with these.  python3 tools/phase_passes.py > profiles/r05_phase_passes_kernel5.json"""
+each phase with these.  python3 tools/phase_passes.py > profiles/r06_phase_passes_kernel5.json"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

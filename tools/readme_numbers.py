@@ -50,9 +50,17 @@ def block(rel, b):
     L = [BEGIN, f"Measured on one MI355X; every figure below is read from `{rel}` (truncated, not rounded):", ""]
     L.append("| workload | Grays/s |")
     L.append("|---|---|")
-    L.append(f"| **C3** — 1 048 576-triangle instanced TLAS, 4 194 304 primary rays, `closest_hit`, the batch repeated (`value`; {b['ms_per_step']:.4f} ms per step) | **{g(b['value'])}** |")
-    if b.get("first_touch_value"):
-        L.append(f"| the same batch traced for the first time (natural claim order; `first_touch_value`) | {g(b['first_touch_value'])} |")
+    if "repeated_value" in b:   # round 6 on: `value` is the first launch of a batch
+        L.append(f"| **C3** — 1 048 576-triangle instanced TLAS, 4 194 304 primary rays, `closest_hit`, every launch a batch never traced before, rays read from HBM "
+                 f"(`value`; {b['ms_per_step']:.4f} ms per step) | **{g(b['value'])}** |")
+        if b.get("same_buffer_natural_order_value"):
+            L.append(f"| ... one cache-warm ray buffer, natural claim order (`same_buffer_natural_order_value`; rounds 4-5's `first_touch_value`) | {g(b['same_buffer_natural_order_value'])} |")
+        if b.get("repeated_value"):
+            L.append(f"| ... one buffer replayed with the claim order learned from its earlier launches (`repeated_value`; rounds 1-5's `value`) | {g(b['repeated_value'])} |")
+    else:
+        L.append(f"| **C3** — 1 048 576-triangle instanced TLAS, 4 194 304 primary rays, `closest_hit`, the batch repeated (`value`; {b['ms_per_step']:.4f} ms per step) | **{g(b['value'])}** |")
+        if b.get("first_touch_value"):
+            L.append(f"| the same batch traced for the first time (natural claim order; `first_touch_value`) | {g(b['first_touch_value'])} |")
     if b.get("moving_camera_value"):
         L.append(f"| a camera that moves every frame (`moving_camera_value`) | {g(b['moving_camera_value'])} |")
     rows = [("c3_any_hit_shadow_mrays_s", "C3 shadow rays, `any_hit`, 2.08 M rays"), ("c3_any_hit_shadow_first_launch_mrays_s", "... first launch"),
@@ -62,6 +70,9 @@ def block(rel, b):
     for k, name in rows:
         if isinstance(e.get(k), (int, float)):
             L.append(f"| {name} | {g(e[k])} |")
+    b4 = e.get("c2_4_independent_batches_one_call") or {}
+    if b4.get("mrays_s"):
+        L.append(f"| four independent C2-sized batches in ONE call (`rc_trace_closest_device_batches`; one after the other: {g(b4['one_after_the_other_mrays_s'])}) | {g(b4['mrays_s'])} |")
     big = e.get("c3_blas_more_instances_closest") or {}
     for k in sorted(big, key=int):
         L.append(f"| {k} instances of the C3 BLAS ({big[k]['triangles']:,} triangles) | {g(big[k]['mrays_s'])} |".replace(",", " "))
@@ -83,10 +94,16 @@ def block(rel, b):
         hm = (vf.get("host_matrix_e2e") or {})
         if parts:
             L.append(f"`view_factors` at C5 ({vf.get('n_prims')} triangles, {vf.get('n_rays', 0) / 1e6:.1f} M rays): " + ", ".join(parts) + ".")
-    h = e.get("hbm_regime_4M_tris_4M_incoherent_rays") or {}
-    if h.get("roofline"):
-        L.append(f"Where HBM binds (4 M-triangle BLAS, 4 M incoherent rays): {g(h['mrays_s'])} Grays/s at {h['roofline']['achieved']:.0f} GB/s of physical HBM traffic "
-                 f"= {h['roofline']['frac']:.2f} of the 8 TB/s peak, {h['roofline']['frac_of_achievable']:.2f} of the achievable 6.3.")
+    for key, what in (("hbm_regime_4M_tris_4M_incoherent_rays", "4 M-triangle BLAS (512 MB of nodes)"), ("hbm_regime_16M_tris_4M_incoherent_rays", "16 M-triangle BLAS (2 GB of nodes, past the 256 MiB Infinity Cache)")):
+        h = e.get(key) or {}
+        rf = h.get("roofline") or {}
+        if rf.get("bound") == "texture-path":
+            L.append(f"Memory-bound regime, {what}, 4 M incoherent rays: {g(h['mrays_s'])} Grays/s; bound by the texture data path (TD {rf['td_busy_frac']:.2f} busy); "
+                     f"{rf['hbm_fabric_GBs']:.0f} GB/s requested from the fabric = {rf['hbm_fabric_frac']:.2f} of the 8 TB/s HBM peak (Infinity-Cache hits included), "
+                     f"{rf['frac_of_achievable_random']:.2f} x the 2.5 TB/s of the round-2 probe of DEPENDENT random 64-byte gathers (which was therefore not the machine's limit for this pattern).")
+        elif rf:
+            L.append(f"Where HBM binds ({what}, 4 M incoherent rays): {g(h['mrays_s'])} Grays/s at {rf['achieved']:.0f} GB/s of physical HBM traffic "
+                     f"= {rf['frac']:.2f} of the 8 TB/s peak, {rf['frac_of_achievable']:.2f} of the achievable 6.3.")
     if r.get("frac"):
         L.append(f"Headline kernel: VALU issue {r['frac']:.2f} of the guide's 2-cycle peak, {r.get('lane_utilisation', 0):.2f} of the issued lanes carry a ray, "
                  f"waves waiting {r.get('waiting_frac_of_wave_cycles') or 0:.2f} of their cycles, texture-data path {r.get('td_busy_frac') or 0:.2f} busy, physical HBM {r.get('hbm_physical_frac') or 0:.2f} of peak.")
