@@ -291,9 +291,11 @@ def main():
     # library -- default options, as shipped -- runs each in natural claim order and records nothing; the rays come from HBM, not from a
     # buffer kept warm in the Infinity Cache.  The repeated-buffer figure of rounds 1-5 (one buffer replayed, claim order learned from its
     # earlier launches) is extras.c3_repeated_batch -> "repeated_value".
-    n_fresh = args.warmup + args.steps
-    if n_fresh > 256:
-        raise SystemExit("--warmup + --steps above 256: every step traces its own 32 B/ray batch (134 MB at the default size); lower them")
+    CLOCK_WARM = 40   # untimed launches in front of the W warm-up steps (below): first launches of their own batches too, so that EVERY dispatch of the
+                      # trace kernel in this command -- what `rocprofv3 --kernel-trace --stats` averages -- is what the timed steps are
+    n_fresh = CLOCK_WARM + args.warmup + args.steps
+    if n_fresh > 512:
+        raise SystemExit("--warmup + --steps above 472: every launch traces its own 32 B/ray batch (134 MB at the default size); lower them")
 
     def fresh_batch(seed):
         """c3_primary_rays(jitter_seed=...) restated on the device (float64 like the numpy version; the batch used for the bit-exact check is
@@ -333,13 +335,13 @@ def main():
             torch.cuda.synchronize()
 
     # Untimed: bring the GPU clocks up before the W warm-up steps (a cold MI355X runs its first few dozen milliseconds of kernels
-    # ~10 % slower; with small W and K that would be what gets timed).  These launches replay the unjittered C3 batch (the extras' batch).
+    # ~10 % slower; with small W and K that would be what gets timed).
     with rc.profile_range("headline:warmup"):
-        for _ in range(40):
-            t.trace_device(d_rays.data_ptr(), d_hits.data_ptr(), n, mode="closest", stream=stream.cuda_stream)
+        for i in range(CLOCK_WARM):
+            step(i)
         torch.cuda.synchronize()
         for i in range(args.warmup):
-            step(i)
+            step(CLOCK_WARM + i)
     # Every launch carries its own two HIP events on its kernel's dispatch (hipExtLaunchKernelGGL binds them to the kernel's start and end on
     # the launch stream): the K durations are read back after the timed region (rc_recent_kernel_ms keeps the last 47 launches').  More steps
     # than that: torch events around every step, as in rounds 1-4 -- two event packets per step, ~6 us, inside the timed region.
@@ -352,14 +354,20 @@ def main():
     rc.lib().rc_range_push(b"headline:timed_steps")
     if own_events:
         for i in range(args.steps):
-            step(args.warmup + i)
+            step(CLOCK_WARM + args.warmup + i)
     else:
         for i, (a, b) in enumerate(ev):
             a.record(stream)
-            step(args.warmup + i)
+            step(CLOCK_WARM + args.warmup + i)
             b.record(stream)
-    fence()
+    # closing bracket: this rank's K steps are complete when its device has drained -- that is where its clock stops; the barrier that follows (every rank
+    # has finished before anything else happens) is a collective of its own, ~1 ms even on a one-rank communicator (gpurun_out/r06camp: 5 steps measured
+    # 0.73 ms per step with it inside the interval against 0.54 without), and is not part of the steps.  The job's time is the MAX over the ranks.
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
     rc.lib().rc_range_pop()
     if own_events:
         per_step = t.recent_kernel_ms(args.steps)

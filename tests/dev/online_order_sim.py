@@ -240,6 +240,26 @@ def workload(name):
     return cost, int(round(row)), measured
 
 
+READING = """# Reading (VERDICT r5 'next' #2: "build only if the simulation recovers >= 40 % of the LPT gain").
+# * The model is trustworthy where it can be checked: the LPT gain it predicts for C2 (+10.6 %) is the one measured on the GPU in round 3 with the chunks physically
+#   reordered (0.402 -> 0.363 ms, +10.7 %, profiles/r03_lpt_upper_bound.txt); for the shadow batch and C3 at 1 Mi rays it predicts +12 % / +10 % where +19 % / +21 % were
+#   measured -- it under-states gains there, it does not invent them.
+# * Neighbour promotion recovers 0 %.  A 1 M-ray launch has 7 813 chunks for 6 144 waves and deals all of them in parts (taper 12): the waves' FIRST claims take chunks
+#   0 .. 3 071, the first wave is out of work at 102-139 us of 250-418, and by then every previous / next chunk and every chunk one image row up or down of a chunk
+#   that has reported a long ray (or holds one that is already old) has been claimed: "promoted 0" in every variant.  The shadow batch (16 230 chunks) promotes 1.
+# * Looking further -- the nearest UNCLAIMED chunks of the same image column, which at that point lie tens to hundreds of rows below -- promotes 1 500-4 600 chunks and LOSES
+#   8-23 %: cost is not coherent over that distance, and a promoted chunk is claimed whole where the taper would have dealt it in eighths.
+# * The bound of ANY in-launch scheme (late-LPT: perfect knowledge of every chunk still unclaimed after the first round) is +5.3 % C2, +4.4 % random 1 M, +6.1 % shadow,
+#   +13 % C3 1 Mi: about half of the LPT gain, because the other half is long rays that sat in first-round chunks and could only have been started earlier by knowing them
+#   before the launch.  A predictor good enough to collect that half needs samples spread over the whole image in the first round -- i.e. a strided / interleaved first round,
+#   which by itself costs 5-6 % on these batches (profiles/r05_chunk_order_probe.txt: no static permutation beats the natural order) -- or a pre-pass, which costs the
+#   15-25 us it saves (round 4).  The box-count predictor of round 4 (rank correlation 0.94 / 0.66 / 0.60 / 0.23 with the true chunk cost on C2 / random 1 M / C3 1 Mi /
+#   shadow) applied to the late chunks only would net about +4 / +2.5 / +7 / +1 % before its own cost.
+# * Not built.  The first-launch targets of the verdict (C2 >= 2.65, random 1 M >= 2.55, shadow >= 5.9 Grays/s) are not reachable by reordering claims inside the launch;
+#   what a first launch of a mid-size batch can still use is overlap with OTHER launches (rc_trace_*_device_batches, round 6: +21 % for four C2-sized batches).
+"""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="c2,r1m,c3_1mi,shadow")
@@ -285,7 +305,7 @@ def main():
                     f"  (promoted {st['promoted']}, claimed from the list {st['claimed_from_prio']}, skipped {st['skipped']})")
         lines.append(f"   ({time.time() - t0:.0f} s)")
         lines.append("")
-    open(args.out, "w").write("\n".join(lines) + "\n")
+    open(args.out, "w").write("\n".join(lines) + "\n" + (READING if args.workloads == "c2,r1m,c3_1mi,shadow" else ""))   # (the reading belongs to the full table)
 
 
 if __name__ == "__main__":
