@@ -24,6 +24,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <thread>
 
 #include "../../include/raycore_mi355x.h"
@@ -221,7 +222,13 @@ struct Rccl {
 constexpr int kNcclUint32 = rc_rccl::kUint32, kNcclUint64 = rc_rccl::kUint64, kNcclSum = rc_rccl::kSum;
 std::mutex g_rccl_mu;
 Rccl g_rccl;
-std::map<std::vector<int>, std::vector<comm_t>> g_comms;  // one communicator set per device list, kept for the life of the process
+// One communicator set per device list, created on first use and kept for the life of the process -- or until a collective on it fails.  A job holds a
+// reference for its duration, so a set that another thread's failure takes out of the cache is destroyed only when its last user is done with it.
+struct CommSet {
+    std::vector<comm_t> comm;
+    ~CommSet();
+};
+std::map<std::vector<int>, std::shared_ptr<CommSet>> g_comms;
 
 // Environment RC_RCCL_LIBRARY names the RCCL build to use (a path or a soname; once a process has mapped some other librccl.so -- torch
 // brings its own -- LD_LIBRARY_PATH no longer decides which one dlopen("librccl.so") returns).  When it is set nothing else is tried: a
@@ -257,26 +264,28 @@ void nccl_ok(int rc, const char* what) {
     if (rc != rc_rccl::kSuccess) throw RcError(RC_ERR_HIP, std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
 }
 
-// The communicator set of a device list (rank g = devs[g]), created on first use and kept for the life of the process.
-std::vector<comm_t> comms_for(const std::vector<int>& devs) {
+// The communicator set of a device list (rank g = devs[g]).
+std::shared_ptr<CommSet> comms_for(const std::vector<int>& devs) {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     Rccl& r = rccl();
     auto it = g_comms.find(devs);
     if (it == g_comms.end()) {
-        std::vector<comm_t> fresh(devs.size());
-        nccl_ok(r.CommInitAll(fresh.data(), (int)devs.size(), devs.data()), "ncclCommInitAll");
+        auto fresh = std::make_shared<CommSet>();
+        fresh->comm.resize(devs.size());
+        nccl_ok(r.CommInitAll(fresh->comm.data(), (int)devs.size(), devs.data()), "ncclCommInitAll");
         it = g_comms.emplace(devs, fresh).first;
     }
     return it->second;
 }
-// A communicator set whose collective failed is not used again (RCCL leaves it in an undefined state): forget and destroy it, the next
-// call builds a fresh one.
-void drop_comms(const std::vector<int>& devs) {
+CommSet::~CommSet() {
+    if (g_rccl.CommDestroy) for (comm_t c : comm) if (c) (void)g_rccl.CommDestroy(c);
+}
+// A communicator set whose collective failed is not used again (RCCL leaves it in an undefined state): forget it -- the next call builds a
+// fresh one; it is destroyed when the last job that still holds it lets go.
+void drop_comms(const std::vector<int>& devs, const std::shared_ptr<CommSet>& failed) {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     auto it = g_comms.find(devs);
-    if (it == g_comms.end()) return;
-    if (g_rccl.CommDestroy) for (comm_t c : it->second) (void)g_rccl.CommDestroy(c);
-    g_comms.erase(it);
+    if (it != g_comms.end() && it->second == failed) g_comms.erase(it);
 }
 // ncclGroupStart ... ncclGroupEnd around the per-rank calls of one collective; an exception between the two still closes the group
 // (this thread's later RCCL calls would otherwise be queued for ever).
@@ -360,7 +369,8 @@ static void multi_rays(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_
     for (int g = 0; g < n_scenes; ++g) devs[g] = scenes[g]->device;
     if (!distinct_devices(scenes, n_scenes))
         throw RcError(RC_ERR_INVALID_ARGUMENT, "RC_VF_MODE_RAYS reduces over RCCL, which needs one DISTINCT device per scene (use RC_VF_MODE_ROWS for several scenes on one device)");
-    const std::vector<comm_t> comms = comms_for(devs);
+    const std::shared_ptr<CommSet> comm_set = comms_for(devs);
+    const std::vector<comm_t>& comms = comm_set->comm;
     const uint32_t C = chunk_rows_for(scenes[0], n, n), n_chunks = (n + C - 1) / C;
     std::vector<DeviceJob> jobs(n_scenes);
     std::vector<DevBuf<uint32_t>> acc(n_scenes);
@@ -445,7 +455,7 @@ static void multi_rays(rc_scene* const* scenes, int n_scenes, uint32_t rays_per_
     } catch (...) {
         abort_copies.store(true, std::memory_order_release);
         copier.join();
-        drop_comms(devs);
+        drop_comms(devs, comm_set);
         throw;
     }
     copier.join();
@@ -493,8 +503,10 @@ void rc_view_factor_totals_multi_impl(rc_scene* const* scenes, int n_scenes, uin
     const bool use_rccl = n_scenes > 1 && distinct_devices(scenes, n_scenes);
     std::vector<int> devs(n_scenes);
     for (int g = 0; g < n_scenes; ++g) devs[g] = scenes[g]->device;
-    std::vector<comm_t> comms;
-    if (use_rccl) comms = comms_for(devs);
+    std::shared_ptr<CommSet> comm_set;
+    if (use_rccl) comm_set = comms_for(devs);
+    static const std::vector<comm_t> no_comms;
+    const std::vector<comm_t>& comms = comm_set ? comm_set->comm : no_comms;
     std::vector<hipStream_t> stream(n_scenes, nullptr);
     hipEvent_t t_begin = nullptr, t_end = nullptr;
     RC_HIP(hipSetDevice(scenes[0]->device));
@@ -523,7 +535,7 @@ void rc_view_factor_totals_multi_impl(rc_scene* const* scenes, int n_scenes, uin
             group.end();
         } catch (...) {
             for (int g = 0; g < n_scenes; ++g) { (void)hipSetDevice(scenes[g]->device); (void)hipStreamSynchronize(stream[g]); }  // the traces in flight write the scenes' staging vectors
-            drop_comms(devs);
+            drop_comms(devs, comm_set);
             throw;
         }
     }
@@ -575,8 +587,10 @@ void rc_multi_prepare_impl(rc_scene* const* scenes, int n_scenes, float out_ms[4
     std::vector<int> devs(n_scenes);
     for (int g = 0; g < n_scenes; ++g) devs[g] = scenes[g]->device;
     auto t0 = now();
-    std::vector<comm_t> comms;
-    if (use_rccl) comms = comms_for(devs);
+    std::shared_ptr<CommSet> comm_set;
+    if (use_rccl) comm_set = comms_for(devs);
+    static const std::vector<comm_t> no_comms;
+    const std::vector<comm_t>& comms = comm_set ? comm_set->comm : no_comms;
     const float ms_comm = ms_since(t0);
     t0 = now();
     for_each_scene(scenes, n_scenes, [&](int g) {
@@ -596,7 +610,7 @@ void rc_multi_prepare_impl(rc_scene* const* scenes, int n_scenes, float out_ms[4
             for (int g = 0; g < n_scenes; ++g)
                 nccl_ok(r.Reduce(scenes[g]->u64_stage.p, scenes[g]->u64_stage.p, (size_t)2 * n, kNcclUint64, kNcclSum, 0, comms[g], scenes[g]->aux_streams[0]), "ncclReduce");
             group.end();
-        } catch (...) { drop_comms(devs); throw; }
+        } catch (...) { drop_comms(devs, comm_set); throw; }
         for (int g = 0; g < n_scenes; ++g) { RC_HIP(hipSetDevice(scenes[g]->device)); RC_HIP(hipStreamSynchronize(scenes[g]->aux_streams[0])); }
     }
     const float ms_warm = use_rccl ? ms_since(t0) : 0.f;
