@@ -257,6 +257,15 @@ READING = """# Reading (VERDICT r5 'next' #2: "build only if the simulation reco
 #   shadow) applied to the late chunks only would net about +4 / +2.5 / +7 / +1 % before its own cost.
 # * Not built.  The first-launch targets of the verdict (C2 >= 2.65, random 1 M >= 2.55, shadow >= 5.9 Grays/s) are not reachable by reordering claims inside the launch;
 #   what a first launch of a mid-size batch can still use is overlap with OTHER launches (rc_trace_*_device_batches, round 6: +21 % for four C2-sized batches).
+#
+# Appendix (tests/dev/coarse_first_round_sim.py, same model): the one scheme that WOULD give a first launch knowledge about unclaimed chunks -- a strided first round
+# (every s-th image row, so that every later chunk has a first-round neighbour <= s/2 rows away in its column) followed by claims in the order of the neighbours'
+# running cost estimates, idealised (one global priority queue, estimates exact at every refill, whole chunks):
+#   C3 2048 x 2048 (natural, taper 12: 504.9 us; LPT 460.4, +9.7 %; late-LPT +9.3 %):  s = 6: 486.2 us (+3.8 %), s = 8: 481.7 (+4.8 %), s = 16: 495.0 (+2.0 %);
+#                                                                                      with a PERFECT predictor behind the strided round: +5.3 / +6.8 / +6.4 %
+#   C3 1024 x 1024 (natural, taper 12: 226.0 us; LPT 204.6, +10.5 %):                  s = 2 / 8 / 16: 259.1 / 250.5 / 250.6 us (-13 / -10 / -10 %); perfect predictor -1 ... +1 %
+# For the 4 Mi-ray batch the idealised scheme is worth +4-5 % before the 1-2.4 % a strided claim order costs in cache locality (profiles/r05_chunk_order_probe.txt:
+# "16-chunk groups, stride" -2.4 %, random chunks -1.7 % on this batch) -- net +2-3 % for a global queue no kernel has; for 1 M-ray batches it loses the taper and 10 %.  Not built.
 """
 
 
