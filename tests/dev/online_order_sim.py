@@ -266,6 +266,9 @@ READING = """# Reading (VERDICT r5 'next' #2: "build only if the simulation reco
 #   C3 1024 x 1024 (natural, taper 12: 226.0 us; LPT 204.6, +10.5 %):                  s = 2 / 8 / 16: 259.1 / 250.5 / 250.6 us (-13 / -10 / -10 %); perfect predictor -1 ... +1 %
 # For the 4 Mi-ray batch the idealised scheme is worth +4-5 % before the 1-2.4 % a strided claim order costs in cache locality (profiles/r05_chunk_order_probe.txt:
 # "16-chunk groups, stride" -2.4 %, random chunks -1.7 % on this batch) -- net +2-3 % for a global queue no kernel has; for 1 M-ray batches it loses the taper and 10 %.  Not built.
+# And the round-4 a-priori predictor (boxes of the TLAS the chunk's middle ray passes; rank correlation 0.61 with the true chunk cost on C3's 4 Mi primaries), applied in the
+# same model: late chunks ordered by it 497.2 us (+1.5 %), all chunks ordered by it 502.8 (+0.4 %) against 504.9 natural -- where perfect knowledge gives +9.3 / +9.7 %.  An
+# in-launch predictor pass is not worth its own cost either.
 """
 
 
