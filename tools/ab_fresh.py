@@ -24,7 +24,8 @@ def main():
         sys.modules[rc.lib.__module__].LIB_PATH = path
     import torch
     sc = rc.scenes
-    label = os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else "in-tree"
+    opts = dict(kv.split("=") for kv in os.environ.get("RC_AB_OPTS", "").split(",") if kv)   # e.g. RC_AB_OPTS=refill=28,pool=256
+    label = (os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else "in-tree") + ("".join(f" {k}={v}" for k, v in opts.items()))
     stream = torch.cuda.current_stream()
 
     def up(a):
@@ -41,7 +42,7 @@ def main():
         return e0.elapsed_time(e1) / (rounds * len(bufs))
 
     def report(name, n, fresh_ms, warm_ms):
-        print(f"[{label:16s}] {name:34s} fresh {n / fresh_ms / 1e3:8.1f} Mrays/s ({fresh_ms:.4f} ms)   same buffer, natural order {n / warm_ms / 1e3:8.1f} Mrays/s ({warm_ms:.4f} ms)", flush=True)
+        print(f"[{label:24s}] {name:34s} fresh {n / fresh_ms / 1e3:8.1f} Mrays/s ({fresh_ms:.4f} ms)   same buffer, natural order {n / warm_ms / 1e3:8.1f} Mrays/s ({warm_ms:.4f} ms)", flush=True)
 
     cfg = sc.config_c3()
     t = rc.TLAS(0)
@@ -50,6 +51,8 @@ def main():
     for b, xf, ids in cfg["instances"]:
         t.push_instances(b, xf, ids)
     t.sync()
+    for k, v in opts.items():
+        t.set_option(k, int(v))
     for res, count in ((2048, 20), (1024, 40)):
         n = res * res
         bufs = [up(sc.c3_primary_rays(cfg, res, res, jitter_seed=100 + i)) for i in range(count)]
@@ -84,6 +87,8 @@ def main():
     t2.add_geometry(*cfg2["blas"][0])
     t2.push_instances(1, cfg2["instances"][0][1], cfg2["instances"][0][2])
     t2.sync()
+    for k, v in opts.items():
+        t2.set_option(k, int(v))
     g = np.random.default_rng(5)
     vd = np.asarray(cfg2["viewdir"], dtype=np.float64)
     bufs = [up(rc.generate_ray_grid(t2, tuple(vd + 0.02 * g.standard_normal(3)), cfg2["grid"])) for _ in range(40)]
