@@ -41,9 +41,10 @@ def hostile_transform(g, kind):
 import os
 
 N_SEEDS = int(os.environ.get("RC_FUZZ_SEEDS", "200"))  # the default -m gpu run; raise for a longer campaign (rounds 1-2: 9000 seeds clean)
+FIRST_SEED = int(os.environ.get("RC_FUZZ_FIRST", "0"))  # a campaign over scenes no earlier campaign has seen: RC_FUZZ_FIRST=27000 RC_FUZZ_SEEDS=60000
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
+@pytest.mark.parametrize("seed", range(FIRST_SEED, FIRST_SEED + N_SEEDS))
 def test_random_hostile_scenes(rc, oracle, seed):
     sc = rc.scenes
     g = np.random.default_rng(1000 + seed)
