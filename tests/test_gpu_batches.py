@@ -133,3 +133,41 @@ def test_capture_and_replay(rc, world):
     for i in range(6):
         assert_hits_equal(d_h[i].cpu().numpy().view(rc.HIT_DT), want[i], f"eager after capture, batch {i}")
     assert t.get_option("claim_drift") == 0
+
+
+def test_two_host_threads_each_with_its_own_stream(rc, world):
+    """The fork / join events and the auxiliary streams are the scene's: calls from several host threads are enqueued one at a time (a mutex around the
+    enqueue, microseconds) and each remains one operation on ITS caller's stream."""
+    import threading
+    import torch
+    cfg, t, o, wb = world
+    sets = []
+    for k in range(2):
+        batches = [random_rays(rc, 90_000 + 777 * (3 * k + i), 300 + 10 * k + i, wb.p_min, wb.p_max) for i in range(3)]
+        sets.append((batches, [o.trace(b, nthreads=8) for b in batches], [upload(torch, b) for b in batches],
+                     [torch.zeros(len(b) * 32, dtype=torch.uint8, device="cuda") for b in batches], torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            batches, want, d_r, d_h, st = sets[k]
+            for rep in range(5):
+                for h in d_h:
+                    h.zero_()
+                torch.cuda.current_stream().synchronize()
+                t.trace_device_batches([x.data_ptr() for x in d_r], [x.data_ptr() for x in d_h], [len(b) for b in batches], stream=st.cuda_stream)
+                st.synchronize()
+                for i in range(3):
+                    assert_hits_equal(d_h[i].cpu().numpy().view(rc.HIT_DT), want[i], f"thread {k} rep {rep} batch {i}")
+        except BaseException as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    t.wait_for_gpu()
+    assert t.get_option("claim_drift") == 0
